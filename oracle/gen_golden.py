@@ -1,0 +1,286 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under ``tests/golden/``.
+
+Run in the authoring container only (it reads ``/root/reference`` and needs
+torch-CPU); the GPU box never runs it.  Fixtures are data: seeds/inputs and
+expected outputs.  Nothing of the reference's source text is written out.
+
+1. ``metrics_*.json`` - the eleven pure-numpy definitions of
+   ``/root/reference/compare_embeddings.py:47-371`` (``rank_concepts`` ...
+   ``q_measure_at_k``) are taken out of the parsed module with ``ast`` (the
+   module itself cannot be imported: ``sentence_transformers`` is absent and its
+   notebook cells open a database connection) and executed on seeded inputs.
+2. ``search_*.npz`` - the published algorithm of ``sentence_transformers.util.
+   cos_sim`` (``F.normalize`` both operands, ``torch.mm``) and the reference's
+   selection primitives (``torch.topk(sorted=True)``, ``np.argsort(-s)[:k]``)
+   executed with torch-CPU / numpy on seeded inputs, next to fp64 truth.
+3. ``adversarial.json`` - what those primitives return on ties, a zero row,
+   NaN scores and k > N (score multisets and index sets).
+4. ``text_to_embed.json`` - one synthetic paper through the string assembly of
+   ``app_create_embeddings.py:48-70`` (the expression is evaluated from the
+   parsed reference module, not retyped).
+"""
+import ast
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+METRIC_FUNCS = [
+    "rank_concepts", "precision_at_k", "hit_at_k", "mrr_at_k", "_generate_qrels",
+    "_get_rels_for_query", "_dcg_from_rels", "ndcg_at_k", "_get_rels_sparse",
+    "err_at_k", "q_measure_at_k",
+]
+
+
+def load_reference_metrics():
+    src = open(os.path.join(REF, "compare_embeddings.py"), encoding="utf-8").read()
+    tree = ast.parse(src)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in METRIC_FUNCS]
+    assert len(keep) == len(METRIC_FUNCS), [n.name for n in keep]
+    ns = {"np": np}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "compare_embeddings.py", "exec"), ns)
+    return ns
+
+
+def metric_cases():
+    """(name, Q, N, seed, qrels-kind, k)"""
+    return [
+        ("q4_n10_identity", 4, 10, 0, "identity", 3),
+        ("q8_n50_identity", 8, 50, 1, "identity", 5),
+        ("q16_n200_graded", 16, 200, 2, "graded", 5),
+        ("q16_n200_graded_k10", 16, 200, 3, "graded", 10),
+        ("q12_n64_paper", 12, 64, 4, "paper", 5),
+    ]
+
+
+def build_qrels(kind, Q, N, rng, ns):
+    if kind == "identity":
+        return {q: {q: 1} for q in range(Q)}
+    if kind == "graded":
+        # exactly one grade-1 document per query, plus 0.5 / 2 / 3 grades
+        out = {}
+        for q in range(Q):
+            docs = rng.choice(N, size=6, replace=False)
+            grades = [1, 0.5, 0.5, 2, 3, 0]
+            out[q] = {int(d): g for d, g in zip(docs, grades)}
+        return out
+    if kind == "paper":
+        # the reference's own generator (grades 0.5 / 0), then one exact match added
+        papers = [f"p{int(i)}" for i in rng.integers(0, 6, size=N)]
+        slogans = [(f"s{j}", papers[j]) for j in range(N)]
+        queries = [(f"q{i}", papers[int(rng.integers(0, N))]) for i in range(Q)]
+        qrels = ns["_generate_qrels"](queries, slogans)
+        for q in range(Q):
+            same = [j for j, g in qrels[q].items() if g == 0.5]
+            qrels[q][same[0] if same else 0] = 1
+        return {"_queries": queries, "_slogans": slogans, "qrels": qrels}
+    raise ValueError(kind)
+
+
+def gen_metrics(ns):
+    for name, Q, N, seed, kind, k in metric_cases():
+        rng = np.random.default_rng(seed)
+        sim = rng.standard_normal((Q, N)).astype(np.float32)
+        qr = build_qrels(kind, Q, N, rng, ns)
+        extra = {}
+        if kind == "paper":
+            extra = {"queries": qr["_queries"], "slogans": qr["_slogans"]}
+            # the un-patched generator output, to pin _generate_qrels itself
+            extra["generated_qrels"] = {str(q): {str(d): g for d, g in v.items()}
+                                        for q, v in ns["_generate_qrels"](qr["_queries"], qr["_slogans"]).items()}
+            qr = qr["qrels"]
+        expected = {
+            "precision_at_k": ns["precision_at_k"](sim, qr, k=k),
+            "precision_at_1": ns["precision_at_k"](sim, qr, k=1),
+            "hit_at_k": ns["hit_at_k"](sim, qr, k=k),
+            "mrr_at_k": ns["mrr_at_k"](sim, qr, k=k),
+            "mrr_all": ns["mrr_at_k"](sim, qr, k=None),
+            "ndcg_at_k": ns["ndcg_at_k"](sim, qr, k=k),
+            "ndcg_linear": ns["ndcg_at_k"](sim, qr, k=k, gain="linear"),
+            "err_at_k": ns["err_at_k"](sim, qr, k=k),
+            "err_maxrel4": ns["err_at_k"](sim, qr, k=k, max_rel=4.0),
+            "q_measure_at_k": ns["q_measure_at_k"](sim, qr, k=k),
+            "rank_row0": [int(i) for i in ns["rank_concepts"](sim)[0]],
+        }
+        doc = {
+            "seed": seed, "Q": Q, "N": N, "k": k, "kind": kind,
+            "recipe": "np.random.default_rng(seed).standard_normal((Q,N)).astype(float32)",
+            "sim_matrix": sim.tolist(),
+            "qrels": {str(q): {str(d): g for d, g in v.items()} for q, v in qr.items()},
+            "expected": expected,
+        }
+        doc.update(extra)
+        with open(os.path.join(OUT, f"metrics_{name}.json"), "w") as f:
+            json.dump(doc, f)
+        print("metrics", name, {k_: v for k_, v in expected.items() if k_ != "rank_row0"})
+
+
+def st_cos_sim(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """Published algorithm of sentence_transformers.util.cos_sim."""
+    if a.dim() == 1:
+        a = a.unsqueeze(0)
+    if b.dim() == 1:
+        b = b.unsqueeze(0)
+    a_n = torch.nn.functional.normalize(a, p=2, dim=1)
+    b_n = torch.nn.functional.normalize(b, p=2, dim=1)
+    return torch.mm(a_n, b_n.transpose(0, 1))
+
+
+def bf16_round(x: np.ndarray) -> np.ndarray:
+    return torch.from_numpy(x).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+def search_cases():
+    """(name, N, B, d, k, metric, dtype, seed, scale) - corpus rows are NOT pre-normalised when metric=cos."""
+    return [
+        ("n1000_b1_k5_cos_f32", 1000, 1, 768, 5, "cos", "f32", 11),
+        ("n1000_b7_k10_cos_f32", 1000, 7, 768, 10, "cos", "f32", 12),
+        ("n4096_b7_k200_cos_f32", 4096, 7, 768, 200, "cos", "f32", 13),
+        ("n4096_b256_k10_ip_bf16", 4096, 256, 768, 10, "ip", "bf16", 14),
+        ("n65537_b1_k10_cos_f32", 65537, 1, 768, 10, "cos", "f32", 15),
+        ("n65537_b7_k1_ip_f32", 65537, 7, 768, 1, "ip", "f32", 16),
+        ("n65537_b256_k10_ip_bf16", 65537, 256, 768, 10, "ip", "bf16", 17),
+        ("n4096_b3_k5_cos_f32_d1024", 4096, 3, 1024, 5, "cos", "f32", 18),
+        ("n20000_b33_k200_cos_bf16", 20000, 33, 768, 200, "cos", "bf16", 19),
+    ]
+
+
+def make_inputs(N, B, d, seed, metric):
+    """Seeded inputs; the recipe lives in oracle.golden_inputs (numpy only, elementwise
+    operations only, so it regenerates bit-identically on any host)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from oracle.oracle import golden_inputs
+    return golden_inputs(N, B, d, seed, metric)
+
+
+def gen_search():
+    for name, N, B, d, k, metric, dtype, seed in search_cases():
+        q, c = make_inputs(N, B, d, seed, metric)
+        if metric == "cos":
+            qn = torch.nn.functional.normalize(torch.from_numpy(q), p=2, dim=1).numpy()
+            cn = torch.nn.functional.normalize(torch.from_numpy(c), p=2, dim=1).numpy()
+        else:
+            qn, cn = q, c
+        if dtype == "bf16":
+            qn, cn = bf16_round(qn), bf16_round(cn)
+        # the reference formulation: normalise (again, for metric=cos on f32 this IS cos_sim) + mm
+        if metric == "cos" and dtype == "f32":
+            S = st_cos_sim(torch.from_numpy(q), torch.from_numpy(c))
+        else:
+            S = torch.mm(torch.from_numpy(qn), torch.from_numpy(cn).T)
+        kk = min(k, N)
+        tk = torch.topk(S, k=kk, dim=1, sorted=True)
+        argsort_idx = np.argsort(-S.numpy(), axis=1)[:, :kk]
+        truth = qn.astype(np.float64) @ cn.astype(np.float64).T
+        order = np.lexsort((np.broadcast_to(np.arange(N), truth.shape), -truth), axis=1)
+        ext = order[:, : min(N, kk + 8)]
+        np.savez_compressed(
+            os.path.join(OUT, f"search_{name}.npz"),
+            N=N, B=B, d=d, k=k, metric=metric, dtype=dtype, seed=seed,
+            torch_topk_idx=tk.indices.numpy().astype(np.int64),
+            torch_topk_scores=tk.values.numpy().astype(np.float32),
+            argsort_idx=argsort_idx.astype(np.int64),
+            truth_idx=ext.astype(np.int64),
+            truth_scores=np.take_along_axis(truth, ext, axis=1),
+        )
+        print("search", name, "top1", tk.indices[0, 0].item(), float(tk.values[0, 0]))
+
+
+def gen_adversarial():
+    out = {}
+    s = np.array([.5, .9, .9, .1, .9, .5], dtype=np.float32)
+    out["ties6"] = {
+        "scores": s.tolist(), "k": 4,
+        "argsort_neg": np.argsort(-s)[:4].tolist(),
+        "argsort_rev": s.argsort()[::-1][:4].tolist(),
+        "torch_topk": torch.topk(torch.from_numpy(s), 4, sorted=True).indices.tolist(),
+    }
+    z = np.zeros(1000, dtype=np.float32)
+    z[[7, 500, 900]] = 1.0
+    out["sparse_ones"] = {
+        "n": 1000, "ones_at": [7, 500, 900], "k": 3,
+        "argsort_neg": np.argsort(-z)[:3].tolist(),
+        "torch_topk": torch.topk(torch.from_numpy(z), 3, sorted=True).indices.tolist(),
+    }
+    n = np.array([0.3, np.nan, 0.7, 0.1], dtype=np.float32)
+    out["nan"] = {
+        "scores": [0.3, None, 0.7, 0.1], "k": 2,
+        "argsort_neg": np.argsort(-n)[:2].tolist(),
+        "argsort_neg_full": np.argsort(-n).tolist(),
+        "torch_topk": torch.topk(torch.from_numpy(n), 2, sorted=True).indices.tolist(),
+    }
+    # zero row through cos_sim: score 0, not NaN
+    a = torch.tensor([[1.0, 2.0, 2.0]])
+    b = torch.tensor([[0.0, 0.0, 0.0], [2.0, 4.0, 4.0], [-1.0, 0.0, 0.0]])
+    out["zero_row"] = {"a": a.tolist(), "b": b.tolist(), "cos_sim": st_cos_sim(a, b).tolist()}
+    # duplicates: rows 3 and 11 equal the query direction
+    rng = np.random.default_rng(77)
+    c = rng.standard_normal((16, 8)).astype(np.float32)
+    qv = rng.standard_normal(8).astype(np.float32)
+    c[3] = 2.0 * qv
+    c[11] = 0.5 * qv
+    S = st_cos_sim(torch.from_numpy(qv), torch.from_numpy(c))[0]
+    out["duplicates"] = {
+        "corpus": c.tolist(), "query": qv.tolist(), "k": 3,
+        "cos_sim": S.tolist(),
+        "torch_topk": torch.topk(S, 3, sorted=True).indices.tolist(),
+        "argsort_neg": np.argsort(-S.numpy())[:3].tolist(),
+    }
+    with open(os.path.join(OUT, "adversarial.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("adversarial", {k: v.get("torch_topk") for k, v in out.items() if "torch_topk" in v})
+
+
+def gen_text():
+    """Evaluate the reference's own f-string / join expressions on a synthetic paper."""
+    src = open(os.path.join(REF, "app_create_embeddings.py"), encoding="utf-8").read()
+    tree = ast.parse(src)
+    gc_expr = tte_expr = None
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Assign) and getattr(node.targets[0], "id", None) == "global_context":
+            gc_expr = node.value
+        if isinstance(node, ast.Dict):
+            for kx, vx in zip(node.keys, node.values):
+                if isinstance(kx, ast.Constant) and kx.value == "text_to_embed":
+                    tte_expr = vx
+    assert gc_expr is not None and tte_expr is not None
+    papers = [
+        {"title": "On trees", "url": "http://example.org/1", "authors": ["A. Author"], "citations": 3,
+         "primary_math_tag": "math.CO", "year": 2020, "source": "arXiv", "journal_published": True,
+         "global_notations": "G denotes a finite graph.", "global_definitions": "A tree is a connected acyclic graph.",
+         "global_assumptions": "",
+         "theorems": [{"type": "theorem", "content": "A tree on $n$ vertices has $n-1$ edges."},
+                      {"type": "lemma", "content": "Every tree with $n\\ge 2$ has a leaf."}]},
+        {"title": "No context", "source": "Stacks Project",
+         "theorems": [{"type": "proposition", "content": "Let $X$ be a scheme."}]},
+    ]
+    cases = []
+    for data in papers:
+        gc = eval(compile(ast.Expression(gc_expr), "gc", "eval"), {"data": data, "filter": filter})
+        for theorem in data["theorems"]:
+            tte = eval(compile(ast.Expression(tte_expr), "tte", "eval"),
+                       {"data": data, "theorem": theorem, "global_context": gc})
+            cases.append({"paper": data, "theorem": theorem, "global_context": gc, "text_to_embed": tte})
+    with open(os.path.join(OUT, "text_to_embed.json"), "w") as f:
+        json.dump(cases, f, indent=1)
+    print("text_to_embed", len(cases), repr(cases[0]["text_to_embed"][:60]))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    ns = load_reference_metrics()
+    gen_metrics(ns)
+    gen_search()
+    gen_adversarial()
+    gen_text()
+
+
+if __name__ == "__main__":
+    sys.exit(main())

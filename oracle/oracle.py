@@ -1,0 +1,509 @@
+"""CPU oracle for the TheoremSearch embedding-similarity + top-k hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``theoremsearch_amd/`` may import this
+module; only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` do, and there only as the checker.
+
+This is a numpy restatement of the arithmetic the reference delegates to
+third-party libraries on its hot path:
+
+* ``sentence_transformers.util.cos_sim`` (unpinned in the reference's
+  ``requirements.txt:9`` / ``ec2/requirements.txt:4``): promote to 2-D, divide
+  every row by ``max(||row||_2, 1e-12)``, then ``a_n @ b_n.T`` in fp32.  Call
+  sites: ``compare_embeddings.py:24,61``, ``app_showcase_model.py:93``,
+  ``app_scratchpad.py:129``, ``test_app.py:76``.
+* selection: ``np.argsort(-scores)[:k]`` (``app_scratchpad.py:130``,
+  ``compare_embeddings.py:52``), ``sims.argsort()[::-1][:top_k]``
+  (``compare_embeddings.py:31``), ``torch.topk(scores, k, sorted=True)``
+  (``app_showcase_model.py:96``): the k largest scores, descending.  The
+  reference's tie order is unspecified, so the oracle fixes the canonical order
+  (score descending, then index ascending) and NaN scores are never returned.
+* pgvector ``<#>`` (negative inner product, fp32) with ``ORDER BY .. ASC LIMIT k``
+  (``streamlit_app.py:253-283``) and the citation-weighted re-rank
+  (``streamlit_app.py:317-364``).
+* the six retrieval metrics of ``compare_embeddings.py:95-371``.
+
+Pinning status: the reference holds no tests or golden vectors for this path
+(SURVEY.md section 4).  The metric restatements are pinned against outputs of the
+reference's own function bodies executed in the authoring container
+(``oracle/gen_golden.py`` -> ``tests/golden/metrics_*.json``).  ``cos_sim`` and
+the selection primitives live in dependencies that are absent from
+``/root/reference``; they are pinned against the published algorithm executed
+with torch-CPU (``F.normalize`` + ``mm``, ``torch.topk``, ``np.argsort``) by
+the same script (``tests/golden/search_*.npz``).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Iterable, List, Mapping, Optional, Sequence, Tuple
+
+import numpy as np
+
+EPS = np.float32(1e-12)
+
+# ----------------------------------------------------------------------------
+# bf16 helpers (round-to-nearest-even, NaN kept a NaN)
+# ----------------------------------------------------------------------------
+
+def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    """fp32 -> bf16 bit patterns (uint16), round-to-nearest-even; NaN stays NaN."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    u = x.view(np.uint32)
+    rounded = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)).astype(np.uint16)
+    nan = np.isnan(x)
+    if nan.any():
+        rounded = np.where(nan, ((u >> np.uint32(16)) | np.uint32(0x0040)).astype(np.uint16), rounded)
+    return rounded
+
+
+def bf16_bits_to_f32(b: np.ndarray) -> np.ndarray:
+    b = np.ascontiguousarray(b, dtype=np.uint16)
+    return (b.astype(np.uint32) << np.uint32(16)).view(np.float32)
+
+
+def round_to_bf16(x: np.ndarray) -> np.ndarray:
+    """fp32 values rounded to the nearest bf16, returned as fp32."""
+    return bf16_bits_to_f32(f32_to_bf16_bits(x))
+
+
+# ----------------------------------------------------------------------------
+# cos_sim / inner product  (sentence_transformers.util.cos_sim semantics)
+# ----------------------------------------------------------------------------
+
+def _as_2d(x) -> np.ndarray:
+    x = np.asarray(x)
+    if x.ndim == 1:
+        x = x[None, :]
+    if x.ndim != 2:
+        raise ValueError("expected a 1-D or 2-D array")
+    return x
+
+
+def l2_normalize(x: np.ndarray) -> np.ndarray:
+    """Row-wise ``x / max(||x||_2, 1e-12)`` in fp32 (``F.normalize(p=2, dim=1)``).
+
+    The squared norm is accumulated in fp64 and rounded once to fp32; the
+    reference's accumulation order is unspecified (it is torch's), so the
+    oracle fixes this one.  A zero row stays zero.
+    """
+    x = _as_2d(x).astype(np.float32, copy=False)
+    ss = np.einsum("ij,ij->i", x.astype(np.float64), x.astype(np.float64))
+    norm = np.sqrt(ss).astype(np.float32)
+    denom = np.maximum(norm, EPS)
+    return (x / denom[:, None]).astype(np.float32)
+
+
+def dot_scores(q: np.ndarray, c: np.ndarray) -> np.ndarray:
+    """``q @ c.T`` in fp32 -> [B x N] (inner product; pgvector ``-(a <#> b)``)."""
+    q = _as_2d(q).astype(np.float32, copy=False)
+    c = _as_2d(c).astype(np.float32, copy=False)
+    return (q @ c.T).astype(np.float32)
+
+
+def cos_sim(a, b) -> np.ndarray:
+    """Restatement of ``util.cos_sim(a, b)``: [B x N] fp32 cosine matrix."""
+    return dot_scores(l2_normalize(a), l2_normalize(b))
+
+
+def scores_fp64(q: np.ndarray, c: np.ndarray) -> np.ndarray:
+    """fp64 "truth" inner products of the same (possibly bf16-rounded) inputs."""
+    return _as_2d(q).astype(np.float64) @ _as_2d(c).astype(np.float64).T
+
+
+# ----------------------------------------------------------------------------
+# selection
+# ----------------------------------------------------------------------------
+
+def topk_canonical(scores: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:
+    """k largest per row, ordered (score desc, index asc); NaN never selected.
+
+    Returns ``(values [B x k] same dtype as scores, indices [B x k] int64)``;
+    rows with fewer than k non-NaN scores are padded with (-inf, -1).
+    Equivalent to ``np.argsort(-s, kind="stable")[:k]`` on NaN-free input
+    (``app_scratchpad.py:130``, ``compare_embeddings.py:52``).
+    """
+    s = _as_2d(scores)
+    B, N = s.shape
+    k = int(k)
+    vals = np.full((B, k), -np.inf, dtype=s.dtype)
+    idx = np.full((B, k), -1, dtype=np.int64)
+    for b in range(B):
+        row = s[b]
+        valid = np.flatnonzero(~np.isnan(row))
+        if valid.size == 0:
+            continue
+        r = row[valid]
+        kk = min(k, valid.size)
+        if valid.size > 4 * kk + 64:
+            # partition first, but keep every element tied with the k-th value
+            part = np.argpartition(-r, kk - 1)[:kk]
+            kth = r[part].min()
+            cand = np.flatnonzero(r >= kth)
+        else:
+            cand = np.arange(valid.size)
+        order = np.lexsort((valid[cand], -r[cand]))[:kk]
+        sel = cand[order]
+        vals[b, :kk] = r[sel]
+        idx[b, :kk] = valid[sel]
+    return vals, idx
+
+
+def search(q: np.ndarray, c: np.ndarray, k: int, metric: str = "ip",
+           dtype: str = "f32") -> Tuple[np.ndarray, np.ndarray]:
+    """Oracle for one brute-force search call.
+
+    metric "cos": both sides L2-normalised first (``util.cos_sim``);
+    metric "ip": inputs used as they are (pgvector ``<#>`` on stored-normalised
+    rows, ``ec2/generate_embeddings/embeddings.py:27,35``).
+    dtype "bf16": corpus rows and queries are rounded to bf16 (after the
+    normalisation) and the product is taken in fp32 on the rounded values.
+    """
+    q = _as_2d(q).astype(np.float32)
+    c = _as_2d(c).astype(np.float32)
+    if metric == "cos":
+        q, c = l2_normalize(q), l2_normalize(c)
+    elif metric != "ip":
+        raise ValueError(metric)
+    if dtype == "bf16":
+        q, c = round_to_bf16(q), round_to_bf16(c)
+    elif dtype != "f32":
+        raise ValueError(dtype)
+    return topk_canonical(dot_scores(q, c), k)
+
+
+def prepared_inputs(q, c, metric="ip", dtype="f32"):
+    """The exact operand values ``search`` multiplies (for fp64 truth checks)."""
+    q = _as_2d(q).astype(np.float32)
+    c = _as_2d(c).astype(np.float32)
+    if metric == "cos":
+        q, c = l2_normalize(q), l2_normalize(c)
+    if dtype == "bf16":
+        q, c = round_to_bf16(q), round_to_bf16(c)
+    return q, c
+
+
+# ----------------------------------------------------------------------------
+# parity protocol ("Hard parts", first item)
+# ----------------------------------------------------------------------------
+
+def check_topk_against_truth(truth_scores: np.ndarray, got_idx: np.ndarray,
+                             got_scores: Optional[np.ndarray], k: int,
+                             gap: float = 1e-6, score_tol: float = 1e-5) -> Dict[str, float]:
+    """Compare a top-k answer with fp64 truth scores of the same inputs.
+
+    A rank position is *pinned* when its fp64 gaps to both neighbours (and, for
+    position k-1, to the (k+1)-th score) exceed ``gap``: there the index must
+    match exactly.  Inside an unpinned run (scores closer than ``gap``) indices
+    must match as a set; the run that straddles the k boundary may pick any of
+    its members.  Scores must be within ``score_tol`` of truth at the returned
+    index.  Raises AssertionError on the first violation; returns statistics.
+    """
+    t = _as_2d(truth_scores)
+    gi = _as_2d(got_idx)
+    B, N = t.shape
+    kk = min(k, N)
+    pinned_total = 0
+    recall_hits = 0
+    for b in range(B):
+        row = t[b].copy()
+        row[np.isnan(row)] = -np.inf
+        order = np.lexsort((np.arange(N), -row))
+        ext = order[: min(N, kk + 64)]
+        sv = row[ext]
+        got = gi[b, :kk]
+        assert len(set(got.tolist())) == kk, f"query {b}: duplicate indices {got}"
+        # split the sorted prefix into runs of near-equal scores
+        pos = 0
+        while pos < kk:
+            end = pos + 1
+            while end < len(ext) and sv[end - 1] - sv[end] <= gap:
+                end += 1
+            members = set(ext[pos:end].tolist())
+            take = min(end, kk) - pos
+            got_run = got[pos:pos + take].tolist()
+            if end - pos == 1:
+                pinned_total += 1
+                assert got_run[0] == ext[pos], (
+                    f"query {b} rank {pos}: got {got_run[0]} want {ext[pos]} "
+                    f"(fp64 scores {row[got_run[0]]!r} vs {sv[pos]!r})")
+            else:
+                assert set(got_run) <= members, (
+                    f"query {b} ranks {pos}..{pos + take}: {got_run} not within tie run {sorted(members)}")
+            pos = end
+        true_set = set(ext[:kk].tolist())
+        kth = sv[kk - 1]
+        for j in got.tolist():
+            if j in true_set or row[j] >= kth - gap:
+                recall_hits += 1
+        if got_scores is not None:
+            gs = _as_2d(got_scores)[b, :kk]
+            ref = row[got]
+            assert np.all(np.abs(gs.astype(np.float64) - ref) <= score_tol), (
+                f"query {b}: scores off by {np.max(np.abs(gs - ref))}")
+        if kk < k:
+            assert np.all(gi[b, kk:] == -1), f"query {b}: padding must be -1"
+    return {"pinned": pinned_total, "positions": B * kk,
+            "recall": recall_hits / float(B * kk) if B * kk else 1.0}
+
+
+def recall_at_k(truth_idx: np.ndarray, got_idx: np.ndarray) -> float:
+    t, g = _as_2d(truth_idx), _as_2d(got_idx)
+    hits = sum(len(set(t[b].tolist()) & set(g[b].tolist())) for b in range(t.shape[0]))
+    return hits / float(t.size)
+
+
+# ----------------------------------------------------------------------------
+# pgvector-shaped search (streamlit_app.py:253-283 and :317-364)
+# ----------------------------------------------------------------------------
+
+def pgvector_search(query_vec: np.ndarray, embeddings: np.ndarray, top_k: int):
+    """``ORDER BY e.embedding <#> q ASC LIMIT k`` with
+    ``similarity = 1.0 - (e.embedding <#> q)`` (``streamlit_app.py:275,282``).
+
+    ``<#>`` is the *negative* inner product, so similarity is ``1 + <e, q>``.
+    Returns (indices int64 [k], similarity float64 [k]).
+    """
+    q = np.asarray(query_vec, dtype=np.float32).reshape(1, -1)
+    ip = dot_scores(q, embeddings)
+    vals, idx = topk_canonical(ip, top_k)
+    dist = -vals[0].astype(np.float64)
+    return idx[0], 1.0 - dist
+
+
+def citation_weighted_rerank(indices: np.ndarray, similarity: np.ndarray,
+                             citations: Sequence[Optional[int]], weight: float, top_k: int):
+    """Re-rank a candidate pool by ``similarity + w * ln(citations)`` when
+    citations > 0 else ``similarity`` (``streamlit_app.py:351-363``); ties broken
+    by similarity descending.  The pool is ``max(50, 10*top_k)`` (``:317``)."""
+    sim = np.asarray(similarity, dtype=np.float64)
+    bonus = np.array([math.log(float(c)) if (c is not None and c > 0) else 0.0 for c in citations])
+    weighted = sim + weight * bonus
+    order = np.lexsort((np.arange(len(sim)), -sim, -weighted))[:top_k]
+    return np.asarray(indices)[order], sim[order], weighted[order]
+
+
+def pool_size(top_k: int) -> int:
+    """``streamlit_app.py:317``."""
+    return max(50, int(top_k) * 10)
+
+
+# ----------------------------------------------------------------------------
+# retrieval metrics (compare_embeddings.py:47-371)
+# ----------------------------------------------------------------------------
+
+def rank_concepts(sim_matrix) -> List[np.ndarray]:
+    """``compare_embeddings.py:47-52``: per row, doc indices by descending score."""
+    return [np.argsort(-np.asarray(row)) for row in sim_matrix]
+
+
+def _ranking(sim_matrix: np.ndarray) -> np.ndarray:
+    return np.argsort(-np.asarray(sim_matrix), axis=1)
+
+
+def _gold_doc(rels: Mapping[int, float]) -> int:
+    # compare_embeddings.py:111,135,158 - first doc whose grade equals 1
+    for doc, grade in rels.items():
+        if grade == 1:
+            return doc
+    raise StopIteration("qrels row has no document with grade 1")
+
+
+def precision_at_k(sim_matrix, qrels, k=5) -> float:
+    """``compare_embeddings.py:95-117``: mean over queries of hit/k."""
+    ranked = _ranking(sim_matrix)
+    vals = []
+    for q in range(ranked.shape[0]):
+        gold = _gold_doc(qrels[q])
+        vals.append((1 if gold in ranked[q, :k] else 0) / k)
+    return float(np.mean(vals))
+
+
+def hit_at_k(sim_matrix, qrels, k=5) -> float:
+    """``compare_embeddings.py:120-140``."""
+    ranked = _ranking(sim_matrix)
+    vals = [1.0 if _gold_doc(qrels[q]) in ranked[q, :k] else 0.0 for q in range(ranked.shape[0])]
+    return float(np.mean(vals))
+
+
+def mrr_at_k(sim_matrix, qrels, k=None) -> float:
+    """``compare_embeddings.py:143-173``."""
+    ranked = _ranking(sim_matrix)
+    vals = []
+    for q in range(ranked.shape[0]):
+        gold = _gold_doc(qrels[q])
+        row = ranked[q] if k is None else ranked[q][:k]
+        where = np.flatnonzero(row == gold)
+        vals.append(1.0 / (int(where[0]) + 1) if where.size else 0.0)
+    return float(np.mean(vals))
+
+
+def generate_qrels(queries, slogans) -> Dict[int, Dict[int, float]]:
+    """``compare_embeddings.py:175-182``: grade 0.5 for a same-paper slogan, else 0."""
+    out = {}
+    for i, (_, paper) in enumerate(queries):
+        out[i] = {j: (0.5 if slogans[j][1] == paper else 0) for j in range(len(slogans))}
+    return out
+
+
+def _grades_in_order(order, rels: Mapping[int, float], k) -> np.ndarray:
+    # compare_embeddings.py:185-193 / :246-254
+    if k is not None:
+        order = order[:k]
+    return np.array([rels.get(int(d), 0.0) for d in order], dtype=float)
+
+
+def _dcg(grades: np.ndarray, gain: str) -> float:
+    # compare_embeddings.py:196-213
+    if grades.size == 0:
+        return 0.0
+    if gain == "exp":
+        g = np.power(2.0, grades) - 1.0
+    elif gain == "linear":
+        g = grades
+    else:
+        raise ValueError(f"Unknown gain scheme: {gain}")
+    return float(np.sum(g * (1.0 / np.log2(np.arange(2, grades.size + 2)))))
+
+
+def ndcg_at_k(sim_matrix, qrels, k=10, gain="exp") -> float:
+    """``compare_embeddings.py:216-243`` (the first argument is the similarity
+    matrix; it is re-argsorted inside, ``:223``)."""
+    ranked = _ranking(sim_matrix)
+    vals = []
+    for q in range(ranked.shape[0]):
+        rels = qrels.get(q, {})
+        dcg = _dcg(_grades_in_order(ranked[q], rels, k), gain)
+        ideal = np.sort(np.array(list(rels.values()), dtype=float))[::-1]
+        if k is not None:
+            ideal = ideal[:k]
+        idcg = _dcg(ideal, gain)
+        vals.append(0.0 if idcg == 0.0 else dcg / idcg)
+    return float(np.mean(vals))
+
+
+def _infer_max_rel(qrels) -> float:
+    # compare_embeddings.py:271-277 / :330-336
+    m = 0.0
+    for rels in qrels.values():
+        if rels:
+            m = max(m, max(rels.values()))
+    return m
+
+
+def err_at_k(sim_matrix, qrels, k=10, max_rel=None) -> float:
+    """``compare_embeddings.py:257-311``."""
+    ranked = _ranking(sim_matrix)
+    if max_rel is None:
+        max_rel = _infer_max_rel(qrels)
+        if max_rel <= 0.0:
+            return 0.0
+    denom = 2.0 ** max_rel
+    vals = []
+    for q in range(ranked.shape[0]):
+        rels = qrels.get(q, None)
+        if not rels:
+            vals.append(0.0)
+            continue
+        grades = _grades_in_order(ranked[q], rels, k)
+        if grades.size == 0:
+            vals.append(0.0)
+            continue
+        p = (np.power(2.0, grades) - 1.0) / denom
+        err, keep_going = 0.0, 1.0
+        for rank, pi in enumerate(p, start=1):
+            if pi > 0.0:
+                err += keep_going * pi * (1.0 / rank)
+            keep_going *= (1.0 - pi)
+            if pi > 0.0 and keep_going <= 1e-12:
+                break
+        vals.append(err)
+    return float(np.mean(vals)) if vals else 0.0
+
+
+def q_measure_at_k(sim_matrix, qrels, k=10, max_rel=None) -> float:
+    """``compare_embeddings.py:315-371``."""
+    ranked = _ranking(sim_matrix)
+    if max_rel is None:
+        max_rel = _infer_max_rel(qrels)
+        if max_rel <= 0.0:
+            return 0.0
+    denom = 2.0 ** max_rel
+    vals = []
+    for q in range(ranked.shape[0]):
+        rels = qrels.get(q, None)
+        if not rels:
+            vals.append(0.0)
+            continue
+        all_gain = (np.power(2.0, np.array(list(rels.values()), dtype=float)) - 1.0) / denom
+        cg_star = all_gain.sum()
+        if cg_star <= 0.0:
+            vals.append(0.0)
+            continue
+        gains = (np.power(2.0, _grades_in_order(ranked[q], rels, k)) - 1.0) / denom
+        cg = acc = 0.0
+        for rank, g in enumerate(gains, start=1):
+            if g > 0.0:
+                cg += g
+                acc += g * (cg / rank)
+        vals.append(acc / cg_star)
+    return float(np.mean(vals)) if vals else 0.0
+
+
+# ----------------------------------------------------------------------------
+# text assembly (app_create_embeddings.py:48-70)
+# ----------------------------------------------------------------------------
+
+def global_context(paper: Mapping) -> str:
+    """``app_create_embeddings.py:48-52``: the three headed blocks joined by a
+    blank line (each block is always non-empty because of its heading)."""
+    parts = [
+        f"**Global Notations:**\n{paper.get('global_notations', '')}",
+        f"**Global Definitions:**\n{paper.get('global_definitions', '')}",
+        f"**Global Assumptions:**\n{paper.get('global_assumptions', '')}",
+    ]
+    return "\n\n".join(p for p in parts if p)
+
+
+def text_to_embed(paper: Mapping, theorem: Mapping) -> str:
+    """``app_create_embeddings.py:69``."""
+    return f"{global_context(paper)}\n\n**{theorem['type'].capitalize()}:**\n{theorem['content']}"
+
+
+# ----------------------------------------------------------------------------
+# synthetic data recipe shared by tests and bench
+# ----------------------------------------------------------------------------
+
+CHUNK_ROWS = 250_000
+
+
+def synth_chunk(chunk_id: int, rows: int = CHUNK_ROWS, d: int = 768, seed: int = 1234,
+                bf16: bool = False) -> np.ndarray:
+    """Chunk ``chunk_id`` of the synthetic corpus: random-normal rows, each
+    L2-normalised in fp32; bf16 configs round after the normalisation.
+    Returns fp32 (``bf16=False``) or uint16 bf16 bit patterns (``bf16=True``)."""
+    x = np.random.default_rng([seed, chunk_id]).standard_normal((rows, d), dtype=np.float32)
+    x = l2_normalize(x)
+    return f32_to_bf16_bits(x) if bf16 else x
+
+
+def synth_queries(batch_id: int, nq: int, d: int = 768, seed: int = 5678, bf16: bool = False) -> np.ndarray:
+    return synth_chunk(batch_id, nq, d, seed, bf16)
+
+
+def golden_inputs(N: int, B: int, d: int, seed: int, metric: str):
+    """Inputs of the ``tests/golden/search_*.npz`` cases (see oracle/gen_golden.py).
+
+    Only elementwise operations, so the arrays regenerate bit-identically on any
+    host.  metric "cos": raw rows with a spread of norms (the normalisation is part
+    of what is tested); metric "ip": rows scaled by 1/sqrt(d) (norm close to 1, like
+    the stored-normalised RDS rows) and used as they are.
+    """
+    c = np.random.default_rng([seed, 0]).standard_normal((N, d), dtype=np.float32)
+    q = np.random.default_rng([seed, 1]).standard_normal((B, d), dtype=np.float32)
+    if metric == "cos":
+        c *= np.random.default_rng([seed, 2]).uniform(0.25, 4.0, size=(N, 1)).astype(np.float32)
+    else:
+        s = np.float32(1.0 / math.sqrt(d))
+        c *= s
+        q *= s
+    return q, c
