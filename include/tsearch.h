@@ -1,0 +1,150 @@
+/*
+ * tsearch.h - C ABI of libtsearch.so, the MI355X (gfx950) brute-force theorem-search engine.
+ *
+ * The reference (uw-math-ai/TheoremSearch) has no FFI of its own: its hot path is Python
+ * calling third-party Python.  These entry points are what a ctypes
+ * binding for that path binds; each one names the reference call it stands in for.  The only
+ * caller in this repository is theoremsearch_amd/_ffi.py; INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types only; every function returns an int status (TS_OK or a negative TS_ERR_*);
+ *     ts_last_error() gives the thread-local message of the last failure.
+ *   - the caller owns every host buffer it passes; the library owns the device memory behind
+ *     the opaque handles.
+ *   - rows are row-major; dtype codes TS_F32 (IEEE binary32) and TS_BF16 (bfloat16 bit patterns,
+ *     uint16_t).
+ *   - search results: for every query, k entries ordered by score descending, then index
+ *     ascending; NaN scores are never returned; when fewer than k rows qualify the tail is
+ *     (score = -inf, index = -1).
+ *   - a stream argument is a hipStream_t passed as void* (NULL = the index's own stream).  With
+ *     host output buffers the call returns after the results have landed; with device buffers
+ *     it returns after enqueueing the work on that stream.
+ *   - one handle may be used from several threads (the Streamlit apps share one model and one
+ *     library across session threads, streamlit_app.py:52); calls on one handle are serialised
+ *     inside, different handles are independent.
+ */
+#ifndef TSEARCH_H
+#define TSEARCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TS_VERSION 100 /* 0.1.0 */
+
+#define TS_OK 0
+#define TS_ERR_INVALID (-1)     /* bad argument */
+#define TS_ERR_HIP (-2)         /* a HIP runtime call failed (message has hipGetErrorString) */
+#define TS_ERR_NOMEM (-3)       /* device or host allocation failed */
+#define TS_ERR_NODEVICE (-4)    /* no usable gfx950 device */
+#define TS_ERR_UNSUPPORTED (-5) /* valid request this build has no kernel for */
+#define TS_ERR_INTERNAL (-6)
+
+#define TS_F32 0
+#define TS_BF16 1
+
+#define TS_METRIC_IP 0  /* inner product: pgvector "<#>" on stored-normalised rows, streamlit_app.py:275-282 */
+#define TS_METRIC_COS 1 /* cosine: sentence_transformers.util.cos_sim, app_showcase_model.py:93 */
+
+#define TS_ALGO_AUTO 0
+#define TS_ALGO_SCAN 1 /* streaming dot-product scan with per-wave running top-k (any dtype, any d) */
+#define TS_ALGO_MFMA 2 /* bf16 MFMA contraction with thresholded candidate selection (bf16 index, d = 768) */
+
+#define TS_MAX_K 256
+
+typedef struct ts_index ts_index;
+typedef struct ts_timer ts_timer;
+
+/* Per-call counters of ts_search_ex (all optional; zero-filled first). */
+typedef struct ts_search_stats {
+    int32_t algo;            /* TS_ALGO_SCAN or TS_ALGO_MFMA actually used */
+    int32_t levels;          /* MFMA path: number of threshold levels run */
+    int32_t fallback_queries; /* MFMA path: queries re-run through the scan (candidate overflow); -1 = not read back */
+    int32_t reserved;
+    int64_t candidates;      /* MFMA path: candidates appended in the last level; -1 = not read back */
+} ts_search_stats;
+
+/* ---- library / device -------------------------------------------------------------------- */
+
+int ts_version(void);
+const char *ts_last_error(void);
+/* Number of visible HIP devices (0 on a CPU-only host; never fails for "no device"). */
+int ts_device_count(int *count);
+int ts_device_info(int device, char *name, int name_len, int64_t *total_mem_bytes, int32_t *compute_units);
+int ts_device_synchronize(int device);
+
+/* ---- the index: the [N x d] theorem-embedding matrix resident in HBM -------------------------
+ * Stands in for the corpus tensor of the in-process form (torch.load of corpus_embeddings.pt,
+ * app_showcase_model.py:52) and for the theorem_embedding_* tables of the in-database form
+ * (rds_schema.sql:43-56).  dtype is the storage type; metric TS_METRIC_COS L2-normalises every
+ * row once at upload (x / max(||x||, 1e-12), what util.cos_sim redoes on every call), then
+ * rounds to bf16 when dtype is TS_BF16.  row_offset is the global id of row 0 (sharded use).
+ */
+int ts_index_create(int device, int64_t n, int32_t d, int dtype, int metric, ts_index **out);
+int ts_index_destroy(ts_index *ix);
+int ts_index_set_row_offset(ts_index *ix, int64_t row_offset);
+/* The index's own HIP stream (hipStream_t as void*): what stream = NULL means in the calls below. */
+int ts_index_stream(const ts_index *ix, void **stream);
+int ts_index_info(const ts_index *ix, int64_t *n, int32_t *d, int32_t *dtype, int32_t *metric,
+                  int64_t *ld_elems, int64_t *row_offset, void **device_rows);
+
+/* Rows [row0, row0 + nrows) from host memory (src_dtype TS_F32 or TS_BF16, dense [nrows x d]).
+ * Replaces building the corpus tensor (app_create_embeddings.py:81-89) and the per-row INSERT /
+ * upsert of vectors (parsed_papers_to_vector_rds/rds.py:37-91, ec2/generate_embeddings/__main__.py:85-99). */
+int ts_index_upload(ts_index *ix, const void *host_rows, int src_dtype, int64_t row0, int64_t nrows);
+/* The same from device memory (row stride src_ld elements), enqueued on `stream`: encoder output
+ * goes straight into the index without a host hop. */
+int ts_index_upload_device(ts_index *ix, const void *dev_rows, int src_dtype, int64_t src_ld,
+                           int64_t row0, int64_t nrows, void *stream);
+/* Stored rows back to the host in the storage dtype, dense [nrows x d] (what the kernels multiply). */
+int ts_index_download(ts_index *ix, void *host_rows, int64_t row0, int64_t nrows);
+
+/* ---- search --------------------------------------------------------------------------------
+ * out_scores [nq x k] float, out_idx [nq x k] int64 (global ids = local row + row_offset).
+ * Replaces  util.cos_sim(q, db)[0] + np.argsort(-s)[:5]        (app_scratchpad.py:129-130)
+ *           util.cos_sim(q, db)[0] + torch.topk(s, k, sorted)   (app_showcase_model.py:93-96)
+ *           ORDER BY e.embedding <#> q ASC LIMIT k              (streamlit_app.py:282-283)
+ * queries: [nq x d] dense, q_dtype TS_F32 or TS_BF16, in host (q_on_device = 0) or device memory.
+ * With metric COS the queries are L2-normalised first; with a bf16 index they are rounded to bf16.
+ * 1 <= k <= TS_MAX_K.
+ */
+int ts_search(ts_index *ix, const void *queries, int q_dtype, int q_on_device, int32_t nq, int32_t k,
+              float *out_scores, int64_t *out_idx, int out_on_device, void *stream);
+int ts_search_ex(ts_index *ix, const void *queries, int q_dtype, int q_on_device, int32_t nq, int32_t k,
+                 float *out_scores, int64_t *out_idx, int out_on_device, void *stream, int algo,
+                 ts_search_stats *stats);
+
+/* Full [nq x n] fp32 score matrix (small N only): util.cos_sim(q_emb, s_emb) of
+ * compare_embeddings.py:24,61.  out row stride is n. */
+int ts_scores(ts_index *ix, const void *queries, int q_dtype, int q_on_device, int32_t nq,
+              float *out, int out_on_device, void *stream);
+
+/* Merge `nparts` partial top-k lists per query (e.g. the all-gathered per-shard results,
+ * SURVEY.md section 8e) into the global top-k_out under the same ordering rule.
+ * scores/idx: [nparts x nq x k_in]; entries with idx < 0 are padding. */
+int ts_merge_topk(int device, const float *scores, const int64_t *idx, int32_t nparts, int32_t nq,
+                  int32_t k_in, int32_t k_out, float *out_scores, int64_t *out_idx, int on_device,
+                  void *stream);
+
+/* ---- kernel timing inside the library ----------------------------------------------------------
+ * With profiling enabled, every launch of the dominant kernel of a search (the full-corpus pass of
+ * the MFMA path, or the scan kernel) is bracketed by a hipEvent pair on the stream it runs on.
+ * ts_index_profile_read waits for the recorded events and returns the number of bracketed launches,
+ * their summed duration and the corpus rows one launch covers; it then clears the record. */
+int ts_index_profile_enable(ts_index *ix, int enable);
+int ts_index_profile_read(ts_index *ix, int64_t *launches, double *total_ms, int64_t *rows_per_launch);
+
+/* ---- timing on a given stream (hipEvent pairs; bench.py measures kernels with these) ------- */
+int ts_timer_create(int device, ts_timer **out);
+int ts_timer_start(ts_timer *t, void *stream);
+int ts_timer_stop(ts_timer *t, void *stream);
+int ts_timer_elapsed_ms(ts_timer *t, float *ms); /* synchronises on the stop event */
+int ts_timer_destroy(ts_timer *t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSEARCH_H */

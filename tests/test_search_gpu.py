@@ -1,0 +1,243 @@
+"""Parity of the HIP search path with the CPU oracle and the committed golden vectors.
+Everything here goes through the C ABI (theoremsearch_amd._ffi -> libtsearch.so)."""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import load_json, load_search_case, search_cases
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+GAP = 1e-6        # fp64 gap below which two ranks count as tied
+SCORE_TOL = 1e-5  # north_star: cosine scores within 1e-5 fp32
+
+
+@pytest.fixture(scope="module")
+def ts():
+    import theoremsearch_amd as ts
+    from theoremsearch_amd import _ffi
+    assert _ffi.device_count() > 0, "GPU tests need a HIP device"
+    return ts
+
+
+def algos_for(dtype, d):
+    return ["scan", "mfma"] if (dtype == "bf16" and d == 768) else ["scan"]
+
+
+def check(q, c, metric, dtype, k, scores, idx):
+    qp, cp = oracle.prepared_inputs(q, c, metric, dtype)
+    truth = oracle.scores_fp64(qp, cp)
+    stats = oracle.check_topk_against_truth(truth, idx, scores, k, gap=GAP, score_tol=SCORE_TOL)
+    assert stats["recall"] == 1.0
+    return stats
+
+
+@pytest.mark.parametrize("name", search_cases())
+def test_golden_cases(ts, name):
+    case = load_search_case(name)
+    q, c = oracle.golden_inputs(case["N"], case["B"], case["d"], case["seed"], case["metric"])
+    k = case["k"]
+    with ts.TheoremIndex.from_embeddings(c, dtype=case["dtype"], metric=case["metric"]) as ix:
+        for algo in algos_for(case["dtype"], case["d"]):
+            scores, idx = ix.search(q, k, algo=algo)
+            stats = check(q, c, case["metric"], case["dtype"], k, scores, idx)
+            # the golden run (torch formulation of the reference) at pinned ranks
+            ts_, ti = case["truth_scores"], case["truth_idx"]
+            gaps = ts_[:, :-1] - ts_[:, 1:]
+            kk = min(k, case["N"])
+            for b in range(case["B"]):
+                for r in range(kk):
+                    lo = gaps[b, r - 1] if r > 0 else np.inf
+                    hi = gaps[b, r] if r < gaps.shape[1] else np.inf
+                    if lo > GAP and hi > GAP:
+                        assert idx[b, r] == case["torch_topk_idx"][b, r] == ti[b, r], (name, algo, b, r)
+            assert stats["pinned"] > 0.9 * stats["positions"]
+
+
+def test_index_rows_match_oracle_preparation(ts):
+    q, c = oracle.golden_inputs(3000, 1, 768, 21, "cos")
+    with ts.TheoremIndex.from_embeddings(c, dtype="f32", metric="cos") as ix:
+        got = ix.download()
+    want = oracle.l2_normalize(c)
+    assert got.shape == want.shape
+    assert np.mean(got == want) > 0.99999 and np.allclose(got, want, rtol=0, atol=1e-7)
+    with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="cos") as ix:
+        gotb = ix.download()
+    wantb = oracle.f32_to_bf16_bits(want)
+    assert np.mean(gotb == wantb) > 0.9999
+    with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as ix:     # plain RNE of the given values
+        assert np.array_equal(ix.download(), oracle.f32_to_bf16_bits(c))
+    with ts.TheoremIndex.from_embeddings(oracle.f32_to_bf16_bits(c), dtype="bf16", metric="ip") as ix:  # stored as given
+        assert np.array_equal(ix.download(), oracle.f32_to_bf16_bits(c))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("n,d,nq,k", [(1, 8, 1, 1), (5, 8, 3, 10), (31, 40, 2, 5), (257, 768, 5, 256),
+                                      (1000, 1024, 9, 7), (4097, 100, 4, 64), (600, 768, 300, 3)])
+def test_ragged_shapes(ts, dtype, n, d, nq, k):
+    rng = np.random.default_rng(n * 7 + d)
+    c = rng.standard_normal((n, d), dtype=np.float32)
+    q = rng.standard_normal((nq, d), dtype=np.float32)
+    with ts.TheoremIndex.from_embeddings(c, dtype=dtype, metric="cos") as ix:
+        for algo in algos_for(dtype, d):
+            scores, idx = ix.search(q, k, algo=algo)
+            assert scores.shape == (nq, k) and idx.shape == (nq, k)
+            check(q, c, "cos", dtype, k, scores, idx)
+            if k > n:
+                assert (idx[:, n:] == -1).all() and np.isneginf(scores[:, n:]).all()
+
+
+def test_adversarial_fixtures(ts):
+    adv = load_json("adversarial.json")
+    dup = adv["duplicates"]
+    c = np.array(dup["corpus"], np.float32)
+    qv = np.array(dup["query"], np.float32)
+    with ts.TheoremIndex.from_embeddings(c, dtype="f32", metric="cos") as ix:
+        scores, idx = ix.search(qv, 3)
+        assert set(idx[0, :2].tolist()) == {3, 11} == set(dup["torch_topk"][:2])
+        assert idx[0, 2] == dup["torch_topk"][2]
+        assert np.allclose(scores[0], np.sort(np.array(dup["cos_sim"], np.float32))[::-1][:3], atol=SCORE_TOL)
+        full = ix.scores(qv)
+        assert np.allclose(full[0], np.array(dup["cos_sim"]), atol=SCORE_TOL)
+    zr = adv["zero_row"]
+    with ts.TheoremIndex.from_embeddings(np.array(zr["b"], np.float32), dtype="f32", metric="cos") as ix:
+        full = ix.scores(np.array(zr["a"], np.float32))
+        assert np.allclose(full, np.array(zr["cos_sim"]), atol=1e-6) and full[0, 0] == 0.0
+        scores, idx = ix.search(np.array(zr["a"], np.float32), 3)
+        assert idx[0].tolist() == [1, 0, 2]
+
+
+def test_exact_ties_resolve_to_lowest_index(ts):
+    rng = np.random.default_rng(8)
+    base = rng.standard_normal((50, 768), dtype=np.float32)
+    c = np.concatenate([base, base, base], axis=0)            # every row three times
+    q = base[:4] + 0.01 * rng.standard_normal((4, 768), dtype=np.float32)
+    for dtype in ("f32", "bf16"):
+        with ts.TheoremIndex.from_embeddings(c, dtype=dtype, metric="cos") as ix:
+            for algo in algos_for(dtype, 768):
+                scores, idx = ix.search(q, 6, algo=algo)
+                want_s, want_i = oracle.search(q, c, 6, "cos", dtype)
+                # duplicates have bit-identical scores on the device: canonical order is exact
+                assert idx[:, :3].tolist() == [[b, b + 50, b + 100] for b in range(4)], (dtype, algo)
+                assert scores[:, 0].tolist() == scores[:, 1].tolist() == scores[:, 2].tolist()
+                check(q, c, "cos", dtype, 6, scores, idx)
+
+
+def test_nan_rows_are_never_returned(ts):
+    rng = np.random.default_rng(9)
+    c = rng.standard_normal((300, 768), dtype=np.float32)
+    c[7, 5] = np.nan
+    c[200, :] = np.nan
+    q = rng.standard_normal((2, 768), dtype=np.float32)
+    for dtype in ("f32", "bf16"):
+        with ts.TheoremIndex.from_embeddings(c, dtype=dtype, metric="ip") as ix:
+            for algo in algos_for(dtype, 768):
+                scores, idx = ix.search(q, 300, algo=algo) if False else ix.search(q, 256, algo=algo)
+                assert 7 not in idx and 200 not in idx
+                assert not np.isnan(scores).any()
+                want_s, want_i = oracle.search(q, c, 256, "ip", dtype)
+                assert set(idx[0].tolist()) == set(want_i[0].tolist())
+
+
+def test_mfma_and_scan_agree_and_levels_run(ts):
+    q, c = oracle.golden_inputs(150_000, 40, 768, 31, "ip")
+    with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as ix:
+        s1, i1, st = ix.search(q, 10, algo="mfma", return_stats=True)
+        s2, i2 = ix.search(q, 10, algo="scan")
+        assert st["algo"] == 2 and st["levels"] >= 2 and st["fallback_queries"] == 0
+        assert 0 < st["candidates"] < 40 * 8192
+        check(q, c, "ip", "bf16", 10, s1, i1)
+        check(q, c, "ip", "bf16", 10, s2, i2)
+        assert np.mean(i1 == i2) > 0.999
+        s3, i3 = ix.search(q, 200, algo="mfma")
+        check(q, c, "ip", "bf16", 200, s3, i3)
+        s4, i4 = ix.search(q[:1], 5)                              # auto picks the MFMA path at this size
+        check(q[:1], c, "ip", "bf16", 5, s4, i4)
+
+
+def test_candidate_overflow_falls_back_exactly(ts):
+    # 20,000 copies of one row that matches query 0: far more ties above any threshold than the
+    # candidate buffer holds -> that query must be re-run by the exact scan
+    rng = np.random.default_rng(10)
+    c = rng.standard_normal((60_000, 768), dtype=np.float32) * np.float32(0.05)
+    hot = rng.standard_normal(768).astype(np.float32)
+    rows = rng.choice(60_000, size=20_000, replace=False)
+    c[rows] = hot
+    q = np.stack([hot, rng.standard_normal(768).astype(np.float32)])
+    with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="cos") as ix:
+        scores, idx, st = ix.search(q, 10, algo="mfma", return_stats=True)
+        assert st["fallback_queries"] >= 1
+        assert idx[0].tolist() == sorted(rows.tolist())[:10]
+        check(q, c, "cos", "bf16", 10, scores, idx)
+
+
+def test_score_matrix_matches_cos_sim(ts):
+    q, c = oracle.golden_inputs(1500, 70, 768, 41, "cos")
+    want = oracle.cos_sim(q, c)
+    for dtype, tol in (("f32", SCORE_TOL),):
+        with ts.TheoremIndex.from_embeddings(c, dtype=dtype, metric="cos") as ix:
+            got = ix.scores(q)
+            assert got.shape == want.shape
+            assert np.max(np.abs(got - want)) <= tol
+            # ranking-by-full-argsort agrees wherever the fp64 gaps are clear (compare_embeddings.py:105)
+            truth = oracle.scores_fp64(*oracle.prepared_inputs(q, c, "cos", dtype))
+            top = np.argsort(-got, axis=1)[:, :5]
+            oracle.check_topk_against_truth(truth, top, None, 5, gap=GAP)
+
+
+def test_merge_topk_matches_numpy(ts):
+    rng = np.random.default_rng(12)
+    nparts, nq, k = 8, 33, 10
+    scores = rng.standard_normal((nparts, nq, k)).astype(np.float32)
+    idx = rng.permutation(nparts * nq * k).reshape(nparts, nq, k).astype(np.int64) + (1 << 33)
+    scores[0, 0, :3] = scores[1, 0, 0]            # ties across parts
+    idx[3, 1, 5:] = -1                            # padding entries
+    scores[3, 1, 5:] = -np.inf
+    got_s, got_i = ts.merge_topk(scores, idx, k)
+    for b in range(nq):
+        s = scores[:, b, :].reshape(-1)
+        i = idx[:, b, :].reshape(-1)
+        keep = i >= 0
+        order = np.lexsort((i[keep], -s[keep]))[:k]
+        assert got_i[b].tolist() == i[keep][order].tolist()
+        assert got_s[b].tolist() == s[keep][order].tolist()
+
+
+def test_sharded_search_equals_whole(ts):
+    # linearity of the top-k reduction: merging per-shard answers gives the whole-index answer,
+    # bit for bit when every part runs the same kernel (same accumulation order per row)
+    q, c = oracle.golden_inputs(40_000, 16, 768, 51, "ip")
+    k = 10
+    bounds = [0, 9_999, 20_000, 33_333, 40_000]
+    for algo in ("mfma", "scan"):
+        with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as whole:
+            ws, wi = whole.search(q, k, algo=algo)
+        parts_s, parts_i = [], []
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            with ts.TheoremIndex.from_embeddings(c[a:b], dtype="bf16", metric="ip", row_offset=a) as shard:
+                s, i = shard.search(q, k, algo=algo)
+                parts_s.append(s)
+                parts_i.append(i)
+        ms, mi = ts.merge_topk(np.stack(parts_s), np.stack(parts_i), k)
+        assert np.array_equal(mi, wi) and np.array_equal(ms, ws), algo
+
+
+def test_empty_and_invalid_arguments(ts):
+    from theoremsearch_amd import _ffi
+    c = np.random.default_rng(1).standard_normal((10, 16), dtype=np.float32)
+    with ts.TheoremIndex.from_embeddings(c) as ix:
+        s, i = ix.search(np.zeros((0, 16), np.float32), 3)
+        assert s.shape == (0, 3)
+        with pytest.raises(_ffi.TSearchError):
+            ix.search(c[:1], 0)
+        with pytest.raises(_ffi.TSearchError):
+            ix.search(c[:1], 257)
+        with pytest.raises(ValueError):
+            ix.search(np.zeros((1, 8), np.float32), 3)
+        with pytest.raises(_ffi.TSearchError):
+            ix.search(c[:1], 3, algo="mfma")          # not a bf16 / d=768 index
+    with ts.TheoremIndex(0, 16) as empty:
+        s, i = empty.search(c[:2], 4)
+        assert (i == -1).all() and np.isneginf(s).all()

@@ -1,0 +1,115 @@
+// Shared device helpers for libtsearch (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ts {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+constexpr int kWave = 64;
+constexpr int kTileRows = 32;      // corpus rows per MFMA tile; index allocations are padded to kRowPad rows
+constexpr int kRowPad = 256;
+constexpr int kLdPad = 64;         // row stride is a multiple of 64 elements, zero padded
+
+// ---- ordered keys -------------------------------------------------------------------------
+// A candidate (score, row) is one 64-bit key whose unsigned order is the result order:
+// larger key = better = (higher score, then lower row).  Key 0 is "empty" (below every real key).
+// NaN scores never become keys (callers test s == s first); -0.0 is folded into +0.0.
+__device__ __forceinline__ u32 ord_f32(float s) {
+    s = s + 0.0f;
+    u32 u = __float_as_uint(s);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unord_f32(u32 o) {
+    u32 u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ u64 make_key(float s, u32 row) {
+    return ((u64)ord_f32(s) << 32) | (u64)(0xFFFFFFFFu - row);
+}
+__device__ __forceinline__ float key_score(u64 k) { return unord_f32((u32)(k >> 32)); }
+__device__ __forceinline__ u32 key_row(u64 k) { return 0xFFFFFFFFu - (u32)k; }
+
+// ---- bf16 ------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_lo(u32 packed) { return __uint_as_float(packed << 16); }
+__device__ __forceinline__ float bf16_hi(u32 packed) { return __uint_as_float(packed & 0xFFFF0000u); }
+__device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __uint_as_float(((u32)b) << 16); }
+// round-to-nearest-even; NaN stays NaN (quiet bit forced) - same rule as oracle.f32_to_bf16_bits
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+    u32 u = __float_as_uint(f);
+    if (f != f) return (unsigned short)((u >> 16) | 0x0040u);
+    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+// ---- wave helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
+    u32 lo = __shfl((int)(u32)v, src, 64);
+    u32 hi = __shfl((int)(u32)(v >> 32), src, 64);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 shfl_up_u64(u64 v, int delta) {
+    u32 lo = __shfl_up((int)(u32)v, delta, 64);
+    u32 hi = __shfl_up((int)(u32)(v >> 32), delta, 64);
+    return ((u64)hi << 32) | lo;
+}
+
+// Per-wave running top-k: slot s = r * 64 + lane holds the s-th best key (descending).
+template <int KR>
+struct WaveTopK {
+    u64 key[KR];
+    u64 thr;  // wave-uniform: key of slot k-1 (0 until k entries are present)
+
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int r = 0; r < KR; ++r) key[r] = 0;
+        thr = 0;
+    }
+    // K must be wave-uniform and non-zero.
+    __device__ __forceinline__ void insert(u64 K, int k, int lane) {
+        int pos = 0;
+#pragma unroll
+        for (int r = 0; r < KR; ++r) pos += __popcll(__ballot(key[r] > K));
+#pragma unroll
+        for (int r = KR - 1; r >= 0; --r) {
+            u64 up = shfl_up_u64(key[r], 1);
+            if (r > 0) {
+                u64 carry = shfl_u64(key[r - 1], 63);
+                if (lane == 0) up = carry;
+            }
+            const int s = r * 64 + lane;
+            key[r] = (s < pos) ? key[r] : (s == pos ? K : up);
+        }
+        const int last = k - 1;
+        u64 t = 0;
+#pragma unroll
+        for (int r = 0; r < KR; ++r)
+            if ((last >> 6) == r) t = shfl_u64(key[r], last & 63);
+        thr = t;
+    }
+};
+
+// Descending bitonic sort of n (power of two) keys in LDS by `nthreads` threads of one workgroup.
+__device__ __forceinline__ void bitonic_sort_desc(u64* keys, int n, int tid, int nthreads) {
+    for (int size = 2; size <= n; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int i = tid; i < (n >> 1); i += nthreads) {
+                const int lo = 2 * i - (i & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const u64 a = keys[lo], b = keys[hi];
+                if ((a < b) == desc) {
+                    keys[lo] = b;
+                    keys[hi] = a;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+}  // namespace ts

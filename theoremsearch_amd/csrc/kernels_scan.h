@@ -1,0 +1,230 @@
+// Streaming scan: scores of a few queries against every corpus row, with a per-wave running
+// top-k in registers.  HBM-bound: each corpus byte is read once per pass with 16-byte-per-lane
+// coalesced loads; one pass serves QB queries.
+//
+// Replaces, for small query batches (the Streamlit apps search one query at a time):
+//   util.cos_sim(query_emb, embeddings_db)[0]            app_showcase_model.py:93, app_scratchpad.py:129
+//   np.argsort(-cosine_scores)[:5] / torch.topk(.., 200) app_scratchpad.py:130, app_showcase_model.py:96
+//   ORDER BY e.embedding <#> q ASC LIMIT k               streamlit_app.py:282-283
+// and is the exact fall-back of the MFMA path when a query's candidate buffer overflows.
+// In EMIT mode it writes the score matrix instead (util.cos_sim of compare_embeddings.py:61).
+//
+// Algorithmic traffic per pass: n * ld * sizeof(elem) bytes (+ QB * ld * 4 for the queries).
+#pragma once
+#include "common.h"
+
+namespace ts {
+
+struct ScanArgs {
+    const void* corpus;   // [n_pad x ld] storage dtype
+    int64_t ld;           // elements per row (multiple of 64)
+    int64_t n;            // real rows
+    const float* qbuf;    // prepared queries, fp32 [* x ld]
+    const int* qlist;     // optional indirection: query ids to run (fallback list); NULL = 0..nq-1
+    const int* qcount;    // optional device count of entries in qlist; NULL = nq
+    int nq;
+    int k;                // entries kept per wave / written per workgroup
+    u64* partial;         // [slot][gridDim.x][k] keys, descending
+    float* scores;        // EMIT: [nq x n]
+};
+
+template <int DT> struct Elem;
+template <> struct Elem<0> { static constexpr int VEC = 4; };
+template <> struct Elem<1> { static constexpr int VEC = 8; };
+
+// dot of one 16-byte chunk with VEC query values, accumulated left to right
+template <int DT>
+__device__ __forceinline__ float chunk_dot(const uint4& v, const float* q, float acc) {
+    if (DT == 0) {
+        acc = fmaf(__uint_as_float(v.x), q[0], acc);
+        acc = fmaf(__uint_as_float(v.y), q[1], acc);
+        acc = fmaf(__uint_as_float(v.z), q[2], acc);
+        acc = fmaf(__uint_as_float(v.w), q[3], acc);
+    } else {
+        acc = fmaf(bf16_lo(v.x), q[0], acc);
+        acc = fmaf(bf16_hi(v.x), q[1], acc);
+        acc = fmaf(bf16_lo(v.y), q[2], acc);
+        acc = fmaf(bf16_hi(v.y), q[3], acc);
+        acc = fmaf(bf16_lo(v.z), q[4], acc);
+        acc = fmaf(bf16_hi(v.z), q[5], acc);
+        acc = fmaf(bf16_lo(v.w), q[6], acc);
+        acc = fmaf(bf16_hi(v.w), q[7], acc);
+    }
+    return acc;
+}
+
+// Sum four per-lane partials over groups of G lanes.  Afterwards every lane holds the complete sum
+// of row rho(lane) = 2*[(lane & G/2) != 0] + [(lane & G/4) != 0] of its group.  Fixed order.
+template <int G>
+__device__ __forceinline__ float reduce4(float v0, float v1, float v2, float v3, int lane) {
+    const bool up = (lane & (G / 2)) != 0;
+    float a = (up ? v2 : v0) + __shfl_xor(up ? v0 : v2, G / 2, 64);
+    float b = (up ? v3 : v1) + __shfl_xor(up ? v1 : v3, G / 2, 64);
+    const bool up2 = (lane & (G / 4)) != 0;
+    float c = (up2 ? b : a) + __shfl_xor(up2 ? a : b, G / 4, 64);
+#pragma unroll
+    for (int off = G / 8; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    return c;
+}
+
+template <int G>
+__device__ __forceinline__ int rho(int lane) {
+    return (((lane & (G / 2)) != 0) ? 2 : 0) + (((lane & (G / 4)) != 0) ? 1 : 0);
+}
+
+// Workgroup epilogue: merge the waves' lists through LDS and write the best k.
+template <int KR>
+__device__ __forceinline__ void wg_merge_store(WaveTopK<KR>& tk, int k, u64* lds, u64* out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int P = 1;
+    while (P < nw * k) P <<= 1;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) lds[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < KR; ++r) {
+        const int s = r * 64 + lane;
+        if (s < k) lds[wave * k + s] = tk.key[r];
+    }
+    bitonic_sort_desc(lds, P, threadIdx.x, blockDim.x);
+    for (int i = threadIdx.x; i < k; i += blockDim.x) out[i] = lds[i];
+    __syncthreads();
+}
+
+constexpr int kScanRB = 4;  // rows per lane group per iteration
+
+// Specialised: row = CH * G chunks of 16 bytes, queries in registers.
+template <int DT, int CH, int G, int QB, int KR, bool EMIT>
+__global__ void __launch_bounds__(256) scan_kernel(ScanArgs a) {
+    constexpr int VEC = Elem<DT>::VEC;
+    constexpr int GROUPS = 64 / G;
+    constexpr int RW = kScanRB * GROUPS;  // rows per wave iteration
+    __shared__ u64 lds_keys[1024];
+    const int lane = threadIdx.x & 63;
+    const int gl = lane & (G - 1);
+    const int grp = lane / G;
+    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t W = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t nblocks = (a.n + RW - 1) / RW;
+    const uint4* __restrict__ base = (const uint4*)a.corpus;
+    const int64_t ld16 = a.ld / VEC;  // row stride in 16-byte chunks
+    const int count = a.qcount ? *a.qcount : a.nq;
+
+    for (int g0 = 0; g0 < count; g0 += QB) {
+        float qv[QB][CH][VEC];
+        int qid[QB];
+#pragma unroll
+        for (int q = 0; q < QB; ++q) {
+            const int slot = (g0 + q < count) ? (g0 + q) : g0;
+            qid[q] = a.qlist ? a.qlist[slot] : slot;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) qv[q][c][e] = a.qbuf[(int64_t)qid[q] * a.ld + (int64_t)(gl + c * G) * VEC + e];
+        }
+        WaveTopK<KR> tk[QB];
+        if (!EMIT) {
+#pragma unroll
+            for (int q = 0; q < QB; ++q) tk[q].init();
+        }
+        for (int64_t blk = gw; blk < nblocks; blk += W) {
+            const int64_t row0 = blk * RW + grp * kScanRB;
+            uint4 v[kScanRB][CH];
+#pragma unroll
+            for (int r = 0; r < kScanRB; ++r)
+#pragma unroll
+                for (int c = 0; c < CH; ++c) v[r][c] = base[(row0 + r) * ld16 + gl + c * G];  // rows < n_pad: in bounds
+            const int myrow = rho<G>(lane);
+            const int64_t row = row0 + myrow;
+            const bool rep = (lane & (G / 4 - 1)) == 0;
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                float acc[kScanRB];
+#pragma unroll
+                for (int r = 0; r < kScanRB; ++r) {
+                    float s = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) s = chunk_dot<DT>(v[r][c], qv[q][c], s);
+                    acc[r] = s;
+                }
+                const float s = reduce4<G>(acc[0], acc[1], acc[2], acc[3], lane);
+                if (EMIT) {
+                    if (rep && row < a.n && g0 + q < count) a.scores[(int64_t)qid[q] * a.n + row] = s;
+                } else {
+                    const u64 key = (rep && row < a.n && s == s) ? make_key(s, (u32)row) : 0ull;
+                    u64 m = __ballot(key > tk[q].thr);
+                    while (m) {
+                        const int src = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const u64 K = shfl_u64(key, src);
+                        if (K > tk[q].thr) tk[q].insert(K, a.k, lane);
+                    }
+                }
+            }
+        }
+        if (!EMIT) {
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                if (g0 + q < count)  // uniform over the workgroup
+                    wg_merge_store<KR>(tk[q], a.k, lds_keys, a.partial + ((int64_t)(g0 + q) * gridDim.x + blockIdx.x) * a.k);
+            }
+        }
+    }
+}
+
+// Generic: any ld (multiple of 64 elements), one query per pass, query staged in LDS.
+template <int DT, int KR, bool EMIT>
+__global__ void __launch_bounds__(256) scan_generic_kernel(ScanArgs a) {
+    constexpr int VEC = Elem<DT>::VEC;
+    constexpr int RW = kScanRB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* lds_keys = (u64*)smem;            // 1024 keys
+    float* lds_q = (float*)(smem + 8192);  // ld floats
+    const int lane = threadIdx.x & 63;
+    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t W = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t nblocks = (a.n + RW - 1) / RW;
+    const uint4* __restrict__ base = (const uint4*)a.corpus;
+    const int64_t ld16 = a.ld / VEC;
+    const int count = a.qcount ? *a.qcount : a.nq;
+
+    for (int g0 = 0; g0 < count; ++g0) {
+        const int qid = a.qlist ? a.qlist[g0] : g0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < a.ld; i += blockDim.x) lds_q[i] = a.qbuf[(int64_t)qid * a.ld + i];
+        __syncthreads();
+        WaveTopK<KR> tk;
+        tk.init();
+        for (int64_t blk = gw; blk < nblocks; blk += W) {
+            const int64_t row0 = blk * RW;
+            float acc[kScanRB] = {0.f, 0.f, 0.f, 0.f};
+            for (int64_t c = lane; c < ld16; c += 64) {
+                float qreg[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) qreg[e] = lds_q[c * VEC + e];
+#pragma unroll
+                for (int r = 0; r < kScanRB; ++r) {
+                    const uint4 v = base[(row0 + r) * ld16 + c];
+                    acc[r] = chunk_dot<DT>(v, qreg, acc[r]);
+                }
+            }
+            const float s = reduce4<64>(acc[0], acc[1], acc[2], acc[3], lane);
+            const int64_t row = row0 + rho<64>(lane);
+            const bool rep = (lane & 15) == 0;
+            if (EMIT) {
+                if (rep && row < a.n) a.scores[(int64_t)qid * a.n + row] = s;
+            } else {
+                const u64 key = (rep && row < a.n && s == s) ? make_key(s, (u32)row) : 0ull;
+                u64 m = __ballot(key > tk.thr);
+                while (m) {
+                    const int src = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const u64 K = shfl_u64(key, src);
+                    if (K > tk.thr) tk.insert(K, a.k, lane);
+                }
+            }
+        }
+        if (!EMIT) wg_merge_store<KR>(tk, a.k, lds_keys, a.partial + ((int64_t)g0 * gridDim.x + blockIdx.x) * a.k);
+    }
+}
+
+}  // namespace ts

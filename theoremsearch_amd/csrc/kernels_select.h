@@ -1,0 +1,172 @@
+// Selection kernels: exact top-k of candidate key lists (bitonic sort in LDS, one workgroup per
+// list segment), the per-level threshold update of the MFMA path, and the cross-shard merge.
+//
+// Replaces the reference's full sorts: np.argsort(-scores)[:k] (app_scratchpad.py:130,
+// compare_embeddings.py:52), torch.topk(scores, k, sorted=True) (app_showcase_model.py:96) and
+// Postgres' top-N heapsort behind ORDER BY ... LIMIT k (streamlit_app.py:282-283).  Order rule:
+// score descending, then row ascending (unsigned order of the 64-bit keys, common.h).
+#pragma once
+#include <math.h>
+
+#include "common.h"
+
+namespace ts {
+
+struct SelectArgs {
+    const u64* in;       // [slot][in_stride] keys (any order; 0 = empty)
+    int64_t in_stride;
+    int m;               // keys per slot
+    int kout;            // keys written per segment
+    u64* out;            // intermediate: [slot][out_stride], segment s writes at s * kout
+    int64_t out_stride;
+    float* out_scores;   // final round (one segment): [query][k_user]
+    int64_t* out_idx;
+    int k_user;
+    int64_t row_offset;
+    const int* qlist;    // optional slot -> query id
+    const int* qcount;   // optional device-side slot count
+};
+
+// grid = (segments, slots); 256 threads; SEG keys of LDS.
+template <int SEG>
+__global__ void __launch_bounds__(256) select_kernel(SelectArgs a) {
+    __shared__ u64 keys[SEG];
+    const int slot = blockIdx.y;
+    if (a.qcount && slot >= *a.qcount) return;
+    const int seg = blockIdx.x;
+    const int begin = seg * SEG;
+    const int cnt = min(SEG, a.m - begin);
+    int P = 1;
+    while (P < cnt) P <<= 1;
+    if (P < 2) P = 2;
+    const u64* src = a.in + (int64_t)slot * a.in_stride + begin;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) keys[i] = (i < cnt) ? src[i] : 0ull;
+    bitonic_sort_desc(keys, P, threadIdx.x, blockDim.x);
+    if (a.out_scores) {
+        const int qid = a.qlist ? a.qlist[slot] : slot;
+        for (int i = threadIdx.x; i < a.k_user; i += blockDim.x) {
+            const u64 key = (i < P) ? keys[i] : 0ull;
+            a.out_scores[(int64_t)qid * a.k_user + i] = key ? key_score(key) : -INFINITY;
+            a.out_idx[(int64_t)qid * a.k_user + i] = key ? (int64_t)key_row(key) + a.row_offset : -1;
+        }
+    } else {
+        u64* dst = a.out + (int64_t)slot * a.out_stride + (int64_t)seg * a.kout;
+        for (int i = threadIdx.x; i < a.kout; i += blockDim.x) dst[i] = (i < P) ? keys[i] : 0ull;
+    }
+}
+
+// MFMA path, after each threshold level: one workgroup per query sorts that query's candidates.
+//   sample level: thr[q] = score of the kk-th best candidate (-inf if fewer), count reset to 0.
+//   final level : writes the k results, or appends q to the fall-back list when the candidate
+//                 buffer overflowed (count > cap: some candidates were dropped).
+struct LevelArgs {
+    u64* cand;           // [nq][cap]
+    u32* count;          // [nq] appended so far (may exceed cap)
+    int cap;
+    int kk;              // threshold rank, >= k_user
+    float* thr;          // [256]
+    int final_level;
+    float* out_scores;
+    int64_t* out_idx;
+    int k_user;
+    int64_t row_offset;
+    int* fb_list;
+    int* fb_count;
+    unsigned long long* stat_candidates;  // sum of counts seen at the final level
+};
+
+__global__ void __launch_bounds__(512) level_select_kernel(LevelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* keys = (u64*)smem;
+    const int q = blockIdx.x;
+    const u32 raw = a.count[q];
+    const int cnt = (int)min(raw, (u32)a.cap);
+    int P = 2;
+    while (P < cnt) P <<= 1;
+    const u64* src = a.cand + (int64_t)q * a.cap;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) keys[i] = (i < cnt) ? src[i] : 0ull;
+    bitonic_sort_desc(keys, P, threadIdx.x, blockDim.x);
+    if (!a.final_level) {
+        if (threadIdx.x == 0) {
+            const u64 key = (a.kk - 1 < P) ? keys[a.kk - 1] : 0ull;
+            a.thr[q] = key ? key_score(key) : -INFINITY;
+            a.count[q] = 0;
+        }
+        return;
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(a.stat_candidates, (unsigned long long)raw);
+        a.count[q] = 0;
+    }
+    if (raw > (u32)a.cap) {
+        if (threadIdx.x == 0) a.fb_list[atomicAdd(a.fb_count, 1)] = q;
+        return;
+    }
+    for (int i = threadIdx.x; i < a.k_user; i += blockDim.x) {
+        const u64 key = (i < P) ? keys[i] : 0ull;
+        a.out_scores[(int64_t)q * a.k_user + i] = key ? key_score(key) : -INFINITY;
+        a.out_idx[(int64_t)q * a.k_user + i] = key ? (int64_t)key_row(key) + a.row_offset : -1;
+    }
+}
+
+// Cross-shard merge: per query, nparts * k_in (score, global id) pairs ->
+// best k_out.  Global ids are 64-bit here, so the sort runs on (ordered score, id) pairs.
+struct MergeArgs {
+    const float* scores;   // [nparts][nq][k_in]
+    const int64_t* idx;
+    int nparts, nq, k_in, k_out;
+    float* out_scores;     // [nq][k_out]
+    int64_t* out_idx;
+};
+
+constexpr int kMergeMax = 4096;
+
+__global__ void __launch_bounds__(256) merge_kernel(MergeArgs a) {
+    __shared__ u32 so[kMergeMax];
+    __shared__ int64_t si[kMergeMax];
+    const int q = blockIdx.x;
+    const int m = a.nparts * a.k_in;
+    int P = 2;
+    while (P < m) P <<= 1;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        u32 o = 0;
+        int64_t id = INT64_MAX;
+        if (i < m) {
+            const int part = i / a.k_in, j = i - part * a.k_in;
+            const int64_t off = ((int64_t)part * a.nq + q) * a.k_in + j;
+            const float s = a.scores[off];
+            const int64_t r = a.idx[off];
+            if (r >= 0 && s == s) {
+                o = ord_f32(s);
+                id = r;
+            }
+        }
+        so[i] = o;
+        si[i] = id;
+    }
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < (P >> 1); i += blockDim.x) {
+                const int lo = 2 * i - (i & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const u32 ao = so[lo], bo = so[hi];
+                const int64_t ai = si[lo], bi = si[hi];
+                const bool a_worse = (ao < bo) || (ao == bo && ai > bi);
+                if (a_worse == desc && !(ao == bo && ai == bi)) {
+                    so[lo] = bo; si[lo] = bi;
+                    so[hi] = ao; si[hi] = ai;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.k_out; i += blockDim.x) {
+        const bool ok = i < P && si[i] != INT64_MAX;
+        a.out_scores[(int64_t)q * a.k_out + i] = ok ? unord_f32(so[i]) : -INFINITY;
+        a.out_idx[(int64_t)q * a.k_out + i] = ok ? si[i] : -1;
+    }
+}
+
+}  // namespace ts

@@ -1,0 +1,812 @@
+// libtsearch.so - C ABI (include/tsearch.h) over the gfx950 kernels.  Host side only in this file:
+// argument checking, device memory, launch sequencing.  No CPU compute path exists: without a
+// HIP device every compute entry point fails with TS_ERR_NODEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/tsearch.h"
+#include "common.h"
+#include "kernels_mfma.h"
+#include "kernels_prep.h"
+#include "kernels_scan.h"
+#include "kernels_select.h"
+
+using namespace ts;
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? TS_ERR_NOMEM : TS_ERR_HIP, "%s failed: %s (%s:%d)", \
+                        #expr, hipGetErrorString(e_), __FILE__, __LINE__);                              \
+    } while (0)
+
+#define TS_TRY(expr)            \
+    do {                        \
+        int rc_ = (expr);       \
+        if (rc_ != TS_OK) return rc_; \
+    } while (0)
+
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+// ---------------------------------------------------------------------------------------------
+// handles
+// ---------------------------------------------------------------------------------------------
+constexpr int kQBlock = 256;          // queries per pass of the search driver
+constexpr int kCandCap = 8192;        // candidate slots per query (MFMA path)
+constexpr int kScanGridPerCU = 4;
+constexpr size_t kStageBytes = (size_t)256 << 20;
+
+struct ts_index {
+    int device = 0;
+    int64_t n = 0, n_pad = 0, ld = 0, row_offset = 0;
+    int d = 0, dtype = 0, metric = 0;
+    int cu_count = 256;
+    void* rows = nullptr;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    // scratch (lazily sized)
+    void* stage = nullptr;      size_t stage_bytes = 0;      // host->device staging
+    void* qstore = nullptr;     float* qf32 = nullptr;       // prepared queries [256 x ld]
+    u64* cand = nullptr;        u32* count = nullptr;        float* thr = nullptr;
+    int* fb_list = nullptr;     int* fb_count = nullptr;     unsigned long long* stat = nullptr;
+    u64* partial = nullptr;     u64* partial2 = nullptr;     size_t partial_bytes = 0;
+    float* res_scores = nullptr; int64_t* res_idx = nullptr; size_t res_cap = 0;  // device result buffers (entries)
+    bool attr_done = false;
+    // optional event brackets around the dominant kernel (ts_index_profile_*)
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;   // pairs: [2i] start, [2i+1] stop
+    size_t ev_used = 0;                // events handed out since the last read
+    int64_t prof_rows = 0;
+    size_t elem() const { return dtype == TS_BF16 ? 2 : 4; }
+};
+
+struct ts_timer {
+    int device = 0;
+    hipEvent_t a = nullptr, b = nullptr;
+};
+
+static int ensure(void** p, size_t* have, size_t want) {
+    if (*have >= want && *p) return TS_OK;
+    if (*p) HIP_TRY(hipFree(*p));
+    *p = nullptr;
+    *have = 0;
+    HIP_TRY(hipMalloc(p, want));
+    *have = want;
+    return TS_OK;
+}
+
+// Event bracket around one launch: prof_begin records the start event and returns the stop event
+// (NULL when profiling is off); the caller records it with prof_end after the launch.
+static hipEvent_t prof_begin(ts_index* ix, hipStream_t st, int64_t rows) {
+    if (!ix->profiling) return nullptr;
+    if (ix->ev_used + 2 > ix->ev_pool.size()) {
+        if (ix->ev_pool.size() >= 16384) return nullptr;
+        hipEvent_t a = nullptr, b = nullptr;
+        if (hipEventCreate(&a) != hipSuccess) return nullptr;
+        if (hipEventCreate(&b) != hipSuccess) { hipEventDestroy(a); return nullptr; }
+        ix->ev_pool.push_back(a);
+        ix->ev_pool.push_back(b);
+    }
+    hipEvent_t start = ix->ev_pool[ix->ev_used], stop = ix->ev_pool[ix->ev_used + 1];
+    ix->ev_used += 2;
+    ix->prof_rows = rows;
+    hipEventRecord(start, st);
+    return stop;
+}
+static void prof_end(hipEvent_t stop, hipStream_t st) {
+    if (stop) hipEventRecord(stop, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// library / device
+// ---------------------------------------------------------------------------------------------
+extern "C" int ts_version(void) { return TS_VERSION; }
+extern "C" const char* ts_last_error(void) { return g_err; }
+
+extern "C" int ts_device_count(int* count) {
+    if (!count) return fail(TS_ERR_INVALID, "count is NULL");
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+    (void)hipGetLastError();
+    *count = c;
+    return TS_OK;
+}
+
+static int check_device(int device) {
+    int c = 0;
+    ts_device_count(&c);
+    if (c <= 0) return fail(TS_ERR_NODEVICE, "no HIP device visible (libtsearch has no CPU path)");
+    if (device < 0 || device >= c) return fail(TS_ERR_INVALID, "device %d out of range [0, %d)", device, c);
+    return TS_OK;
+}
+
+extern "C" int ts_device_info(int device, char* name, int name_len, int64_t* total_mem, int32_t* cus) {
+    TS_TRY(check_device(device));
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, device));
+    if (name && name_len > 0) snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName);
+    if (total_mem) *total_mem = (int64_t)p.totalGlobalMem;
+    if (cus) *cus = p.multiProcessorCount;
+    return TS_OK;
+}
+
+extern "C" int ts_device_synchronize(int device) {
+    TS_TRY(check_device(device));
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipDeviceSynchronize());
+    return TS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// index
+// ---------------------------------------------------------------------------------------------
+extern "C" int ts_index_create(int device, int64_t n, int32_t d, int dtype, int metric, ts_index** out) {
+    if (!out) return fail(TS_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (n < 0 || n > 0xFFFFFFF0ll) return fail(TS_ERR_INVALID, "n = %lld out of range", (long long)n);
+    if (d <= 0 || d > 16384) return fail(TS_ERR_INVALID, "d = %d out of range [1, 16384]", d);
+    if (dtype != TS_F32 && dtype != TS_BF16) return fail(TS_ERR_INVALID, "dtype %d", dtype);
+    if (metric != TS_METRIC_IP && metric != TS_METRIC_COS) return fail(TS_ERR_INVALID, "metric %d", metric);
+    TS_TRY(check_device(device));
+    HIP_TRY(hipSetDevice(device));
+    ts_index* ix = new (std::nothrow) ts_index();
+    if (!ix) return fail(TS_ERR_NOMEM, "host allocation failed");
+    ix->device = device;
+    ix->n = n;
+    ix->n_pad = std::max<int64_t>(kRowPad, (n + kRowPad - 1) / kRowPad * kRowPad);
+    ix->d = d;
+    ix->ld = (d + kLdPad - 1) / kLdPad * kLdPad;
+    ix->dtype = dtype;
+    ix->metric = metric;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) == hipSuccess) ix->cu_count = p.multiProcessorCount;
+    const size_t bytes = (size_t)ix->n_pad * ix->ld * ix->elem();
+    hipError_t e = hipMalloc(&ix->rows, bytes);
+    if (e != hipSuccess) {
+        delete ix;
+        return fail(TS_ERR_NOMEM, "hipMalloc of %zu bytes for the index failed: %s", bytes, hipGetErrorString(e));
+    }
+    e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMemsetAsync(ix->rows, 0, bytes, ix->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+    if (e != hipSuccess) {
+        hipFree(ix->rows);
+        delete ix;
+        return fail(TS_ERR_HIP, "index initialisation failed: %s", hipGetErrorString(e));
+    }
+    *out = ix;
+    return TS_OK;
+}
+
+extern "C" int ts_index_destroy(ts_index* ix) {
+    if (!ix) return TS_OK;
+    hipSetDevice(ix->device);
+    if (ix->stream) hipStreamSynchronize(ix->stream);
+    void* ptrs[] = {ix->rows,  ix->stage,   ix->qstore,   ix->qf32,     ix->cand,       ix->count,  ix->thr,
+                    ix->fb_list, ix->fb_count, ix->stat, ix->partial, ix->partial2, ix->res_scores, ix->res_idx};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    for (hipEvent_t e : ix->ev_pool) hipEventDestroy(e);
+    if (ix->stream) hipStreamDestroy(ix->stream);
+    delete ix;
+    return TS_OK;
+}
+
+extern "C" int ts_index_set_row_offset(ts_index* ix, int64_t off) {
+    if (!ix || off < 0) return fail(TS_ERR_INVALID, "bad argument");
+    ix->row_offset = off;
+    return TS_OK;
+}
+
+extern "C" int ts_index_stream(const ts_index* ix, void** stream) {
+    if (!ix || !stream) return fail(TS_ERR_INVALID, "NULL argument");
+    *stream = (void*)ix->stream;
+    return TS_OK;
+}
+
+extern "C" int ts_index_info(const ts_index* ix, int64_t* n, int32_t* d, int32_t* dtype, int32_t* metric, int64_t* ld,
+                             int64_t* row_offset, void** rows) {
+    if (!ix) return fail(TS_ERR_INVALID, "index is NULL");
+    if (n) *n = ix->n;
+    if (d) *d = ix->d;
+    if (dtype) *dtype = ix->dtype;
+    if (metric) *metric = ix->metric;
+    if (ld) *ld = ix->ld;
+    if (row_offset) *row_offset = ix->row_offset;
+    if (rows) *rows = ix->rows;
+    return TS_OK;
+}
+
+template <int SRC, int DST>
+static void launch_prep(bool normalize, const void* src, int64_t src_ld, void* dst, float* f32copy, int64_t ld, int d,
+                        int64_t nrows, int64_t rows_total, hipStream_t st) {
+    const int64_t waves = std::max<int64_t>(1, rows_total);
+    const int grid = (int)std::min<int64_t>((waves + 3) / 4, 4096);
+    if (normalize)
+        prep_rows_kernel<SRC, DST, true><<<grid, 256, 0, st>>>(src, src_ld, dst, f32copy, ld, d, nrows, rows_total);
+    else
+        prep_rows_kernel<SRC, DST, false><<<grid, 256, 0, st>>>(src, src_ld, dst, f32copy, ld, d, nrows, rows_total);
+}
+
+static int prep_dispatch(int src_dtype, int dst_dtype, bool normalize, const void* src, int64_t src_ld, void* dst,
+                         float* f32copy, int64_t ld, int d, int64_t nrows, int64_t rows_total, hipStream_t st) {
+    if (src_dtype == TS_F32 && dst_dtype == TS_F32)
+        launch_prep<0, 0>(normalize, src, src_ld, dst, f32copy, ld, d, nrows, rows_total, st);
+    else if (src_dtype == TS_F32 && dst_dtype == TS_BF16)
+        launch_prep<0, 1>(normalize, src, src_ld, dst, f32copy, ld, d, nrows, rows_total, st);
+    else if (src_dtype == TS_BF16 && dst_dtype == TS_F32)
+        launch_prep<1, 0>(normalize, src, src_ld, dst, f32copy, ld, d, nrows, rows_total, st);
+    else
+        launch_prep<1, 1>(normalize, src, src_ld, dst, f32copy, ld, d, nrows, rows_total, st);
+    HIP_TRY(hipGetLastError());
+    return TS_OK;
+}
+
+static int check_rows(const ts_index* ix, const void* p, int src_dtype, int64_t row0, int64_t nrows) {
+    if (!ix || !p) return fail(TS_ERR_INVALID, "NULL argument");
+    if (src_dtype != TS_F32 && src_dtype != TS_BF16) return fail(TS_ERR_INVALID, "src_dtype %d", src_dtype);
+    if (row0 < 0 || nrows < 0 || row0 + nrows > ix->n)
+        return fail(TS_ERR_INVALID, "rows [%lld, %lld) outside the index of %lld rows", (long long)row0,
+                    (long long)(row0 + nrows), (long long)ix->n);
+    return TS_OK;
+}
+
+extern "C" int ts_index_upload_device(ts_index* ix, const void* dev_rows, int src_dtype, int64_t src_ld, int64_t row0,
+                                      int64_t nrows, void* stream) {
+    TS_TRY(check_rows(ix, dev_rows, src_dtype, row0, nrows));
+    if (src_ld < ix->d) return fail(TS_ERR_INVALID, "src_ld %lld < d %d", (long long)src_ld, ix->d);
+    if (nrows == 0) return TS_OK;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
+    char* dst = (char*)ix->rows + (size_t)row0 * ix->ld * ix->elem();
+    return prep_dispatch(src_dtype, ix->dtype, ix->metric == TS_METRIC_COS, dev_rows, src_ld, dst, nullptr, ix->ld, ix->d,
+                         nrows, nrows, st);
+}
+
+extern "C" int ts_index_upload(ts_index* ix, const void* host_rows, int src_dtype, int64_t row0, int64_t nrows) {
+    TS_TRY(check_rows(ix, host_rows, src_dtype, row0, nrows));
+    if (nrows == 0) return TS_OK;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    const size_t src_elem = src_dtype == TS_BF16 ? 2 : 4;
+    const size_t src_row = (size_t)ix->d * src_elem;
+    if (src_dtype == ix->dtype && ix->metric == TS_METRIC_IP && ix->ld == ix->d) {
+        // stored as given: straight copy into place
+        HIP_TRY(hipMemcpy((char*)ix->rows + (size_t)row0 * src_row, host_rows, (size_t)nrows * src_row, hipMemcpyHostToDevice));
+        return TS_OK;
+    }
+    TS_TRY(ensure(&ix->stage, &ix->stage_bytes, kStageBytes));
+    const int64_t rows_per = std::max<int64_t>(1, (int64_t)(kStageBytes / src_row));
+    for (int64_t r = 0; r < nrows; r += rows_per) {
+        const int64_t cnt = std::min(rows_per, nrows - r);
+        HIP_TRY(hipMemcpyAsync(ix->stage, (const char*)host_rows + (size_t)r * src_row, (size_t)cnt * src_row,
+                               hipMemcpyHostToDevice, ix->stream));
+        char* dst = (char*)ix->rows + (size_t)(row0 + r) * ix->ld * ix->elem();
+        TS_TRY(prep_dispatch(src_dtype, ix->dtype, ix->metric == TS_METRIC_COS, ix->stage, ix->d, dst, nullptr, ix->ld,
+                             ix->d, cnt, cnt, ix->stream));
+        HIP_TRY(hipStreamSynchronize(ix->stream));  // the stage buffer is reused by the next chunk
+    }
+    return TS_OK;
+}
+
+extern "C" int ts_index_download(ts_index* ix, void* host_rows, int64_t row0, int64_t nrows) {
+    TS_TRY(check_rows(ix, host_rows, ix ? ix->dtype : 0, row0, nrows));
+    if (nrows == 0) return TS_OK;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    const size_t row_bytes = (size_t)ix->d * ix->elem();
+    TS_TRY(ensure(&ix->stage, &ix->stage_bytes, kStageBytes));
+    const int64_t rows_per = std::max<int64_t>(1, (int64_t)(kStageBytes / row_bytes));
+    for (int64_t r = 0; r < nrows; r += rows_per) {
+        const int64_t cnt = std::min(rows_per, nrows - r);
+        const char* src = (const char*)ix->rows + (size_t)(row0 + r) * ix->ld * ix->elem();
+        if (ix->dtype == TS_F32)
+            unpad_rows_kernel<0><<<1024, 256, 0, ix->stream>>>(src, ix->ld, ix->stage, ix->d, cnt);
+        else
+            unpad_rows_kernel<1><<<1024, 256, 0, ix->stream>>>(src, ix->ld, ix->stage, ix->d, cnt);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync((char*)host_rows + (size_t)r * row_bytes, ix->stage, (size_t)cnt * row_bytes,
+                               hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipStreamSynchronize(ix->stream));
+    }
+    return TS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// search
+// ---------------------------------------------------------------------------------------------
+__global__ void init_thr_kernel(float* thr, int nq) {
+    const int i = threadIdx.x;
+    if (i < kMfmaQ) thr[i] = (i < nq) ? -INFINITY : INFINITY;
+}
+
+static int ensure_search_scratch(ts_index* ix, int k) {
+    size_t z = 0;
+    if (!ix->qstore) {
+        void* p = nullptr;
+        z = 0;
+        TS_TRY(ensure(&p, &z, (size_t)kQBlock * ix->ld * ix->elem()));
+        ix->qstore = p;
+        p = nullptr; z = 0;
+        TS_TRY(ensure(&p, &z, (size_t)kQBlock * ix->ld * 4));
+        ix->qf32 = (float*)p;
+        p = nullptr; z = 0;
+        TS_TRY(ensure(&p, &z, (size_t)kQBlock * 4));
+        ix->count = (u32*)p;
+        HIP_TRY(hipMemset(ix->count, 0, kQBlock * 4));
+        p = nullptr; z = 0;
+        TS_TRY(ensure(&p, &z, (size_t)kQBlock * 4));
+        ix->thr = (float*)p;
+        p = nullptr; z = 0;
+        TS_TRY(ensure(&p, &z, (size_t)kQBlock * 4));
+        ix->fb_list = (int*)p;
+        p = nullptr; z = 0;
+        TS_TRY(ensure(&p, &z, 16));
+        ix->fb_count = (int*)p;
+        p = nullptr; z = 0;
+        TS_TRY(ensure(&p, &z, 16));
+        ix->stat = (unsigned long long*)p;
+    }
+    if (!ix->cand && ix->dtype == TS_BF16 && ix->d == kMfmaD) {
+        void* p = nullptr;
+        z = 0;
+        TS_TRY(ensure(&p, &z, (size_t)kQBlock * kCandCap * 8));
+        ix->cand = (u64*)p;
+    }
+    // scan partials: [256 slots][grid][k] keys, twice (ping-pong for the select rounds)
+    const size_t grid = (size_t)ix->cu_count * kScanGridPerCU;
+    const size_t want = (size_t)kQBlock * grid * (size_t)k * 8;
+    if (ix->partial_bytes < want) {
+        if (ix->partial) HIP_TRY(hipFree(ix->partial));
+        if (ix->partial2) HIP_TRY(hipFree(ix->partial2));
+        ix->partial = ix->partial2 = nullptr;
+        ix->partial_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&ix->partial, want));
+        HIP_TRY(hipMalloc((void**)&ix->partial2, want / 8 + 4096 * 8));
+        ix->partial_bytes = want;
+    }
+    return TS_OK;
+}
+
+template <int DT, int CH, int G, bool EMIT>
+static void launch_scan_spec(int qb, int kr, int grid, hipStream_t st, const ScanArgs& a) {
+    if (EMIT) {
+        if (qb == 4) scan_kernel<DT, CH, G, 4, 1, true><<<grid, 256, 0, st>>>(a);
+        else scan_kernel<DT, CH, G, 1, 1, true><<<grid, 256, 0, st>>>(a);
+        return;
+    }
+    if (qb == 4) {
+        if (kr == 1) scan_kernel<DT, CH, G, 4, 1, false><<<grid, 256, 0, st>>>(a);
+        else scan_kernel<DT, CH, G, 4, 4, false><<<grid, 256, 0, st>>>(a);
+    } else {
+        if (kr == 1) scan_kernel<DT, CH, G, 1, 1, false><<<grid, 256, 0, st>>>(a);
+        else scan_kernel<DT, CH, G, 1, 4, false><<<grid, 256, 0, st>>>(a);
+    }
+}
+
+template <int DT, bool EMIT>
+static void launch_scan_generic(int kr, int grid, hipStream_t st, const ScanArgs& a) {
+    const size_t lds = 8192 + (size_t)a.ld * 4;
+    if (EMIT || kr == 1) {
+        auto kern = scan_generic_kernel<DT, 1, EMIT>;
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        kern<<<grid, 256, lds, st>>>(a);
+    } else {
+        auto kern = scan_generic_kernel<DT, 4, EMIT>;
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        kern<<<grid, 256, lds, st>>>(a);
+    }
+}
+
+// One scan pass configuration for (dtype, ld); returns the query-batch width used.
+template <bool EMIT>
+static int launch_scan(const ts_index* ix, ScanArgs a, int qb_pref, hipStream_t st, int grid) {
+    const int kr = (a.k <= 64) ? 1 : 4;
+    const bool force_generic = env_int("TS_SCAN_GENERIC", 0) != 0;
+    if (!force_generic && ix->dtype == TS_F32 && ix->ld == 768) { launch_scan_spec<0, 3, 64, EMIT>(qb_pref, kr, grid, st, a); return qb_pref; }
+    if (!force_generic && ix->dtype == TS_F32 && ix->ld == 1024) { launch_scan_spec<0, 4, 64, EMIT>(qb_pref, kr, grid, st, a); return qb_pref; }
+    if (!force_generic && ix->dtype == TS_BF16 && ix->ld == 768) { launch_scan_spec<1, 3, 32, EMIT>(qb_pref, kr, grid, st, a); return qb_pref; }
+    if (!force_generic && ix->dtype == TS_BF16 && ix->ld == 1024) { launch_scan_spec<1, 2, 64, EMIT>(qb_pref, kr, grid, st, a); return qb_pref; }
+    if (ix->dtype == TS_F32) launch_scan_generic<0, EMIT>(kr, grid, st, a);
+    else launch_scan_generic<1, EMIT>(kr, grid, st, a);
+    return 1;
+}
+
+// Reduce [slots][m] partial keys to the final k per query: select rounds of 4096-key segments.
+static int run_select_rounds(ts_index* ix, int slots, int m, int k, float* out_scores, int64_t* out_idx, const int* qlist,
+                             const int* qcount, hipStream_t st) {
+    const u64* in = ix->partial;
+    u64* scratch[2] = {ix->partial2, ix->partial};
+    int which = 0;
+    int64_t in_stride = m;
+    for (;;) {
+        SelectArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in = in;
+        a.in_stride = in_stride;
+        a.m = m;
+        a.kout = k;
+        a.k_user = k;
+        a.row_offset = ix->row_offset;
+        a.qlist = qlist;
+        a.qcount = qcount;
+        if (m <= 4096) {
+            a.out_scores = out_scores;
+            a.out_idx = out_idx;
+            if (m <= 1024) select_kernel<1024><<<dim3(1, slots), 256, 0, st>>>(a);
+            else select_kernel<4096><<<dim3(1, slots), 256, 0, st>>>(a);
+            HIP_TRY(hipGetLastError());
+            return TS_OK;
+        }
+        const int nseg = (m + 4095) / 4096;
+        a.out = scratch[which];
+        a.out_stride = (int64_t)nseg * k;
+        select_kernel<4096><<<dim3(nseg, slots), 256, 0, st>>>(a);
+        HIP_TRY(hipGetLastError());
+        in = scratch[which];
+        in_stride = a.out_stride;
+        m = nseg * k;
+        which ^= 1;
+    }
+}
+
+static int scan_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* out_idx, const int* qlist, const int* qcount,
+                       hipStream_t st) {
+    const int grid = ix->cu_count * kScanGridPerCU;
+    ScanArgs a;
+    memset(&a, 0, sizeof(a));
+    a.corpus = ix->rows;
+    a.ld = ix->ld;
+    a.n = ix->n;
+    a.qbuf = ix->qf32;
+    a.qlist = qlist;
+    a.qcount = qcount;
+    a.nq = nq;
+    a.k = k;
+    a.partial = ix->partial;
+    const int qb = (nq >= 2 || qcount) ? 4 : 1;
+    hipEvent_t stop = qcount ? nullptr : prof_begin(ix, st, ix->n);  // the MFMA path's fall-back pass is not bracketed
+    launch_scan<false>(ix, a, qb, st, grid);
+    prof_end(stop, st);
+    HIP_TRY(hipGetLastError());
+    return run_select_rounds(ix, nq, grid * k, k, out_scores, out_idx, qlist, qcount, st);
+}
+
+struct Level { int64_t stride, ntiles; };
+
+static std::vector<Level> plan_levels(int64_t n, int kk) {
+    const int64_t T = (n + kTileRows - 1) / kTileRows;
+    const int target = std::max(64, env_int("TS_MFMA_TARGET_CANDS", kCandCap / 4));
+    int64_t R = 1;
+    while (R * 2 * kk <= target) R *= 2;   // rows ratio between consecutive levels (power of two)
+    if (R < 2) R = 2;
+    std::vector<Level> lv;
+    int64_t stride = 1;
+    for (;;) {
+        const int64_t nt = (T + stride - 1) / stride;
+        lv.push_back({stride, nt});
+        if (nt * kTileRows <= kCandCap / 2) break;  // every score of this level fits: it can run unthresholded
+        stride *= R;
+    }
+    std::reverse(lv.begin(), lv.end());
+    return lv;
+}
+
+static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* out_idx, hipStream_t st, ts_search_stats* stats) {
+    const int kk = std::max(k, 16);
+    if (!ix->attr_done) {
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
+        HIP_TRY(hipFuncSetAttribute((const void*)level_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kCandCap * 8));
+        ix->attr_done = true;
+    }
+    init_thr_kernel<<<1, 256, 0, st>>>(ix->thr, nq);
+    HIP_TRY(hipMemsetAsync(ix->fb_count, 0, 16, st));
+    HIP_TRY(hipMemsetAsync(ix->stat, 0, 16, st));
+    const std::vector<Level> lv = plan_levels(ix->n, kk);
+    const int grid = env_int("TS_MFMA_GRID", ix->cu_count);
+    for (size_t i = 0; i < lv.size(); ++i) {
+        MfmaArgs a;
+        a.corpus = (const unsigned short*)ix->rows;
+        a.n = ix->n;
+        a.ntiles = lv[i].ntiles;
+        a.tile_stride = lv[i].stride;
+        a.q = (const unsigned short*)ix->qstore;
+        a.thr = ix->thr;
+        a.cand = ix->cand;
+        a.count = ix->count;
+        a.cap = kCandCap;
+        hipEvent_t stop = (i + 1 == lv.size()) ? prof_begin(ix, st, ix->n) : nullptr;  // only the full pass is bracketed
+        mfma_topk_kernel<<<grid, kMfmaThreads, kMfmaLds, st>>>(a);
+        prof_end(stop, st);
+        HIP_TRY(hipGetLastError());
+        LevelArgs l;
+        memset(&l, 0, sizeof(l));
+        l.cand = ix->cand;
+        l.count = ix->count;
+        l.cap = kCandCap;
+        l.kk = kk;
+        l.thr = ix->thr;
+        l.final_level = (i + 1 == lv.size());
+        l.out_scores = out_scores;
+        l.out_idx = out_idx;
+        l.k_user = k;
+        l.row_offset = ix->row_offset;
+        l.fb_list = ix->fb_list;
+        l.fb_count = ix->fb_count;
+        l.stat_candidates = ix->stat;
+        level_select_kernel<<<nq, 512, kCandCap * 8, st>>>(l);
+        HIP_TRY(hipGetLastError());
+    }
+    // exact fall-back for queries whose candidate list overflowed (device-side count; no-op when 0)
+    TS_TRY(scan_search(ix, nq, k, out_scores, out_idx, ix->fb_list, ix->fb_count, st));
+    if (stats) stats->levels = (int)lv.size();
+    return TS_OK;
+}
+
+static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_device, int32_t nq, int32_t k,
+                       float* out_scores, int64_t* out_idx, int out_on_device, void* stream, int algo,
+                       ts_search_stats* stats) {
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!ix || !queries || !out_scores || !out_idx) return fail(TS_ERR_INVALID, "NULL argument");
+    if (q_dtype != TS_F32 && q_dtype != TS_BF16) return fail(TS_ERR_INVALID, "q_dtype %d", q_dtype);
+    if (nq < 0) return fail(TS_ERR_INVALID, "nq = %d", nq);
+    if (k < 1 || k > TS_MAX_K) return fail(TS_ERR_INVALID, "k = %d outside [1, %d]", k, TS_MAX_K);
+    if (algo < TS_ALGO_AUTO || algo > TS_ALGO_MFMA) return fail(TS_ERR_INVALID, "algo %d", algo);
+    const bool mfma_ok = ix->dtype == TS_BF16 && ix->d == kMfmaD && ix->n >= 1;
+    if (algo == TS_ALGO_MFMA && !mfma_ok)
+        return fail(TS_ERR_UNSUPPORTED, "the MFMA path needs a bf16 index with d = %d", kMfmaD);
+    if (nq == 0) return TS_OK;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
+    TS_TRY(ensure_search_scratch(ix, k));
+    int use = algo;
+    if (use == TS_ALGO_AUTO) use = (mfma_ok && ix->n >= env_int("TS_MFMA_MIN_ROWS", 16384)) ? TS_ALGO_MFMA : TS_ALGO_SCAN;
+    if (stats) stats->algo = use;
+
+    float* dscores = out_scores;
+    int64_t* didx = out_idx;
+    if (!out_on_device) {
+        const size_t want = (size_t)nq * k;
+        if (ix->res_cap < want) {
+            if (ix->res_scores) HIP_TRY(hipFree(ix->res_scores));
+            if (ix->res_idx) HIP_TRY(hipFree(ix->res_idx));
+            ix->res_scores = nullptr; ix->res_idx = nullptr; ix->res_cap = 0;
+            HIP_TRY(hipMalloc((void**)&ix->res_scores, want * 4));
+            HIP_TRY(hipMalloc((void**)&ix->res_idx, want * 8));
+            ix->res_cap = want;
+        }
+        dscores = ix->res_scores;
+        didx = ix->res_idx;
+    }
+    const size_t q_elem = q_dtype == TS_BF16 ? 2 : 4;
+    if (!q_on_device) TS_TRY(ensure(&ix->stage, &ix->stage_bytes, kStageBytes));
+
+    for (int q0 = 0; q0 < nq; q0 += kQBlock) {
+        const int nb = std::min(kQBlock, nq - q0);
+        const void* qsrc = (const char*)queries + (size_t)q0 * ix->d * q_elem;
+        if (!q_on_device) {
+            HIP_TRY(hipMemcpyAsync(ix->stage, qsrc, (size_t)nb * ix->d * q_elem, hipMemcpyHostToDevice, st));
+            qsrc = ix->stage;
+        }
+        // normalise (COS), round to the storage type, zero-pad to 256 rows x ld; fp32 copy for the scan
+        TS_TRY(prep_dispatch(q_dtype, ix->dtype, ix->metric == TS_METRIC_COS, qsrc, ix->d, ix->qstore, ix->qf32, ix->ld, ix->d,
+                             nb, kQBlock, st));
+        float* os = dscores + (size_t)q0 * k;
+        int64_t* oi = didx + (size_t)q0 * k;
+        if (use == TS_ALGO_MFMA) TS_TRY(mfma_search(ix, nb, k, os, oi, st, stats));
+        else TS_TRY(scan_search(ix, nb, k, os, oi, nullptr, nullptr, st));
+    }
+    if (!out_on_device) {
+        HIP_TRY(hipMemcpyAsync(out_scores, dscores, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(out_idx, didx, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
+    }
+    if (!out_on_device || stats) {
+        int fb = 0;
+        unsigned long long cands = 0;
+        if (stats && use == TS_ALGO_MFMA) {
+            HIP_TRY(hipMemcpyAsync(&fb, ix->fb_count, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(&cands, ix->stat, 8, hipMemcpyDeviceToHost, st));
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+        if (stats && use == TS_ALGO_MFMA) {
+            stats->fallback_queries = fb;
+            stats->candidates = (int64_t)cands;
+        }
+    }
+    return TS_OK;
+}
+
+extern "C" int ts_search_ex(ts_index* ix, const void* queries, int q_dtype, int q_on_device, int32_t nq, int32_t k,
+                            float* out_scores, int64_t* out_idx, int out_on_device, void* stream, int algo,
+                            ts_search_stats* stats) {
+    return search_impl(ix, queries, q_dtype, q_on_device, nq, k, out_scores, out_idx, out_on_device, stream, algo, stats);
+}
+
+extern "C" int ts_search(ts_index* ix, const void* queries, int q_dtype, int q_on_device, int32_t nq, int32_t k,
+                         float* out_scores, int64_t* out_idx, int out_on_device, void* stream) {
+    return search_impl(ix, queries, q_dtype, q_on_device, nq, k, out_scores, out_idx, out_on_device, stream, TS_ALGO_AUTO,
+                       nullptr);
+}
+
+extern "C" int ts_scores(ts_index* ix, const void* queries, int q_dtype, int q_on_device, int32_t nq, float* out,
+                         int out_on_device, void* stream) {
+    if (!ix || !queries || !out) return fail(TS_ERR_INVALID, "NULL argument");
+    if (q_dtype != TS_F32 && q_dtype != TS_BF16) return fail(TS_ERR_INVALID, "q_dtype %d", q_dtype);
+    if (nq < 0) return fail(TS_ERR_INVALID, "nq = %d", nq);
+    if (nq == 0 || ix->n == 0) return TS_OK;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
+    TS_TRY(ensure_search_scratch(ix, 1));
+    float* dout = out;
+    if (!out_on_device) HIP_TRY(hipMalloc((void**)&dout, (size_t)nq * ix->n * 4));
+    const size_t q_elem = q_dtype == TS_BF16 ? 2 : 4;
+    if (!q_on_device) TS_TRY(ensure(&ix->stage, &ix->stage_bytes, kStageBytes));
+    int rc = TS_OK;
+    for (int q0 = 0; q0 < nq && rc == TS_OK; q0 += kQBlock) {
+        const int nb = std::min(kQBlock, nq - q0);
+        const void* qsrc = (const char*)queries + (size_t)q0 * ix->d * q_elem;
+        if (!q_on_device) {
+            hipMemcpyAsync(ix->stage, qsrc, (size_t)nb * ix->d * q_elem, hipMemcpyHostToDevice, st);
+            qsrc = ix->stage;
+        }
+        rc = prep_dispatch(q_dtype, ix->dtype, ix->metric == TS_METRIC_COS, qsrc, ix->d, ix->qstore, ix->qf32, ix->ld, ix->d, nb,
+                           kQBlock, st);
+        if (rc != TS_OK) break;
+        ScanArgs a;
+        memset(&a, 0, sizeof(a));
+        a.corpus = ix->rows;
+        a.ld = ix->ld;
+        a.n = ix->n;
+        a.qbuf = ix->qf32;
+        a.nq = nb;
+        a.k = 1;
+        a.scores = dout + (size_t)q0 * ix->n;
+        launch_scan<true>(ix, a, nb >= 2 ? 4 : 1, st, ix->cu_count * kScanGridPerCU);
+        if (hipGetLastError() != hipSuccess) rc = fail(TS_ERR_HIP, "score kernel launch failed");
+    }
+    if (!out_on_device) {
+        if (rc == TS_OK && hipMemcpyAsync(out, dout, (size_t)nq * ix->n * 4, hipMemcpyDeviceToHost, st) != hipSuccess)
+            rc = fail(TS_ERR_HIP, "copy of the score matrix failed");
+        if (hipStreamSynchronize(st) != hipSuccess && rc == TS_OK) rc = fail(TS_ERR_HIP, "stream synchronize failed");
+        hipFree(dout);
+    }
+    return rc;
+}
+
+extern "C" int ts_merge_topk(int device, const float* scores, const int64_t* idx, int32_t nparts, int32_t nq, int32_t k_in,
+                             int32_t k_out, float* out_scores, int64_t* out_idx, int on_device, void* stream) {
+    if (!scores || !idx || !out_scores || !out_idx) return fail(TS_ERR_INVALID, "NULL argument");
+    if (nparts < 1 || nq < 0 || k_in < 1 || k_out < 1 || k_out > TS_MAX_K)
+        return fail(TS_ERR_INVALID, "bad merge shape");
+    if ((int64_t)nparts * k_in > kMergeMax)
+        return fail(TS_ERR_UNSUPPORTED, "nparts * k_in = %lld exceeds %d", (long long)nparts * k_in, kMergeMax);
+    if (nq == 0) return TS_OK;
+    TS_TRY(check_device(device));
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    MergeArgs a;
+    a.nparts = nparts; a.nq = nq; a.k_in = k_in; a.k_out = k_out;
+    const size_t nin = (size_t)nparts * nq * k_in, nout = (size_t)nq * k_out;
+    if (on_device) {
+        a.scores = scores; a.idx = idx; a.out_scores = out_scores; a.out_idx = out_idx;
+        merge_kernel<<<nq, 256, 0, st>>>(a);
+        HIP_TRY(hipGetLastError());
+        return TS_OK;
+    }
+    float *ds = nullptr, *dos = nullptr;
+    int64_t *di = nullptr, *doi = nullptr;
+    HIP_TRY(hipMalloc((void**)&ds, nin * 4));
+    HIP_TRY(hipMalloc((void**)&di, nin * 8));
+    HIP_TRY(hipMalloc((void**)&dos, nout * 4));
+    HIP_TRY(hipMalloc((void**)&doi, nout * 8));
+    HIP_TRY(hipMemcpyAsync(ds, scores, nin * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(di, idx, nin * 8, hipMemcpyHostToDevice, st));
+    a.scores = ds; a.idx = di; a.out_scores = dos; a.out_idx = doi;
+    merge_kernel<<<nq, 256, 0, st>>>(a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_scores, dos, nout * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out_idx, doi, nout * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    hipFree(ds); hipFree(di); hipFree(dos); hipFree(doi);
+    return TS_OK;
+}
+
+extern "C" int ts_index_profile_enable(ts_index* ix, int enable) {
+    if (!ix) return fail(TS_ERR_INVALID, "index is NULL");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    ix->profiling = enable != 0;
+    ix->ev_used = 0;
+    return TS_OK;
+}
+
+extern "C" int ts_index_profile_read(ts_index* ix, int64_t* launches, double* total_ms, int64_t* rows_per_launch) {
+    if (!ix) return fail(TS_ERR_INVALID, "index is NULL");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    double sum = 0.0;
+    int64_t cnt = 0;
+    for (size_t i = 0; i + 1 < ix->ev_used; i += 2) {
+        HIP_TRY(hipEventSynchronize(ix->ev_pool[i + 1]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ix->ev_pool[i], ix->ev_pool[i + 1]));
+        sum += ms;
+        ++cnt;
+    }
+    ix->ev_used = 0;
+    if (launches) *launches = cnt;
+    if (total_ms) *total_ms = sum;
+    if (rows_per_launch) *rows_per_launch = ix->prof_rows;
+    return TS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// timers
+// ---------------------------------------------------------------------------------------------
+extern "C" int ts_timer_create(int device, ts_timer** out) {
+    if (!out) return fail(TS_ERR_INVALID, "out is NULL");
+    TS_TRY(check_device(device));
+    HIP_TRY(hipSetDevice(device));
+    ts_timer* t = new (std::nothrow) ts_timer();
+    if (!t) return fail(TS_ERR_NOMEM, "host allocation failed");
+    t->device = device;
+    HIP_TRY(hipEventCreate(&t->a));
+    HIP_TRY(hipEventCreate(&t->b));
+    *out = t;
+    return TS_OK;
+}
+extern "C" int ts_timer_start(ts_timer* t, void* stream) {
+    if (!t) return fail(TS_ERR_INVALID, "timer is NULL");
+    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(hipEventRecord(t->a, (hipStream_t)stream));
+    return TS_OK;
+}
+extern "C" int ts_timer_stop(ts_timer* t, void* stream) {
+    if (!t) return fail(TS_ERR_INVALID, "timer is NULL");
+    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(hipEventRecord(t->b, (hipStream_t)stream));
+    return TS_OK;
+}
+extern "C" int ts_timer_elapsed_ms(ts_timer* t, float* ms) {
+    if (!t || !ms) return fail(TS_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(hipEventSynchronize(t->b));
+    HIP_TRY(hipEventElapsedTime(ms, t->a, t->b));
+    return TS_OK;
+}
+extern "C" int ts_timer_destroy(ts_timer* t) {
+    if (!t) return TS_OK;
+    hipSetDevice(t->device);
+    if (t->a) hipEventDestroy(t->a);
+    if (t->b) hipEventDestroy(t->b);
+    delete t;
+    return TS_OK;
+}

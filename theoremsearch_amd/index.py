@@ -1,0 +1,207 @@
+"""TheoremIndex: the [N x d] theorem-embedding matrix resident in HBM, and exact top-k search.
+
+Host-side mirror of the two-line search idiom of the reference apps::
+
+    cosine_scores = util.cos_sim(query_emb, embeddings_db)[0]           # app_showcase_model.py:93
+    top = torch.topk(cosine_scores, k=min(200, N), sorted=True)          # app_showcase_model.py:96
+    top_indices = np.argsort(-cosine_scores.cpu())[:5]                  # app_scratchpad.py:130
+
+and of ``ORDER BY e.embedding <#> q ASC LIMIT k`` (streamlit_app.py:282-283).  All arithmetic
+runs in libtsearch.so's HIP kernels; numpy is only the container of host inputs and results.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import TS_ALGO_AUTO, TS_ALGO_MFMA, TS_ALGO_SCAN, TS_BF16, TS_F32, TS_METRIC_COS, TS_METRIC_IP
+
+_DTYPES = {"f32": TS_F32, "fp32": TS_F32, "float32": TS_F32, "bf16": TS_BF16, "bfloat16": TS_BF16}
+_METRICS = {"ip": TS_METRIC_IP, "dot": TS_METRIC_IP, "cos": TS_METRIC_COS, "cosine": TS_METRIC_COS}
+_ALGOS = {"auto": TS_ALGO_AUTO, "scan": TS_ALGO_SCAN, "mfma": TS_ALGO_MFMA}
+
+
+def _host_rows(x) -> np.ndarray:
+    """numpy float32 / uint16(bf16 bits) 2-D, C-contiguous; accepts lists and CPU torch tensors."""
+    if hasattr(x, "detach") and hasattr(x, "cpu"):          # torch.Tensor without importing torch
+        t = x.detach().cpu()
+        if str(t.dtype) == "torch.bfloat16":
+            x = t.view(dtype=__import__("torch").int16).numpy().view(np.uint16)
+        else:
+            x = t.float().numpy()
+    a = np.asarray(x)
+    if a.dtype != np.uint16:
+        a = a.astype(np.float32, copy=False)
+    if a.ndim == 1:
+        a = a[None, :]
+    if a.ndim != 2:
+        raise ValueError("expected a 1-D or 2-D array of embeddings")
+    return np.ascontiguousarray(a)
+
+
+class TheoremIndex:
+    """Device-resident embedding matrix with brute-force exact top-k search."""
+
+    def __init__(self, n: int, d: int, dtype: str = "f32", metric: str = "cos", device: int = 0,
+                 row_offset: int = 0):
+        self._lib = _ffi.load()
+        self._h = C.c_void_p()
+        self.n, self.d = int(n), int(d)
+        self.dtype, self.metric, self.device = dtype, metric, int(device)
+        _ffi.check(self._lib.ts_index_create(self.device, self.n, self.d, _DTYPES[dtype], _METRICS[metric],
+                                             C.byref(self._h)))
+        self.row_offset = 0
+        if row_offset:
+            self.set_row_offset(row_offset)
+
+    # -- construction ---------------------------------------------------------------------
+    @classmethod
+    def from_embeddings(cls, embeddings, dtype: str = "f32", metric: str = "cos", device: int = 0,
+                        row_offset: int = 0) -> "TheoremIndex":
+        """Build from a host matrix (numpy, list of lists, or the CPU tensor that
+        ``torch.load('corpus_embeddings.pt')`` returns, app_showcase_model.py:52)."""
+        rows = _host_rows(embeddings)
+        ix = cls(rows.shape[0], rows.shape[1], dtype=dtype, metric=metric, device=device, row_offset=row_offset)
+        ix.upload(rows, 0)
+        return ix
+
+    def upload(self, rows, row0: int = 0) -> None:
+        rows = _host_rows(rows)
+        if rows.shape[1] != self.d:
+            raise ValueError(f"rows have d={rows.shape[1]}, index has d={self.d}")
+        _ffi.check(self._lib.ts_index_upload(self._h, _ffi.as_ptr(rows), _ffi.np_dtype_code(rows), int(row0),
+                                             rows.shape[0]))
+
+    def upload_device(self, dev_ptr: int, src_dtype: str, src_ld: int, row0: int, nrows: int, stream: int = 0) -> None:
+        """Rows already in device memory (e.g. ``tensor.data_ptr()`` of the encoder output)."""
+        _ffi.check(self._lib.ts_index_upload_device(self._h, C.c_void_p(dev_ptr), _DTYPES[src_dtype], int(src_ld),
+                                                    int(row0), int(nrows), C.c_void_p(stream)))
+
+    def set_row_offset(self, offset: int) -> None:
+        _ffi.check(self._lib.ts_index_set_row_offset(self._h, int(offset)))
+        self.row_offset = int(offset)
+
+    def download(self, row0: int = 0, nrows: Optional[int] = None) -> np.ndarray:
+        """Stored rows (normalised / bf16-rounded as the kernels see them)."""
+        nrows = self.n - row0 if nrows is None else nrows
+        out = np.empty((nrows, self.d), dtype=np.uint16 if _DTYPES[self.dtype] == TS_BF16 else np.float32)
+        _ffi.check(self._lib.ts_index_download(self._h, _ffi.as_ptr(out), int(row0), int(nrows)))
+        return out
+
+    @property
+    def stream(self) -> int:
+        s = C.c_void_p()
+        _ffi.check(self._lib.ts_index_stream(self._h, C.byref(s)))
+        return s.value or 0
+
+    @property
+    def handle(self) -> C.c_void_p:
+        return self._h
+
+    # -- search -----------------------------------------------------------------------------
+    def search(self, queries, k: int, algo: str = "auto", return_stats: bool = False):
+        """Exact top-k.  Returns ``(scores [nq x k] float32, indices [nq x k] int64)`` ordered by
+        score descending then index ascending; padding is ``(-inf, -1)``."""
+        q = _host_rows(queries)
+        if q.shape[1] != self.d:
+            raise ValueError(f"queries have d={q.shape[1]}, index has d={self.d}")
+        nq, k = q.shape[0], int(k)
+        scores = np.empty((nq, k), dtype=np.float32)
+        idx = np.empty((nq, k), dtype=np.int64)
+        stats = _ffi.SearchStats()
+        _ffi.check(self._lib.ts_search_ex(self._h, _ffi.as_ptr(q), _ffi.np_dtype_code(q), 0, nq, k,
+                                          _ffi.as_ptr(scores), _ffi.as_ptr(idx), 0, None, _ALGOS[algo],
+                                          C.byref(stats)))
+        if return_stats:
+            return scores, idx, {"algo": stats.algo, "levels": stats.levels,
+                                 "fallback_queries": stats.fallback_queries, "candidates": stats.candidates}
+        return scores, idx
+
+    def search_device(self, q_ptr: int, q_dtype: str, nq: int, k: int, out_scores_ptr: int, out_idx_ptr: int,
+                      stream: int = 0, algo: str = "auto") -> None:
+        """Asynchronous search on device buffers (queries [nq x d] dense; outputs [nq x k] f32 / i64),
+        enqueued on ``stream`` (0 = the index's own stream)."""
+        _ffi.check(self._lib.ts_search_ex(self._h, C.c_void_p(q_ptr), _DTYPES[q_dtype], 1, int(nq), int(k),
+                                          C.c_void_p(out_scores_ptr), C.c_void_p(out_idx_ptr), 1,
+                                          C.c_void_p(stream), _ALGOS[algo], None))
+
+    def scores(self, queries) -> np.ndarray:
+        """Full ``[nq x N]`` fp32 score matrix (small N): ``util.cos_sim(q_emb, s_emb)`` of
+        compare_embeddings.py:24,61 when the index metric is "cos"."""
+        q = _host_rows(queries)
+        if q.shape[1] != self.d:
+            raise ValueError(f"queries have d={q.shape[1]}, index has d={self.d}")
+        out = np.empty((q.shape[0], self.n), dtype=np.float32)
+        _ffi.check(self._lib.ts_scores(self._h, _ffi.as_ptr(q), _ffi.np_dtype_code(q), 0, q.shape[0],
+                                       _ffi.as_ptr(out), 0, None))
+        return out
+
+    # -- profiling ---------------------------------------------------------------------------
+    def profile_enable(self, enable: bool = True) -> None:
+        _ffi.check(self._lib.ts_index_profile_enable(self._h, 1 if enable else 0))
+
+    def profile_read(self) -> dict:
+        """Launch count and summed hipEvent duration of the dominant kernel since the last read."""
+        n, ms, rows = C.c_int64(0), C.c_double(0.0), C.c_int64(0)
+        _ffi.check(self._lib.ts_index_profile_read(self._h, C.byref(n), C.byref(ms), C.byref(rows)))
+        return {"launches": n.value, "total_ms": ms.value, "rows_per_launch": rows.value}
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.ts_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def merge_topk(scores: np.ndarray, idx: np.ndarray, k_out: int, device: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+    """Merge ``[nparts x nq x k_in]`` partial results into the global top-``k_out`` on the device."""
+    s = np.ascontiguousarray(scores, dtype=np.float32)
+    i = np.ascontiguousarray(idx, dtype=np.int64)
+    nparts, nq, k_in = s.shape
+    os_ = np.empty((nq, k_out), dtype=np.float32)
+    oi = np.empty((nq, k_out), dtype=np.int64)
+    _ffi.check(_ffi.load().ts_merge_topk(device, _ffi.as_ptr(s), _ffi.as_ptr(i), nparts, nq, k_in, k_out,
+                                         _ffi.as_ptr(os_), _ffi.as_ptr(oi), 0, None))
+    return os_, oi
+
+
+class Timer:
+    """hipEvent pair on a given stream (ts_timer_*)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = _ffi.load()
+        self._h = C.c_void_p()
+        _ffi.check(self._lib.ts_timer_create(device, C.byref(self._h)))
+
+    def start(self, stream: int = 0):
+        _ffi.check(self._lib.ts_timer_start(self._h, C.c_void_p(stream)))
+
+    def stop(self, stream: int = 0):
+        _ffi.check(self._lib.ts_timer_stop(self._h, C.c_void_p(stream)))
+
+    def elapsed_ms(self) -> float:
+        ms = C.c_float(0)
+        _ffi.check(self._lib.ts_timer_elapsed_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self._h.value:
+                self._lib.ts_timer_destroy(self._h)
+        except Exception:
+            pass
