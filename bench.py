@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""bench.py - queries/sec of brute-force top-10 over an [N x 768] theorem-embedding matrix.
+
+Contract (one JSON line on rank 0):
+  python bench.py --gpus N --steps K --warmup W          (N = 1)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+Workload (BASELINE.json): configs[2] "10M x 768 bf16 corpus, batch-256 queries" - the shape the
+north-star target is quoted on; it fits one GPU (15.36 GB).  One step = one batch of 256 queries
+searched against the whole corpus (inputs resident in HBM).  With N > 1 the SAME corpus is
+row-sharded over the ranks (strong scaling): every rank searches its shard, the per-shard top-10
+are exchanged with one RCCL all-gather, and every rank merges them.
+Other workloads: --workload c2 (1M x 768 fp32, batch 1), --workload c4 (50M x 768 bf16, batch 256).
+
+Synthetic data: corpus chunk c (250,000 rows) = default_rng([1234, c]).standard_normal, rows
+L2-normalised in fp32, rounded to bf16 for the bf16 workloads (oracle.synth_chunk); queries from
+default_rng([5678, 0]) the same way.  Rows are stored as given (metric = inner product on
+normalised rows = cosine).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (rows, dtype, nq)
+    "c2": (1_000_000, "f32", 1),
+    "c3": (10_000_000, "bf16", 256),
+    "c4": (50_000_000, "bf16", 256),
+}
+D = 768
+K = 10
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def log(rank, *a):
+    if rank == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--rows", type=int, default=0, help="override the corpus size (debug)")
+    ap.add_argument("--nq", type=int, default=0, help="override the query batch (debug)")
+    ap.add_argument("--algo", default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--gen-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle  # synthetic-data recipe + checker + cpu_baseline only
+    import theoremsearch_amd as ts
+    from theoremsearch_amd import _ffi
+
+    if _ffi.device_count() <= 0:
+        raise SystemExit("bench.py needs a HIP device (libtsearch has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    rows_total, dtype, nq = WORKLOADS[args.workload]
+    if args.rows:
+        rows_total = args.rows
+    if args.nq:
+        nq = args.nq
+    bf16 = dtype == "bf16"
+    elem = 2 if bf16 else 4
+
+    # ---- this rank's shard: contiguous rows [lo, hi), generated chunk by chunk -------------------
+    lo = rows_total * rank // world
+    hi = rows_total * (rank + 1) // world
+    n_local = hi - lo
+    CH = oracle.CHUNK_ROWS
+    chunks = list(range(lo // CH, (hi + CH - 1) // CH))
+    ix = ts.TheoremIndex(n_local, D, dtype=dtype, metric="ip", device=local_rank, row_offset=lo)
+    ncpu = len(os.sched_getaffinity(0))
+    nthreads = args.gen_threads or max(1, min(16, ncpu // max(1, min(world, 8))))
+    t_gen = time.time()
+    cache = {}                                   # host copies for the recall check / cpu baseline
+    cache_ok = n_local * D * elem <= (40 << 30) and not args.no_recall
+
+    def make(c):
+        data = oracle.synth_chunk(c, CH, D, bf16=bf16)
+        a, b = max(lo, c * CH), min(hi, (c + 1) * CH)
+        ix.upload(data[a - c * CH:b - c * CH], a - lo)
+        if cache_ok or (c == 0 and rank == 0):
+            cache[c] = data
+        return c
+
+    with ThreadPoolExecutor(nthreads) as ex:
+        for i, c in enumerate(ex.map(make, chunks)):
+            if (i + 1) % 8 == 0:
+                log(rank, f"generated+uploaded {i + 1}/{len(chunks)} chunks ({time.time() - t_gen:.0f}s)")
+    log(rank, f"corpus ready: {n_local} rows/rank x {D} {dtype} in {time.time() - t_gen:.1f}s ({nthreads} threads)")
+
+    q_host = oracle.synth_queries(0, nq, D, bf16=bf16)      # uint16 bits or float32
+    stream = torch.cuda.current_stream().cuda_stream
+    q_dev = torch.from_numpy(q_host.view(np.int16) if bf16 else q_host).cuda()
+    out_s = torch.empty((nq, K), dtype=torch.float32, device="cuda")
+    out_i = torch.empty((nq, K), dtype=torch.int64, device="cuda")
+    if world > 1:
+        gat_s = torch.empty((world, nq, K), dtype=torch.float32, device="cuda")
+        gat_i = torch.empty((world, nq, K), dtype=torch.int64, device="cuda")
+        fin_s = torch.empty((nq, K), dtype=torch.float32, device="cuda")
+        fin_i = torch.empty((nq, K), dtype=torch.int64, device="cuda")
+    lib = _ffi.load()
+    import ctypes as C
+
+    def step():
+        ix.search_device(q_dev.data_ptr(), dtype, nq, K, out_s.data_ptr(), out_i.data_ptr(), stream, algo=args.algo)
+        if world > 1:
+            dist.all_gather_into_tensor(gat_s, out_s)
+            dist.all_gather_into_tensor(gat_i, out_i)
+            _ffi.check(lib.ts_merge_topk(local_rank, C.c_void_p(gat_s.data_ptr()), C.c_void_p(gat_i.data_ptr()), world, nq,
+                                         K, K, C.c_void_p(fin_s.data_ptr()), C.c_void_p(fin_i.data_ptr()), 1,
+                                         C.c_void_p(stream)))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ix.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ix.profile_read()
+    ix.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    qps = nq * args.steps / dt
+
+    # ---- roofline of the dominant kernel (live hipEvent brackets inside the library) -------------
+    kern_ms = prof["total_ms"] / max(1, prof["launches"])
+    launches_per_step = prof["launches"] / max(1, args.steps)
+    alg_bytes = prof["rows_per_launch"] * D * elem           # corpus rows read once per launch
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes per launch from rocprofv3 --pmc (offline pass)
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(f"{args.workload}_n{world}")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "mfma_topk_kernel" if bf16 else "scan_kernel",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel_ms": round(kern_ms, 4), "launches_per_step": launches_per_step,
+                "algorithmic_bytes_per_launch": alg_bytes}
+
+    # ---- recall@10 against the oracle (fp64 scores of the same bf16/fp32 values) -------------------
+    res_s = (fin_s if world > 1 else out_s).cpu().numpy()
+    res_i = (fin_i if world > 1 else out_i).cpu().numpy()
+    recall = None
+    if not args.no_recall:
+        nchk = min(nq, 8)
+        qf = oracle.bf16_bits_to_f32(q_host[:nchk]) if bf16 else q_host[:nchk]
+        best_s = np.full((nchk, K), -np.inf)
+        t_chk = time.time()
+
+        def local_truth(c):
+            data = cache[c] if c in cache else oracle.synth_chunk(c, CH, D, bf16=bf16)
+            a, b = max(lo, c * CH), min(hi, (c + 1) * CH)
+            blk = data[a - c * CH:b - c * CH]
+            blk = oracle.bf16_bits_to_f32(blk) if bf16 else blk
+            s = qf.astype(np.float64) @ blk.astype(np.float64).T
+            top = -np.sort(-s, axis=1)[:, :K] if s.shape[1] > K else s
+            # fp64 scores of the rows the GPU returned that live in this chunk
+            got = {}
+            for b_ in range(nchk):
+                for j in res_i[b_]:
+                    if a <= j < b:
+                        got[(b_, int(j))] = float(s[b_, j - a])
+            return top, got
+
+        got_scores = {}
+        with ThreadPoolExecutor(max(1, nthreads // 2)) as ex:
+            for top, got in ex.map(local_truth, chunks):
+                best_s = -np.sort(-np.concatenate([best_s, top], axis=1), axis=1)[:, :K]
+                got_scores.update(got)
+        if world > 1:
+            objs = [None] * world
+            dist.all_gather_object(objs, (best_s, got_scores))
+            best_s = -np.sort(-np.concatenate([o[0] for o in objs], axis=1), axis=1)[:, :K]
+            got_scores = {k_: v for o in objs for k_, v in o[1].items()}
+        hits = 0
+        for b_ in range(nchk):
+            kth = best_s[b_, K - 1]
+            for j in res_i[b_]:
+                if got_scores.get((b_, int(j)), -np.inf) >= kth - 1e-6:
+                    hits += 1
+        recall = hits / float(nchk * K)
+        log(rank, f"recall@10 over {nchk} queries vs fp64 oracle: {recall:.4f} ({time.time() - t_chk:.0f}s)")
+
+    # ---- CPU baseline: the reference's formulation on the host cores, bounded sample ---------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import torch.nn.functional as F
+        rows_s = cache[0][: min(CH, rows_total)]
+        c_s = torch.from_numpy(oracle.bf16_bits_to_f32(rows_s) if bf16 else rows_s)
+        q_s = torch.from_numpy(oracle.bf16_bits_to_f32(q_host) if bf16 else q_host)
+        torch.set_num_threads(ncpu)
+        t1 = time.perf_counter()
+        # util.cos_sim (normalise both, mm) + np.argsort(-S, axis=1)[:, :10]  (compare_embeddings.py:61,105)
+        S = torch.mm(F.normalize(q_s, p=2, dim=1), F.normalize(c_s, p=2, dim=1).T).numpy()
+        top = np.argsort(-S, axis=1)[:, :K]
+        t_cpu = time.perf_counter() - t1
+        scale = rows_total / float(c_s.shape[0])
+        cpu = {"value": round(nq / (t_cpu * scale), 3), "unit": "queries/s", "cores": ncpu, "kind": "port",
+               "sample": f"{c_s.shape[0]} of {rows_total} rows x {nq} queries, fp32 torch-CPU cos_sim + np.argsort "
+                         f"in {t_cpu:.2f}s; value scaled linearly to the full corpus (x{1 / scale:.4f})",
+               "measured_qps_on_sample": round(nq / t_cpu, 2)}
+        # the sample doubles as a parity spot check of chunk 0
+        del S, top
+
+    if rank == 0:
+        line = {
+            "metric": "queries/sec, brute-force top-10 over N x 768 theorem embeddings",
+            "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": f"{rows_total}x{D} {dtype} corpus, batch-{nq} queries, top-{K} "
+                                   f"(BASELINE.json configs[{ {'c2': 1, 'c3': 2, 'c4': 3}[args.workload] }])",
+                       "rows": rows_total, "dim": D, "batch": nq, "k": K,
+                       "parallelism": f"corpus row-sharded x{world}" + (", RCCL all-gather of per-shard top-k" if world > 1 else "")},
+            "recall_at_10": recall,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -87,7 +87,7 @@ def l2_normalize(x: np.ndarray) -> np.ndarray:
     oracle fixes this one.  A zero row stays zero.
     """
     x = _as_2d(x).astype(np.float32, copy=False)
-    ss = np.einsum("ij,ij->i", x.astype(np.float64), x.astype(np.float64))
+    ss = np.einsum("ij,ij->i", x, x, dtype=np.float64)
     norm = np.sqrt(ss).astype(np.float32)
     denom = np.maximum(norm, EPS)
     return (x / denom[:, None]).astype(np.float32)
@@ -479,11 +479,18 @@ CHUNK_ROWS = 250_000
 def synth_chunk(chunk_id: int, rows: int = CHUNK_ROWS, d: int = 768, seed: int = 1234,
                 bf16: bool = False) -> np.ndarray:
     """Chunk ``chunk_id`` of the synthetic corpus: random-normal rows, each
-    L2-normalised in fp32; bf16 configs round after the normalisation.
-    Returns fp32 (``bf16=False``) or uint16 bf16 bit patterns (``bf16=True``)."""
+    L2-normalised in fp32 (``l2_normalize``); bf16 configs round after the normalisation.
+    Returns fp32 (``bf16=False``) or uint16 bf16 bit patterns (``bf16=True``).
+    Works in sub-blocks so that many chunks can be generated by concurrent threads."""
     x = np.random.default_rng([seed, chunk_id]).standard_normal((rows, d), dtype=np.float32)
-    x = l2_normalize(x)
-    return f32_to_bf16_bits(x) if bf16 else x
+    out = np.empty((rows, d), dtype=np.uint16) if bf16 else x
+    for r0 in range(0, rows, 16384):
+        blk = l2_normalize(x[r0:r0 + 16384])
+        if bf16:
+            out[r0:r0 + 16384] = f32_to_bf16_bits(blk)
+        else:
+            x[r0:r0 + 16384] = blk
+    return out
 
 
 def synth_queries(batch_id: int, nq: int, d: int = 768, seed: int = 5678, bf16: bool = False) -> np.ndarray:
