@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--gen-threads", type=int, default=0)
+    ap.add_argument("--zero-queries", action="store_true", help="diagnostic: all-zero queries (power probe)")
+    ap.add_argument("--zero-corpus", action="store_true", help="diagnostic: all-zero corpus (power probe)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -102,7 +104,7 @@ def main():
     cache_ok = n_local * D * elem <= (40 << 30) and not args.no_recall
 
     def make(c):
-        data = oracle.synth_chunk(c, CH, D, bf16=bf16)
+        data = oracle.synth_chunk(c, CH, D, bf16=bf16) if not args.zero_corpus else np.zeros((CH, D), np.uint16 if bf16 else np.float32)
         a, b = max(lo, c * CH), min(hi, (c + 1) * CH)
         ix.upload(data[a - c * CH:b - c * CH], a - lo)
         if cache_ok or (c == 0 and rank == 0):
@@ -116,6 +118,8 @@ def main():
     log(rank, f"corpus ready: {n_local} rows/rank x {D} {dtype} in {time.time() - t_gen:.1f}s ({nthreads} threads)")
 
     q_host = oracle.synth_queries(0, nq, D, bf16=bf16)      # uint16 bits or float32
+    if args.zero_queries:
+        q_host = np.zeros_like(q_host)
     stream = torch.cuda.current_stream().cuda_stream
     q_dev = torch.from_numpy(q_host.view(np.int16) if bf16 else q_host).cuda()
     out_s = torch.empty((nq, K), dtype=torch.float32, device="cuda")

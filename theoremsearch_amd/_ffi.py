@@ -18,7 +18,8 @@ TS_METRIC_IP, TS_METRIC_COS = 0, 1
 TS_ALGO_AUTO, TS_ALGO_SCAN, TS_ALGO_MFMA = 0, 1, 2
 TS_MAX_K = 256
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtsearch.so")
+# TS_LIB overrides the library file (A/B builds of the same ABI during kernel tuning)
+_LIB_PATH = os.environ.get("TS_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtsearch.so")
 _lib = None
 _lock = threading.Lock()
 

@@ -522,7 +522,20 @@ static std::vector<Level> plan_levels(int64_t n, int kk) {
 static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* out_idx, hipStream_t st, ts_search_stats* stats) {
     const int kk = std::max(k, 16);
     if (!ix->attr_done) {
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_v2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kV2Lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_v2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kV2Lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_v2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kV2Lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_v2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, kV2Lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_v2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kV2Lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_v2_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, kV2Lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_v2_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, kV2Lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_v2_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, kV2Lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_v2_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, kV2Lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_v2_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, kV2Lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
         HIP_TRY(hipFuncSetAttribute((const void*)level_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kCandCap * 8));
         ix->attr_done = true;
     }
@@ -542,10 +555,43 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         a.cand = ix->cand;
         a.count = ix->count;
         a.cap = kCandCap;
+        a.dbg = nullptr;
+        static unsigned long long* g_dbg = nullptr;  // diagnostics (TS_MFMA_VARIANT=5): per-wave cycle sums
+        if (env_int("TS_MFMA_VARIANT", 0) == 5) {
+            if (!g_dbg) HIP_TRY(hipMalloc((void**)&g_dbg, 4096 * 4 * 4 * 8));
+            a.dbg = g_dbg;
+        }
         hipEvent_t stop = (i + 1 == lv.size()) ? prof_begin(ix, st, ix->n) : nullptr;  // only the full pass is bracketed
-        mfma_topk_kernel<<<grid, kMfmaThreads, kMfmaLds, st>>>(a);
+        if (env_int("TS_MFMA_KERNEL", 2) == 2) {
+            switch (env_int("TS_MFMA_VARIANT", 0)) {
+                case 1: mfma_topk_v2_kernel<1><<<grid, kV2Threads, kV2Lds, st>>>(a); break;
+                case 2: mfma_topk_v2_kernel<2><<<grid, kV2Threads, kV2Lds, st>>>(a); break;
+                case 3: mfma_topk_v2_kernel<3><<<grid, kV2Threads, kV2Lds, st>>>(a); break;
+                case 4: mfma_topk_v2_kernel<4><<<grid, kV2Threads, kV2Lds, st>>>(a); break;
+                case 5: mfma_topk_v2_kernel<5><<<grid, kV2Threads, kV2Lds, st>>>(a); break;
+                case 6: mfma_topk_v2_kernel<6><<<grid, kV2Threads, kV2Lds, st>>>(a); break;
+                case 7: mfma_topk_v2_kernel<7><<<grid, kV2Threads, kV2Lds, st>>>(a); break;
+                case 8: mfma_topk_v2_kernel<8><<<grid, kV2Threads, kV2Lds, st>>>(a); break;
+                case 9: mfma_topk_v2_kernel<9><<<grid, kV2Threads, kV2Lds, st>>>(a); break;
+                default: mfma_topk_v2_kernel<0><<<grid, kV2Threads, kV2Lds, st>>>(a); break;
+            }
+        } else switch (env_int("TS_MFMA_VARIANT", 0)) {
+            case 1: mfma_topk_kernel<1><<<grid, kMfmaThreads, kMfmaLds, st>>>(a); break;
+            case 2: mfma_topk_kernel<2><<<grid, kMfmaThreads, kMfmaLds, st>>>(a); break;
+            case 3: mfma_topk_kernel<3><<<grid, kMfmaThreads, kMfmaLds, st>>>(a); break;
+            default: mfma_topk_kernel<0><<<grid, kMfmaThreads, kMfmaLds, st>>>(a); break;
+        }
         prof_end(stop, st);
         HIP_TRY(hipGetLastError());
+        if (a.dbg && i + 1 == lv.size()) {
+            std::vector<unsigned long long> h((size_t)grid * 16);
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost));
+            double tot = 0, vm = 0, bar = 0, units = 0;
+            for (int w = 0; w < grid * 4; ++w) { tot += h[w * 4]; vm += h[w * 4 + 1]; bar += h[w * 4 + 2]; units += h[w * 4 + 3]; }
+            fprintf(stderr, "[tsearch stamps] per unit: total %.0f cycles, vmcnt wait %.0f, barrier wait %.0f (units/wave %.0f)\n",
+                    tot / units, vm / units, bar / units, units / (grid * 4));
+        }
         LevelArgs l;
         memset(&l, 0, sizeof(l));
         l.cand = ix->cand;
