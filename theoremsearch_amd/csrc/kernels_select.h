@@ -55,13 +55,18 @@ __global__ void __launch_bounds__(256) select_kernel(SelectArgs a) {
     }
 }
 
-// MFMA path, after each threshold level: one workgroup per query sorts that query's candidates.
-//   sample level: thr[q] = score of the kk-th best candidate (-inf if fewer), count reset to 0.
-//   final level : writes the k results, or appends q to the fall-back list when the candidate
-//                 buffer overflowed (count > cap: some candidates were dropped).
+// MFMA path, after each threshold level: one workgroup per query gathers that query's candidates
+// (the writers' private lists plus the shared spill list), sorts them, and
+//   sample level: sets thr[q] = score of the kk-th best candidate (-inf if fewer);
+//   final level : writes the k results, or appends q to the fall-back list when candidates were
+//                 lost (shared list overflow, or more candidates than the sort buffer holds).
 struct LevelArgs {
-    u64* cand;           // [nq][cap]
-    u32* count;          // [nq] appended so far (may exceed cap)
+    const u64* priv;     // [nq][nwriters][priv_cap]
+    const u32* pcount;   // [nq][nwriters] entries produced per writer (> priv_cap: the rest spilled)
+    int nwriters;
+    int priv_cap;
+    const u64* cand;     // [nq][cap] shared spill lists
+    u32* count;          // [nq] appended to the shared list (may exceed cap); reset here
     int cap;
     int kk;              // threshold rank, >= k_user
     float* thr;          // [256]
@@ -72,33 +77,66 @@ struct LevelArgs {
     int64_t row_offset;
     int* fb_list;
     int* fb_count;
-    unsigned long long* stat_candidates;  // sum of counts seen at the final level
+    unsigned long long* stat_candidates;  // sum of candidates seen at the final level
 };
+
+constexpr int kLevelSortMax = 8192;
+constexpr int kLevelLds = kLevelSortMax * 8 + 16;
 
 __global__ void __launch_bounds__(512) level_select_kernel(LevelArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64* keys = (u64*)smem;
+    u64* keys = (u64*)smem;  // kLevelSortMax, then three counters (all LDS in the one dynamic region)
+    u32& fill = *(u32*)(smem + kLevelSortMax * 8);
+    u32& produced = *(u32*)(smem + kLevelSortMax * 8 + 4);
+    u32& base_shared = *(u32*)(smem + kLevelSortMax * 8 + 8);
     const int q = blockIdx.x;
+    if (threadIdx.x == 0) {
+        fill = 0;
+        produced = 0;
+    }
+    __syncthreads();
+    // private lists
+    for (int w = threadIdx.x; w < a.nwriters; w += blockDim.x) {
+        const u32 made = a.pcount[(int64_t)q * a.nwriters + w];
+        if (made == 0) continue;
+        const u32 n = min(made, (u32)a.priv_cap);
+        const u64* src = a.priv + ((int64_t)q * a.nwriters + w) * a.priv_cap;
+        const u32 at = atomicAdd(&fill, n);
+        atomicAdd(&produced, n);
+        for (u32 e = 0; e < n; ++e)
+            if (at + e < (u32)kLevelSortMax) keys[at + e] = src[e];
+    }
+    // shared spill list
     const u32 raw = a.count[q];
-    const int cnt = (int)min(raw, (u32)a.cap);
+    const u32 ns = min(raw, (u32)a.cap);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        base_shared = fill;
+        fill += ns;
+        produced += raw;
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < ns; i += blockDim.x)
+        if (base_shared + i < (u32)kLevelSortMax) keys[base_shared + i] = a.cand[(int64_t)q * a.cap + i];
+    __syncthreads();
+    const u32 total = fill;
+    const bool lost = raw > (u32)a.cap || total > (u32)kLevelSortMax;
+    const int cnt = (int)min(total, (u32)kLevelSortMax);
     int P = 2;
     while (P < cnt) P <<= 1;
-    const u64* src = a.cand + (int64_t)q * a.cap;
-    for (int i = threadIdx.x; i < P; i += blockDim.x) keys[i] = (i < cnt) ? src[i] : 0ull;
+    for (int i = cnt + threadIdx.x; i < P; i += blockDim.x) keys[i] = 0ull;
     bitonic_sort_desc(keys, P, threadIdx.x, blockDim.x);
+    if (threadIdx.x == 0) a.count[q] = 0;
     if (!a.final_level) {
+        // any subset of the candidates still gives a valid (lower) bound, so `lost` is harmless here
         if (threadIdx.x == 0) {
             const u64 key = (a.kk - 1 < P) ? keys[a.kk - 1] : 0ull;
             a.thr[q] = key ? key_score(key) : -INFINITY;
-            a.count[q] = 0;
         }
         return;
     }
-    if (threadIdx.x == 0) {
-        atomicAdd(a.stat_candidates, (unsigned long long)raw);
-        a.count[q] = 0;
-    }
-    if (raw > (u32)a.cap) {
+    if (threadIdx.x == 0) atomicAdd(a.stat_candidates, (unsigned long long)produced);
+    if (lost) {
         if (threadIdx.x == 0) a.fb_list[atomicAdd(a.fb_count, 1)] = q;
         return;
     }

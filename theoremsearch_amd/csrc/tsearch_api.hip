@@ -74,6 +74,7 @@ struct ts_index {
     void* stage = nullptr;      size_t stage_bytes = 0;      // host->device staging
     void* qstore = nullptr;     float* qf32 = nullptr;       // prepared queries [256 x ld]
     u64* cand = nullptr;        u32* count = nullptr;        float* thr = nullptr;
+    u64* priv = nullptr;        u32* pcount = nullptr;       int priv_writers = 0;  // MFMA path: lane-private candidate lists
     int* fb_list = nullptr;     int* fb_count = nullptr;     unsigned long long* stat = nullptr;
     u64* partial = nullptr;     u64* partial2 = nullptr;     size_t partial_bytes = 0;
     float* res_scores = nullptr; int64_t* res_idx = nullptr; size_t res_cap = 0;  // device result buffers (entries)
@@ -208,7 +209,7 @@ extern "C" int ts_index_destroy(ts_index* ix) {
     if (!ix) return TS_OK;
     hipSetDevice(ix->device);
     if (ix->stream) hipStreamSynchronize(ix->stream);
-    void* ptrs[] = {ix->rows,  ix->stage,   ix->qstore,   ix->qf32,     ix->cand,       ix->count,  ix->thr,
+    void* ptrs[] = {ix->rows,  ix->stage,   ix->qstore,   ix->qf32,     ix->cand,       ix->count,  ix->thr, ix->priv, ix->pcount,
                     ix->fb_list, ix->fb_count, ix->stat, ix->partial, ix->partial2, ix->res_scores, ix->res_idx};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -342,9 +343,14 @@ extern "C" int ts_index_download(ts_index* ix, void* host_rows, int64_t row0, in
 // ---------------------------------------------------------------------------------------------
 // search
 // ---------------------------------------------------------------------------------------------
-__global__ void init_thr_kernel(float* thr, int nq) {
+// Per search: thresholds of level 0 and the two per-search counters (one launch instead of memsets).
+__global__ void init_thr_kernel(float* thr, int nq, int* fb_count, unsigned long long* stat) {
     const int i = threadIdx.x;
     if (i < kMfmaQ) thr[i] = (i < nq) ? -INFINITY : INFINITY;
+    if (i == 0) {
+        *fb_count = 0;
+        *stat = 0ull;
+    }
 }
 
 static int ensure_search_scratch(ts_index* ix, int k) {
@@ -503,7 +509,9 @@ struct Level { int64_t stride, ntiles; };
 
 static std::vector<Level> plan_levels(int64_t n, int kk) {
     const int64_t T = (n + kTileRows - 1) / kTileRows;
-    const int target = std::max(64, env_int("TS_MFMA_TARGET_CANDS", kCandCap / 4));
+    // expected candidates per query a level passes on (measured optimum for 10M x 768, batch 256: 512;
+    // fewer = fewer trips through the append path of the full pass, but a larger sample level before it)
+    const int target = std::max(64, env_int("TS_MFMA_TARGET_CANDS", 512));
     int64_t R = 1;
     while (R * 2 * kk <= target) R *= 2;   // rows ratio between consecutive levels (power of two)
     if (R < 2) R = 2;
@@ -521,30 +529,29 @@ static std::vector<Level> plan_levels(int64_t n, int kk) {
 
 static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* out_idx, hipStream_t st, ts_search_stats* stats) {
     const int kk = std::max(k, 16);
+    const int variant = env_int("TS_MFMA_VARIANT", 0);
     if (!ix->attr_done) {
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_v2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kV2Lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_v2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kV2Lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_v2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kV2Lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_v2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, kV2Lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_v2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kV2Lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_v2_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, kV2Lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_v2_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, kV2Lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_v2_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, kV2Lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_v2_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, kV2Lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_v2_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, kV2Lds));
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
-        HIP_TRY(hipFuncSetAttribute((const void*)level_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kCandCap * 8));
+        HIP_TRY(hipFuncSetAttribute((const void*)level_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelLds));
         ix->attr_done = true;
     }
-    init_thr_kernel<<<1, 256, 0, st>>>(ix->thr, nq);
-    HIP_TRY(hipMemsetAsync(ix->fb_count, 0, 16, st));
-    HIP_TRY(hipMemsetAsync(ix->stat, 0, 16, st));
+    const int grid = std::max(1, std::min(env_int("TS_MFMA_GRID", ix->cu_count), 2048));
+    if (ix->priv_writers != 2 * grid) {
+        if (ix->priv) HIP_TRY(hipFree(ix->priv));
+        if (ix->pcount) HIP_TRY(hipFree(ix->pcount));
+        ix->priv = nullptr; ix->pcount = nullptr; ix->priv_writers = 0;
+        HIP_TRY(hipMalloc((void**)&ix->priv, (size_t)kMfmaQ * 2 * grid * kMfmaPrivCap * 8));
+        HIP_TRY(hipMalloc((void**)&ix->pcount, (size_t)kMfmaQ * 2 * grid * 4));
+        ix->priv_writers = 2 * grid;
+    }
+    init_thr_kernel<<<1, 256, 0, st>>>(ix->thr, nq, ix->fb_count, ix->stat);
     const std::vector<Level> lv = plan_levels(ix->n, kk);
-    const int grid = env_int("TS_MFMA_GRID", ix->cu_count);
+    static unsigned long long* g_dbg = nullptr;  // diagnostics (TS_MFMA_VARIANT=3): per-wave cycle sums
     for (size_t i = 0; i < lv.size(); ++i) {
+        const bool full_pass = (i + 1 == lv.size());
         MfmaArgs a;
         a.corpus = (const unsigned short*)ix->rows;
         a.n = ix->n;
@@ -552,30 +559,18 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         a.tile_stride = lv[i].stride;
         a.q = (const unsigned short*)ix->qstore;
         a.thr = ix->thr;
+        a.priv = ix->priv;
+        a.pcount = ix->pcount;
         a.cand = ix->cand;
         a.count = ix->count;
         a.cap = kCandCap;
         a.dbg = nullptr;
-        static unsigned long long* g_dbg = nullptr;  // diagnostics (TS_MFMA_VARIANT=5): per-wave cycle sums
-        if (env_int("TS_MFMA_VARIANT", 0) == 5) {
-            if (!g_dbg) HIP_TRY(hipMalloc((void**)&g_dbg, 4096 * 4 * 4 * 8));
+        if (variant == 3) {
+            if (!g_dbg) HIP_TRY(hipMalloc((void**)&g_dbg, 2048 * 4 * 4 * 8));
             a.dbg = g_dbg;
         }
-        hipEvent_t stop = (i + 1 == lv.size()) ? prof_begin(ix, st, ix->n) : nullptr;  // only the full pass is bracketed
-        if (env_int("TS_MFMA_KERNEL", 2) == 2) {
-            switch (env_int("TS_MFMA_VARIANT", 0)) {
-                case 1: mfma_topk_v2_kernel<1><<<grid, kV2Threads, kV2Lds, st>>>(a); break;
-                case 2: mfma_topk_v2_kernel<2><<<grid, kV2Threads, kV2Lds, st>>>(a); break;
-                case 3: mfma_topk_v2_kernel<3><<<grid, kV2Threads, kV2Lds, st>>>(a); break;
-                case 4: mfma_topk_v2_kernel<4><<<grid, kV2Threads, kV2Lds, st>>>(a); break;
-                case 5: mfma_topk_v2_kernel<5><<<grid, kV2Threads, kV2Lds, st>>>(a); break;
-                case 6: mfma_topk_v2_kernel<6><<<grid, kV2Threads, kV2Lds, st>>>(a); break;
-                case 7: mfma_topk_v2_kernel<7><<<grid, kV2Threads, kV2Lds, st>>>(a); break;
-                case 8: mfma_topk_v2_kernel<8><<<grid, kV2Threads, kV2Lds, st>>>(a); break;
-                case 9: mfma_topk_v2_kernel<9><<<grid, kV2Threads, kV2Lds, st>>>(a); break;
-                default: mfma_topk_v2_kernel<0><<<grid, kV2Threads, kV2Lds, st>>>(a); break;
-            }
-        } else switch (env_int("TS_MFMA_VARIANT", 0)) {
+        hipEvent_t stop = full_pass ? prof_begin(ix, st, ix->n) : nullptr;  // only the full pass is bracketed
+        switch (full_pass ? variant : 0) {
             case 1: mfma_topk_kernel<1><<<grid, kMfmaThreads, kMfmaLds, st>>>(a); break;
             case 2: mfma_topk_kernel<2><<<grid, kMfmaThreads, kMfmaLds, st>>>(a); break;
             case 3: mfma_topk_kernel<3><<<grid, kMfmaThreads, kMfmaLds, st>>>(a); break;
@@ -583,7 +578,7 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         }
         prof_end(stop, st);
         HIP_TRY(hipGetLastError());
-        if (a.dbg && i + 1 == lv.size()) {
+        if (a.dbg && full_pass) {
             std::vector<unsigned long long> h((size_t)grid * 16);
             HIP_TRY(hipStreamSynchronize(st));
             HIP_TRY(hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost));
@@ -594,12 +589,16 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         }
         LevelArgs l;
         memset(&l, 0, sizeof(l));
+        l.priv = ix->priv;
+        l.pcount = ix->pcount;
+        l.nwriters = 2 * grid;
+        l.priv_cap = kMfmaPrivCap;
         l.cand = ix->cand;
         l.count = ix->count;
         l.cap = kCandCap;
         l.kk = kk;
         l.thr = ix->thr;
-        l.final_level = (i + 1 == lv.size());
+        l.final_level = full_pass;
         l.out_scores = out_scores;
         l.out_idx = out_idx;
         l.k_user = k;
@@ -607,10 +606,10 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         l.fb_list = ix->fb_list;
         l.fb_count = ix->fb_count;
         l.stat_candidates = ix->stat;
-        level_select_kernel<<<nq, 512, kCandCap * 8, st>>>(l);
+        level_select_kernel<<<nq, 512, kLevelLds, st>>>(l);
         HIP_TRY(hipGetLastError());
     }
-    // exact fall-back for queries whose candidate list overflowed (device-side count; no-op when 0)
+    // exact fall-back for queries that lost candidates (device-side count; no-op when 0)
     TS_TRY(scan_search(ix, nq, k, out_scores, out_idx, ix->fb_list, ix->fb_count, st));
     if (stats) stats->levels = (int)lv.size();
     return TS_OK;
