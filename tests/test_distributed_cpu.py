@@ -1,0 +1,65 @@
+"""The N > 1 path on CPU: world_size-2 gloo ranks exercise partition + exchange + merge of
+ShardedSearcher.  The per-shard search and the merge are injected (numpy oracle) because the HIP
+kernels need a GPU; what is tested is that the distributed plumbing returns the whole-corpus answer."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import oracle
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _numpy_merge(scores, idx, k):
+    nparts, nq, _ = scores.shape
+    out_s = np.full((nq, k), -np.inf, np.float32)
+    out_i = np.full((nq, k), -1, np.int64)
+    for b in range(nq):
+        s, i = scores[:, b, :].reshape(-1), idx[:, b, :].reshape(-1)
+        keep = i >= 0
+        order = np.lexsort((i[keep], -s[keep]))[:k]
+        out_s[b, : order.size] = s[keep][order]
+        out_i[b, : order.size] = i[keep][order]
+    return out_s, out_i
+
+
+def _worker(rank, world, port, n, nq, k, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from theoremsearch_amd.distributed import ShardedSearcher, shard_bounds
+        q, c = oracle.golden_inputs(n, nq, 64, 123, "ip")
+        lo, hi = shard_bounds(n, world, rank)
+
+        def local_search(queries, kk):
+            s, i = oracle.search(queries, c[lo:hi], kk, "ip", "f32")
+            return s, np.where(i >= 0, i + lo, -1)
+
+        searcher = ShardedSearcher(local_search, merge=_numpy_merge)
+        scores, idx = searcher.search(q, k)
+        want_s, want_i = oracle.search(q, c, k, "ip", "f32")
+        ok = np.array_equal(idx, want_i) and np.allclose(scores, want_s, atol=1e-6)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,nq,k", [(1001, 5, 10), (7, 3, 5)])
+def test_sharded_search_two_gloo_ranks(n, nq, k):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), n, nq, k, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}

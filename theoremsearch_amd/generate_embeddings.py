@@ -1,0 +1,47 @@
+"""Mirror of ``ec2/generate_embeddings/{embedders,embeddings}.py`` (the production embedding job's
+two helpers) plus a device-resident variant that feeds the search index without a host hop.
+
+    EMBEDDERS                                  embedders.py:1-4
+    get_embedder(embedder_alias)               embeddings.py:10-14
+    embed_texts(embedder, texts, batch_size)   embeddings.py:16-40  -> list[list[float]], normalised
+
+The RDS paging / upsert driver around them (``__main__.py:10-105``) is out of scope (network I/O);
+``embed_into_index`` is what replaces its ``upsert_rows`` step when the destination is the HBM index.
+"""
+from __future__ import annotations
+
+from .encoder import SentenceEncoder
+from .index import TheoremIndex
+
+EMBEDDERS = {
+    "qwen": "Qwen/Qwen3-Embedding-0.6B",
+    "gemma": "google/embeddinggemma-300m",
+}
+
+
+def get_embedder(embedder_alias: str) -> SentenceEncoder:
+    model = SentenceEncoder(EMBEDDERS[embedder_alias])
+    model.eval()
+    return model
+
+
+def embed_texts(embedder, texts_to_embed: list[str], batch_size: int = 16):
+    """Normalised embeddings as ``list[list[float]]`` (reference returns ``embeddings.tolist()``)."""
+    embeddings = embedder.encode(texts_to_embed, normalize_embeddings=True, show_progress_bar=False,
+                                 batch_size=batch_size)
+    return embeddings.tolist()
+
+
+def embed_into_index(embedder: SentenceEncoder, index: TheoremIndex, texts: list[str], row0: int,
+                     batch_size: int = 16) -> None:
+    """Encode ``texts`` and store them as index rows ``[row0, row0 + len(texts))`` (upsert-by-position,
+    the HBM counterpart of ``ON CONFLICT (slogan_id) DO UPDATE``, __main__.py:85-99).  On a GPU the
+    encoder output goes device-to-device through ``ts_index_upload_device``."""
+    emb = embedder.encode_device(texts, batch_size=batch_size, normalize_embeddings=True)
+    if emb.is_cuda:
+        import torch
+        stream = torch.cuda.current_stream().cuda_stream
+        index.upload_device(emb.data_ptr(), "f32", emb.stride(0), row0, emb.shape[0], stream)
+        torch.cuda.current_stream().synchronize()
+    else:
+        index.upload(emb.numpy(), row0)
