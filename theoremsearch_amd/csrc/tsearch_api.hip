@@ -463,7 +463,7 @@ static int run_select_rounds(ts_index* ix, int slots, int m, int k, float* out_s
         a.row_offset = ix->row_offset;
         a.qlist = qlist;
         a.qcount = qcount;
-        if (m <= 4096) {
+        if (m <= 1024 || (k > 64 && m <= 4096)) {
             a.out_scores = out_scores;
             a.out_idx = out_idx;
             if (m <= 1024) select_kernel<1024><<<dim3(1, slots), 256, 0, st>>>(a);
@@ -471,10 +471,14 @@ static int run_select_rounds(ts_index* ix, int slots, int m, int k, float* out_s
             HIP_TRY(hipGetLastError());
             return TS_OK;
         }
-        const int nseg = (m + 4095) / 4096;
+        // intermediate round: many small sorts in parallel beat a few big ones (a 4096-key bitonic
+        // sort by one workgroup costs ~80 us, a 1024-key one ~15 us)
+        const int seg = (m > 65536) ? 4096 : 1024;
+        const int nseg = (m + seg - 1) / seg;
         a.out = scratch[which];
         a.out_stride = (int64_t)nseg * k;
-        select_kernel<4096><<<dim3(nseg, slots), 256, 0, st>>>(a);
+        if (seg == 4096) select_kernel<4096><<<dim3(nseg, slots), 256, 0, st>>>(a);
+        else select_kernel<1024><<<dim3(nseg, slots), 256, 0, st>>>(a);
         HIP_TRY(hipGetLastError());
         in = scratch[which];
         in_stride = a.out_stride;
