@@ -59,7 +59,8 @@ struct MfmaArgs {
     const unsigned short* corpus;  // bf16 [n_pad x 768]
     int64_t n;                     // real rows
     int64_t ntiles;                // tiles visited at this level
-    int64_t tile_stride;           // visited tile j is global tile j * tile_stride
+    int64_t tile_stride;           // visited tile j is global tile (j / run) * run * tile_stride + j % run:
+    int run;                       //   runs of `run` consecutive tiles, `run * tile_stride` tiles apart
     const unsigned short* q;       // bf16 [256 x 768], zero rows past nq
     const float* thr;              // [256] pass threshold per query (+inf for absent queries)
     u64* priv;                     // [256][W][kMfmaPrivCap] lane-private lists, W = 2 * gridDim.x writers
@@ -195,10 +196,12 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma_topk_kernel(MfmaArgs a) 
     // DMA source of this lane: row 8w + (lane >> 3) of the tile, swizzled chunk of K-block 0 of the unit
     const int drow = 8 * wave + (lane >> 3);
     const int dchunk = (lane & 7) ^ ((drow >> 1) & 7);
-    const int64_t tile_bytes = (int64_t)kTileRows * kMfmaD * 2 * a.tile_stride;  // between consecutive level tiles
+    const int64_t tile_bytes = (int64_t)kTileRows * kMfmaD * 2;
+    const int64_t run_jump = tile_bytes * ((int64_t)a.run * a.tile_stride - a.run + 1);  // last tile of a run -> next run
+    const int64_t g0 = (t0 / a.run) * a.run * a.tile_stride + t0 % a.run;               // global tile of level tile t0
     const unsigned char* tile_src = (const unsigned char*)a.corpus + (int64_t)drow * (kMfmaD * 2) + dchunk * 16 +
-                                    t0 * tile_bytes;                              // tile of the next unit to issue
-    const int64_t tile_step = tile_bytes;
+                                    g0 * tile_bytes;                              // tile of the next unit to issue
+    int issue_run_pos = (int)(t0 % a.run);                                        // its position inside its run
     int issue_u = 0;  // next unit to issue
     int issue_slot = 0;
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem + wave * 1024;
@@ -227,7 +230,10 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma_topk_kernel(MfmaArgs a) 
         const unsigned char* src = tile_src + (issue_u & 1) * (kMfmaUnitK * 2);
 #pragma unroll
         for (int j = 0; j < kMfmaPieces; ++j) lds_dma16(src + j * 128, lds0 + issue_slot * kMfmaUnitBytes + j * 4096);
-        if (issue_u & 1) tile_src += tile_step;
+        if (issue_u & 1) {
+            tile_src += (issue_run_pos + 1 == a.run) ? run_jump : tile_bytes;
+            issue_run_pos = (issue_run_pos + 1 == a.run) ? 0 : issue_run_pos + 1;
+        }
         ++issue_u;
         issue_slot = (issue_slot + 1 == kMfmaSlots) ? 0 : issue_slot + 1;
     }
@@ -287,7 +293,10 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma_topk_kernel(MfmaArgs a) 
             if ((s & 3) == 1 && do_issue) lds_dma16(isrc + (s >> 2) * 128, idst + (s >> 2) * 4096);               \
         }                                                                                                         \
         if (do_issue) {                                                                                           \
-            if (issue_u & 1) tile_src += tile_step;                                                               \
+            if (issue_u & 1) {                                                                                    \
+                tile_src += (issue_run_pos + 1 == a.run) ? run_jump : tile_bytes;                                 \
+                issue_run_pos = (issue_run_pos + 1 == a.run) ? 0 : issue_run_pos + 1;                             \
+            }                                                                                                     \
             ++issue_u;                                                                                            \
             issue_slot = (issue_slot + 1 == kMfmaSlots) ? 0 : issue_slot + 1;                                     \
         }                                                                                                         \
@@ -309,7 +318,8 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma_topk_kernel(MfmaArgs a) 
         const float m_b = max16(acc_b);
         const bool hit_a = __any(m_a >= thr_a), hit_b = __any(m_b >= thr_b);
         if (__builtin_expect(hit_a || hit_b, 0)) {
-            const int64_t tile_row = (t0 + t) * a.tile_stride * kTileRows;
+            const int64_t lt = t0 + t;  // level tile -> global tile -> first row
+            const int64_t tile_row = ((lt / a.run) * a.run * a.tile_stride + lt % a.run) * kTileRows;
             const int64_t row_base = tile_row + 4 * h;
             if (tile_row + kTileRows <= a.n) {
                 if (hit_a) mfma_append<true>(acc_a, thr_a, qid_a, writer, nwriters, cnt_a, row_base, a);

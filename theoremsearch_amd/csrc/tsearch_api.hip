@@ -509,23 +509,33 @@ static int scan_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
     return run_select_rounds(ix, nq, grid * k, k, out_scores, out_idx, qlist, qcount, st);
 }
 
-struct Level { int64_t stride, ntiles; };
+struct Level { int64_t stride, ntiles; int run; };
 
+// Threshold levels of the MFMA path, sparsest first.  Level i visits runs of `run` consecutive tiles
+// every run * stride tiles (stride 1 = every tile = the full pass) and passes on to level i+1 the
+// kk-th best score it saw as that level's pass threshold: a lower bound of the final kk-th best, so
+// nothing that belongs to the answer is ever dropped.  Expected candidates per query in level i+1 =
+// kk * rows(i+1) / rows(i): the full pass is planned for `target` candidates (few trips through
+// the append path), the sparser levels for up to kCandCap / 4 (they are short anyway); the first
+// level is small enough to run unthresholded.
 static std::vector<Level> plan_levels(int64_t n, int kk) {
     const int64_t T = (n + kTileRows - 1) / kTileRows;
-    // expected candidates per query a level passes on (measured optimum for 10M x 768, batch 256: 512;
-    // fewer = fewer trips through the append path of the full pass, but a larger sample level before it)
+    // measured optimum of the full pass for 10M x 768, batch 256: ~512 candidates per query
     const int target = std::max(64, env_int("TS_MFMA_TARGET_CANDS", 512));
-    int64_t R = 1;
-    while (R * 2 * kk <= target) R *= 2;   // rows ratio between consecutive levels (power of two)
-    if (R < 2) R = 2;
+    auto pow2_ratio = [&](int cands) { int64_t r = 2; while (r * 2 * kk <= cands) r *= 2; return r; };
+    // (a larger ratio between the sparse levels was tried: their selects then sort 4x the keys and cost more
+    // than the extra level)
+    const int64_t r_last = pow2_ratio(target), r_rest = pow2_ratio(env_int("TS_MFMA_TARGET_SPARSE", target));
     std::vector<Level> lv;
     int64_t stride = 1;
     for (;;) {
         const int64_t nt = (T + stride - 1) / stride;
-        lv.push_back({stride, nt});
+        // sampling in runs of consecutive tiles (shared DRAM pages / TLB entries) measured no different from
+        // single tiles; kept as a knob
+        const int run = (stride > 1 && nt >= 8 * 256) ? env_int("TS_MFMA_RUN", 1) : 1;
+        lv.push_back({stride, nt, run});
         if (nt * kTileRows <= kCandCap / 2) break;  // every score of this level fits: it can run unthresholded
-        stride *= R;
+        stride *= lv.size() == 1 ? r_last : r_rest;
     }
     std::reverse(lv.begin(), lv.end());
     return lv;
@@ -561,6 +571,7 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         a.n = ix->n;
         a.ntiles = lv[i].ntiles;
         a.tile_stride = lv[i].stride;
+        a.run = lv[i].run;
         a.q = (const unsigned short*)ix->qstore;
         a.thr = ix->thr;
         a.priv = ix->priv;
