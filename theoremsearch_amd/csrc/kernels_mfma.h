@@ -150,7 +150,9 @@ __device__ __forceinline__ void mfma_append(const f32x16& acc, float thr, int qi
 
 // VARIANT 0 = the product kernel.  Timing-only diagnostics (wrong results), selected with
 // TS_MFMA_VARIANT: 1 = no epilogue, 2 = DMA stream only, 3 = product + cycle stamps into a.dbg.
-template <int VARIANT>
+// SPARSE only changes the symbol: the sample levels show up under their own name in kernel traces, so
+// the statistics of the full-corpus pass are not mixed with them.
+template <int VARIANT, bool SPARSE>
 __global__ void __launch_bounds__(kMfmaThreads, 1) mfma_topk_kernel(MfmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;

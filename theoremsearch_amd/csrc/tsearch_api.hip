@@ -545,10 +545,11 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
     const int kk = std::max(k, 16);
     const int variant = env_int("TS_MFMA_VARIANT", 0);
     if (!ix->attr_done) {
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
         HIP_TRY(hipFuncSetAttribute((const void*)level_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelLds));
         ix->attr_done = true;
     }
@@ -585,11 +586,13 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
             a.dbg = g_dbg;
         }
         hipEvent_t stop = full_pass ? prof_begin(ix, st, ix->n) : nullptr;  // only the full pass is bracketed
-        switch (full_pass ? variant : 0) {
-            case 1: mfma_topk_kernel<1><<<grid, kMfmaThreads, kMfmaLds, st>>>(a); break;
-            case 2: mfma_topk_kernel<2><<<grid, kMfmaThreads, kMfmaLds, st>>>(a); break;
-            case 3: mfma_topk_kernel<3><<<grid, kMfmaThreads, kMfmaLds, st>>>(a); break;
-            default: mfma_topk_kernel<0><<<grid, kMfmaThreads, kMfmaLds, st>>>(a); break;
+        if (!full_pass) {
+            mfma_topk_kernel<0, true><<<grid, kMfmaThreads, kMfmaLds, st>>>(a);
+        } else switch (variant) {
+            case 1: mfma_topk_kernel<1, false><<<grid, kMfmaThreads, kMfmaLds, st>>>(a); break;
+            case 2: mfma_topk_kernel<2, false><<<grid, kMfmaThreads, kMfmaLds, st>>>(a); break;
+            case 3: mfma_topk_kernel<3, false><<<grid, kMfmaThreads, kMfmaLds, st>>>(a); break;
+            default: mfma_topk_kernel<0, false><<<grid, kMfmaThreads, kMfmaLds, st>>>(a); break;
         }
         prof_end(stop, st);
         HIP_TRY(hipGetLastError());

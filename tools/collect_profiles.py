@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Copy the judged summaries of one round out of gpurun_out/ into profiles/ and derive
+profiles/traffic.json (HBM bytes per launch of the dominant kernel from rocprofv3 --pmc
+FETCH_SIZE / WRITE_SIZE passes).
+
+gfx950 corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE is in KiB and reports exactly
+half of the bytes of a wide coalesced stream (16 B per lane; global_load and LDS-DMA alike), so the
+read side is doubled; WRITE_SIZE is taken as is (KiB)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def pmc_per_launch(d, counter, kernel_substr):
+    vals = []
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter and kernel_substr in r["Kernel_Name"]:
+                vals.append(float(r["Counter_Value"]))
+    return vals
+
+
+def main(src, tag):
+    out = os.path.join(ROOT, "profiles")
+    os.makedirs(out, exist_ok=True)
+    traffic = {}
+    tpath = os.path.join(out, "traffic.json")
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath))
+    notes = []
+    for w, kern in (("c3", "mfma_topk_kernel<0, false>"), ("c2", "scan_kernel")):
+        stats = glob.glob(os.path.join(src, f"trace_{w}", "**", "*kernel_stats.csv"), recursive=True)
+        if stats:
+            shutil.copy(stats[0], os.path.join(out, f"{tag}_{w}_kernel_stats.csv"))
+        fetch = pmc_per_launch(os.path.join(src, f"pmc_{w}_FETCH_SIZE"), "FETCH_SIZE", kern)
+        write = pmc_per_launch(os.path.join(src, f"pmc_{w}_WRITE_SIZE"), "WRITE_SIZE", kern)
+        if fetch:
+            # the full-corpus pass is the launch with the largest fetch
+            f_kib, w_kib = max(fetch), (max(write) if write else 0.0)
+            hbm = 2.0 * f_kib * 1024.0 + w_kib * 1024.0
+            traffic[f"{w}_n1"] = int(hbm)
+            notes.append(f"{w}: kernel {kern}: FETCH_SIZE {f_kib:.0f} KiB (x2 gfx950 correction) + WRITE_SIZE {w_kib:.0f} KiB "
+                         f"= {hbm / 1e9:.3f} GB per launch")
+    json.dump(traffic, open(tpath, "w"), indent=1)
+    with open(os.path.join(out, f"{tag}_traffic_notes.txt"), "w") as f:
+        f.write("HBM traffic per launch of the dominant kernel, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes),\n"
+                "command: python3 bench.py --workload <w> --steps 3 --warmup 1 --no-cpu-baseline --no-recall\n")
+        f.write("\n".join(notes) + "\n")
+    print("\n".join(notes))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
