@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--gen-threads", type=int, default=0)
+    ap.add_argument("--force-dist", action="store_true", help="debug: run the exchange + merge path even with one rank")
     ap.add_argument("--zero-queries", action="store_true", help="diagnostic: all-zero queries (power probe)")
     ap.add_argument("--zero-corpus", action="store_true", help="diagnostic: all-zero corpus (power probe)")
     args = ap.parse_args()
@@ -78,9 +79,10 @@ def main():
     if _ffi.device_count() <= 0:
         raise SystemExit("bench.py needs a HIP device (libtsearch has no CPU path)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     rows_total, dtype, nq = WORKLOADS[args.workload]
     if args.rows:
@@ -120,26 +122,42 @@ def main():
     q_host = oracle.synth_queries(0, nq, D, bf16=bf16)      # uint16 bits or float32
     if args.zero_queries:
         q_host = np.zeros_like(q_host)
-    stream = torch.cuda.current_stream().cuda_stream
+    main = torch.cuda.current_stream()
     q_dev = torch.from_numpy(q_host.view(np.int16) if bf16 else q_host).cuda()
-    out_s = torch.empty((nq, K), dtype=torch.float32, device="cuda")
-    out_i = torch.empty((nq, K), dtype=torch.int64, device="cuda")
-    if world > 1:
-        gat_s = torch.empty((world, nq, K), dtype=torch.float32, device="cuda")
-        gat_i = torch.empty((world, nq, K), dtype=torch.int64, device="cuda")
-        fin_s = torch.empty((nq, K), dtype=torch.float32, device="cuda")
-        fin_i = torch.empty((nq, K), dtype=torch.int64, device="cuda")
+    # one result block per step parity: scores [nq x K] f32 at offset 0, ids [nq x K] i64 at `idx_off`
+    idx_off = (nq * K * 4 + 7) // 8 * 8
+    blk = idx_off + nq * K * 8
+    res = [torch.empty(blk, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    use_dist = world > 1 or args.force_dist
     lib = _ffi.load()
     import ctypes as C
+    if use_dist:
+        # the exchange + merge of step i run on a side stream and overlap the search of step i+1
+        side = torch.cuda.Stream()
+        gat = [torch.empty(world * blk, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        fin_s = [torch.empty((nq, K), dtype=torch.float32, device="cuda") for _ in range(2)]
+        fin_i = [torch.empty((nq, K), dtype=torch.int64, device="cuda") for _ in range(2)]
+        ev_search = [torch.cuda.Event() for _ in range(2)]
+        ev_done = [torch.cuda.Event() for _ in range(2)]
+    step_no = [0]
 
     def step():
-        ix.search_device(q_dev.data_ptr(), dtype, nq, K, out_s.data_ptr(), out_i.data_ptr(), stream, algo=args.algo)
-        if world > 1:
-            dist.all_gather_into_tensor(gat_s, out_s)
-            dist.all_gather_into_tensor(gat_i, out_i)
-            _ffi.check(lib.ts_merge_topk(local_rank, C.c_void_p(gat_s.data_ptr()), C.c_void_p(gat_i.data_ptr()), world, nq,
-                                         K, K, C.c_void_p(fin_s.data_ptr()), C.c_void_p(fin_i.data_ptr()), 1,
-                                         C.c_void_p(stream)))
+        i = step_no[0]
+        step_no[0] += 1
+        b = i & 1
+        if use_dist and i >= 2:
+            main.wait_event(ev_done[b])        # step i-2's exchange has consumed res[b]
+        base = res[b].data_ptr()
+        ix.search_device(q_dev.data_ptr(), dtype, nq, K, base, base + idx_off, main.cuda_stream, algo=args.algo)
+        if use_dist:
+            ev_search[b].record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev_search[b])
+                dist.all_gather_into_tensor(gat[b], res[b])          # ONE collective: 12 * nq * K bytes per rank
+                _ffi.check(lib.ts_merge_topk_packed(local_rank, C.c_void_p(gat[b].data_ptr()), blk, idx_off, world, nq,
+                                                    K, K, C.c_void_p(fin_s[b].data_ptr()), C.c_void_p(fin_i[b].data_ptr()),
+                                                    C.c_void_p(side.cuda_stream)))
+                ev_done[b].record(side)
 
     def barrier():
         if world > 1:
@@ -184,8 +202,13 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes}
 
     # ---- recall@10 against the oracle (fp64 scores of the same bf16/fp32 values) -------------------
-    res_s = (fin_s if world > 1 else out_s).cpu().numpy()
-    res_i = (fin_i if world > 1 else out_i).cpu().numpy()
+    last = (step_no[0] - 1) & 1
+    if use_dist:
+        res_s, res_i = fin_s[last].cpu().numpy(), fin_i[last].cpu().numpy()
+    else:
+        raw = res[last].cpu().numpy()
+        res_s = raw[: nq * K * 4].view(np.float32).reshape(nq, K)
+        res_i = raw[idx_off: idx_off + nq * K * 8].view(np.int64).reshape(nq, K)
     recall = None
     if not args.no_recall:
         nchk = min(nq, 8)
@@ -257,13 +280,13 @@ def main():
             "config": {"workload": f"{rows_total}x{D} {dtype} corpus, batch-{nq} queries, top-{K} "
                                    f"(BASELINE.json configs[{ {'c2': 1, 'c3': 2, 'c4': 3}[args.workload] }])",
                        "rows": rows_total, "dim": D, "batch": nq, "k": K,
-                       "parallelism": f"corpus row-sharded x{world}" + (", RCCL all-gather of per-shard top-k" if world > 1 else "")},
+                       "parallelism": f"corpus row-sharded x{world}" + (", RCCL all-gather of per-shard top-k" if use_dist else "")},
             "recall_at_10": recall,
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or args.force_dist:
         dist.destroy_process_group()
 
 

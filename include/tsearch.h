@@ -129,6 +129,14 @@ int ts_merge_topk(int device, const float *scores, const int64_t *idx, int32_t n
                   int32_t k_in, int32_t k_out, float *out_scores, int64_t *out_idx, int on_device,
                   void *stream);
 
+/* The same for results that were exchanged as one packed block per part (one all-gather instead of
+ * two): part p starts at packed + p * part_stride_bytes and holds its scores [nq x k_in] float at
+ * offset 0 and its ids [nq x k_in] int64 at idx_offset_bytes (a multiple of 8).  Device memory only;
+ * enqueued on `stream`. */
+int ts_merge_topk_packed(int device, const void *packed, int64_t part_stride_bytes, int64_t idx_offset_bytes,
+                         int32_t nparts, int32_t nq, int32_t k_in, int32_t k_out, float *out_scores,
+                         int64_t *out_idx, void *stream);
+
 /* ---- kernel timing inside the library ----------------------------------------------------------
  * With profiling enabled, every launch of the dominant kernel of a search (the full-corpus pass of
  * the MFMA path, or the scan kernel) is bracketed by a hipEvent pair on the stream it runs on.

@@ -59,6 +59,8 @@ _SIGNATURES = {
     "ts_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_void_p, C.c_int, C.c_void_p]),
     "ts_merge_topk": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                 C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "ts_merge_topk_packed": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "ts_index_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "ts_index_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "ts_timer_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),

@@ -150,8 +150,9 @@ __global__ void __launch_bounds__(512) level_select_kernel(LevelArgs a) {
 // Cross-shard merge: per query, nparts * k_in (score, global id) pairs ->
 // best k_out.  Global ids are 64-bit here, so the sort runs on (ordered score, id) pairs.
 struct MergeArgs {
-    const float* scores;   // [nparts][nq][k_in]
-    const int64_t* idx;
+    const float* scores;   // part p: scores + p * part_stride (in floats), [nq][k_in]
+    const int64_t* idx;    // part p: idx + p * part_stride_idx (in int64), [nq][k_in]
+    int64_t part_stride, part_stride_idx;
     int nparts, nq, k_in, k_out;
     float* out_scores;     // [nq][k_out]
     int64_t* out_idx;
@@ -171,9 +172,9 @@ __global__ void __launch_bounds__(256) merge_kernel(MergeArgs a) {
         int64_t id = INT64_MAX;
         if (i < m) {
             const int part = i / a.k_in, j = i - part * a.k_in;
-            const int64_t off = ((int64_t)part * a.nq + q) * a.k_in + j;
-            const float s = a.scores[off];
-            const int64_t r = a.idx[off];
+            const int64_t off = (int64_t)q * a.k_in + j;
+            const float s = a.scores[(int64_t)part * a.part_stride + off];
+            const int64_t r = a.idx[(int64_t)part * a.part_stride_idx + off];
             if (r >= 0 && s == s) {
                 o = ord_f32(s);
                 id = r;

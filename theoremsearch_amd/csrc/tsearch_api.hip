@@ -778,6 +778,7 @@ extern "C" int ts_merge_topk(int device, const float* scores, const int64_t* idx
     hipStream_t st = (hipStream_t)stream;
     MergeArgs a;
     a.nparts = nparts; a.nq = nq; a.k_in = k_in; a.k_out = k_out;
+    a.part_stride = a.part_stride_idx = (int64_t)nq * k_in;
     const size_t nin = (size_t)nparts * nq * k_in, nout = (size_t)nq * k_out;
     if (on_device) {
         a.scores = scores; a.idx = idx; a.out_scores = out_scores; a.out_idx = out_idx;
@@ -828,6 +829,33 @@ extern "C" int ts_index_profile_read(ts_index* ix, int64_t* launches, double* to
     if (launches) *launches = cnt;
     if (total_ms) *total_ms = sum;
     if (rows_per_launch) *rows_per_launch = ix->prof_rows;
+    return TS_OK;
+}
+
+extern "C" int ts_merge_topk_packed(int device, const void* packed, int64_t part_stride_bytes, int64_t idx_offset_bytes,
+                                    int32_t nparts, int32_t nq, int32_t k_in, int32_t k_out, float* out_scores,
+                                    int64_t* out_idx, void* stream) {
+    if (!packed || !out_scores || !out_idx) return fail(TS_ERR_INVALID, "NULL argument");
+    if (nparts < 1 || nq < 0 || k_in < 1 || k_out < 1 || k_out > TS_MAX_K) return fail(TS_ERR_INVALID, "bad merge shape");
+    if ((int64_t)nparts * k_in > kMergeMax)
+        return fail(TS_ERR_UNSUPPORTED, "nparts * k_in = %lld exceeds %d", (long long)nparts * k_in, kMergeMax);
+    if (part_stride_bytes % 8 || idx_offset_bytes % 8 || idx_offset_bytes < (int64_t)nq * k_in * 4 ||
+        part_stride_bytes < idx_offset_bytes + (int64_t)nq * k_in * 8)
+        return fail(TS_ERR_INVALID, "bad packed layout (stride %lld, idx offset %lld)", (long long)part_stride_bytes,
+                    (long long)idx_offset_bytes);
+    if (nq == 0) return TS_OK;
+    TS_TRY(check_device(device));
+    HIP_TRY(hipSetDevice(device));
+    MergeArgs a;
+    a.nparts = nparts; a.nq = nq; a.k_in = k_in; a.k_out = k_out;
+    a.scores = (const float*)packed;
+    a.idx = (const int64_t*)((const char*)packed + idx_offset_bytes);
+    a.part_stride = part_stride_bytes / 4;
+    a.part_stride_idx = part_stride_bytes / 8;
+    a.out_scores = out_scores;
+    a.out_idx = out_idx;
+    merge_kernel<<<nq, 256, 0, (hipStream_t)stream>>>(a);
+    HIP_TRY(hipGetLastError());
     return TS_OK;
 }
 
