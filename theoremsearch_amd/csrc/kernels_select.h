@@ -12,6 +12,8 @@
 
 namespace ts {
 
+#define TS_MAX_K_INTERNAL 256
+
 struct SelectArgs {
     const u64* in;       // [slot][in_stride] keys (any order; 0 = empty)
     int64_t in_stride;
@@ -81,21 +83,27 @@ struct LevelArgs {
 };
 
 constexpr int kLevelSortMax = 8192;
-constexpr int kLevelLds = kLevelSortMax * 8 + 16;
+constexpr int kLevelThreads = 512;
+constexpr int kLevelLds = kLevelSortMax * 8 + (kLevelThreads / 64) * TS_MAX_K_INTERNAL * 8 + 16;
 
-__global__ void __launch_bounds__(512) level_select_kernel(LevelArgs a) {
+// KR = key registers per lane of the per-wave running top-k (1: kk <= 64, 4: kk <= 256).
+template <int KR>
+__global__ void __launch_bounds__(kLevelThreads) level_select_kernel(LevelArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64* keys = (u64*)smem;  // kLevelSortMax, then three counters (all LDS in the one dynamic region)
-    u32& fill = *(u32*)(smem + kLevelSortMax * 8);
-    u32& produced = *(u32*)(smem + kLevelSortMax * 8 + 4);
-    u32& base_shared = *(u32*)(smem + kLevelSortMax * 8 + 8);
+    u64* keys = (u64*)smem;                                   // kLevelSortMax gathered candidates
+    u64* best = (u64*)(smem + kLevelSortMax * 8);             // 8 waves x kk, then sorted
+    u32* ctr = (u32*)(smem + kLevelSortMax * 8 + (kLevelThreads / 64) * TS_MAX_K_INTERNAL * 8);
+    u32& fill = ctr[0];
+    u32& produced = ctr[1];
+    u32& base_shared = ctr[2];
     const int q = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     if (threadIdx.x == 0) {
         fill = 0;
         produced = 0;
     }
     __syncthreads();
-    // private lists
+    // gather: private lists ...
     for (int w = threadIdx.x; w < a.nwriters; w += blockDim.x) {
         const u32 made = a.pcount[(int64_t)q * a.nwriters + w];
         if (made == 0) continue;
@@ -106,7 +114,7 @@ __global__ void __launch_bounds__(512) level_select_kernel(LevelArgs a) {
         for (u32 e = 0; e < n; ++e)
             if (at + e < (u32)kLevelSortMax) keys[at + e] = src[e];
     }
-    // shared spill list
+    // ... and the shared spill list
     const u32 raw = a.count[q];
     const u32 ns = min(raw, (u32)a.cap);
     __syncthreads();
@@ -122,15 +130,39 @@ __global__ void __launch_bounds__(512) level_select_kernel(LevelArgs a) {
     const u32 total = fill;
     const bool lost = raw > (u32)a.cap || total > (u32)kLevelSortMax;
     const int cnt = (int)min(total, (u32)kLevelSortMax);
+    const int kk = a.kk;
+
+    // every wave streams its slice through a running top-kk (a key enters only if it beats the wave's
+    // kk-th: about kk ln(n / kk) insertions for n keys), then the waves' lists are merged by one sort
+    WaveTopK<KR> tk;
+    tk.init();
+    for (int i0 = wave * 64; i0 < cnt; i0 += nw * 64) {
+        const int i = i0 + lane;
+        const u64 key = (i < cnt) ? keys[i] : 0ull;
+        u64 m = __ballot(key > tk.thr);
+        while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const u64 K = shfl_u64(key, src);
+            if (K > tk.thr) tk.insert(K, kk, lane);
+        }
+    }
     int P = 2;
-    while (P < cnt) P <<= 1;
-    for (int i = cnt + threadIdx.x; i < P; i += blockDim.x) keys[i] = 0ull;
-    bitonic_sort_desc(keys, P, threadIdx.x, blockDim.x);
+    while (P < nw * kk) P <<= 1;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) best[i] = 0ull;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < KR; ++r) {
+        const int s = r * 64 + lane;
+        if (s < kk) best[wave * kk + s] = tk.key[r];
+    }
+    bitonic_sort_desc(best, P, threadIdx.x, blockDim.x);
+
     if (threadIdx.x == 0) a.count[q] = 0;
     if (!a.final_level) {
         // any subset of the candidates still gives a valid (lower) bound, so `lost` is harmless here
         if (threadIdx.x == 0) {
-            const u64 key = (a.kk - 1 < P) ? keys[a.kk - 1] : 0ull;
+            const u64 key = best[kk - 1];
             a.thr[q] = key ? key_score(key) : -INFINITY;
         }
         return;
@@ -141,7 +173,7 @@ __global__ void __launch_bounds__(512) level_select_kernel(LevelArgs a) {
         return;
     }
     for (int i = threadIdx.x; i < a.k_user; i += blockDim.x) {
-        const u64 key = (i < P) ? keys[i] : 0ull;
+        const u64 key = best[i];
         a.out_scores[(int64_t)q * a.k_user + i] = key ? key_score(key) : -INFINITY;
         a.out_idx[(int64_t)q * a.k_user + i] = key ? (int64_t)key_row(key) + a.row_offset : -1;
     }

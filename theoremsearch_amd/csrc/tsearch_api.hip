@@ -16,6 +16,7 @@
 #include "../../include/tsearch.h"
 #include "common.h"
 #include "kernels_mfma.h"
+#include "kernels_mfma16.h"
 #include "kernels_prep.h"
 #include "kernels_scan.h"
 #include "kernels_select.h"
@@ -520,8 +521,12 @@ struct Level { int64_t stride, ntiles; int run; };
 // level is small enough to run unthresholded.
 static std::vector<Level> plan_levels(int64_t n, int kk) {
     const int64_t T = (n + kTileRows - 1) / kTileRows;
-    // measured optimum of the full pass for 10M x 768, batch 256: ~512 candidates per query
-    const int target = std::max(64, env_int("TS_MFMA_TARGET_CANDS", 512));
+    // Cost model fitted on 10M / 1.25M x 768, batch 256: a sample row costs ~0.4 ns, a candidate of the next
+    // level ~0.27 us per query (the append path is ~1 us of wave time).  Minimising kk * N * c_row / F + c_cand * F
+    // gives F ~ 512 * sqrt(N / 1e7) candidates per query for the full pass.
+    int target = (int)(512.0 * std::sqrt(std::max<double>((double)n, 1.0) / 1e7));
+    target = std::max(target, 8 * kk);  // large k: keep the level ratio >= 8, or the sparse levels cost as much as the pass
+    target = std::min(2048, std::max(64, env_int("TS_MFMA_TARGET_CANDS", target)));
     auto pow2_ratio = [&](int cands) { int64_t r = 2; while (r * 2 * kk <= cands) r *= 2; return r; };
     // (a larger ratio between the sparse levels was tried: their selects then sort 4x the keys and cost more
     // than the extra level)
@@ -542,25 +547,34 @@ static std::vector<Level> plan_levels(int64_t n, int kk) {
 }
 
 static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* out_idx, hipStream_t st, ts_search_stats* stats) {
-    const int kk = std::max(k, 16);
+    // threshold rank: the k-th best of a sample is already a valid lower bound of the final k-th best; private
+    // lists + spill absorb the run-to-run spread of the candidate count, so no safety margin in the rank
+    const int kk = std::max(k, env_int("TS_MFMA_MIN_RANK", 1));
     const int variant = env_int("TS_MFMA_VARIANT", 0);
     if (!ix->attr_done) {
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
-        HIP_TRY(hipFuncSetAttribute((const void*)level_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelLds));
+        HIP_TRY(hipFuncSetAttribute((const void*)level_select_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelLds));
+        HIP_TRY(hipFuncSetAttribute((const void*)level_select_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelLds));
         ix->attr_done = true;
     }
     const int grid = std::max(1, std::min(env_int("TS_MFMA_GRID", ix->cu_count), 2048));
-    if (ix->priv_writers != 2 * grid) {
+    const int shape = env_int("TS_MFMA_SHAPE", 32);            // 32 = 32x32x16 MFMA, 16 = 16x16x32
+    const int nwriters = (shape == 16 ? 4 : 2) * grid;
+    if (ix->priv_writers != nwriters) {
         if (ix->priv) HIP_TRY(hipFree(ix->priv));
         if (ix->pcount) HIP_TRY(hipFree(ix->pcount));
         ix->priv = nullptr; ix->pcount = nullptr; ix->priv_writers = 0;
-        HIP_TRY(hipMalloc((void**)&ix->priv, (size_t)kMfmaQ * 2 * grid * kMfmaPrivCap * 8));
-        HIP_TRY(hipMalloc((void**)&ix->pcount, (size_t)kMfmaQ * 2 * grid * 4));
-        ix->priv_writers = 2 * grid;
+        HIP_TRY(hipMalloc((void**)&ix->priv, (size_t)kMfmaQ * nwriters * kMfmaPrivCap * 8));
+        HIP_TRY(hipMalloc((void**)&ix->pcount, (size_t)kMfmaQ * nwriters * 4));
+        ix->priv_writers = nwriters;
     }
     init_thr_kernel<<<1, 256, 0, st>>>(ix->thr, nq, ix->fb_count, ix->stat);
     const std::vector<Level> lv = plan_levels(ix->n, kk);
@@ -586,7 +600,12 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
             a.dbg = g_dbg;
         }
         hipEvent_t stop = full_pass ? prof_begin(ix, st, ix->n) : nullptr;  // only the full pass is bracketed
-        if (!full_pass) {
+        if (shape == 16) {
+            if (!full_pass) mfma16_topk_kernel<0, true><<<grid, kMfmaThreads, kMfmaLds, st>>>(a);
+            else if (variant == 1) mfma16_topk_kernel<1, false><<<grid, kMfmaThreads, kMfmaLds, st>>>(a);
+            else if (variant == 2) mfma16_topk_kernel<2, false><<<grid, kMfmaThreads, kMfmaLds, st>>>(a);
+            else mfma16_topk_kernel<0, false><<<grid, kMfmaThreads, kMfmaLds, st>>>(a);
+        } else if (!full_pass) {
             mfma_topk_kernel<0, true><<<grid, kMfmaThreads, kMfmaLds, st>>>(a);
         } else switch (variant) {
             case 1: mfma_topk_kernel<1, false><<<grid, kMfmaThreads, kMfmaLds, st>>>(a); break;
@@ -609,7 +628,7 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         memset(&l, 0, sizeof(l));
         l.priv = ix->priv;
         l.pcount = ix->pcount;
-        l.nwriters = 2 * grid;
+        l.nwriters = nwriters;
         l.priv_cap = kMfmaPrivCap;
         l.cand = ix->cand;
         l.count = ix->count;
@@ -624,7 +643,8 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         l.fb_list = ix->fb_list;
         l.fb_count = ix->fb_count;
         l.stat_candidates = ix->stat;
-        level_select_kernel<<<nq, 512, kLevelLds, st>>>(l);
+        if (kk <= 64) level_select_kernel<1><<<nq, kLevelThreads, kLevelLds, st>>>(l);
+        else level_select_kernel<4><<<nq, kLevelThreads, kLevelLds, st>>>(l);
         HIP_TRY(hipGetLastError());
     }
     // exact fall-back for queries that lost candidates (device-side count; no-op when 0)
