@@ -34,6 +34,7 @@ WORKLOADS = {
     "c2": (1_000_000, "f32", 1),
     "c3": (10_000_000, "bf16", 256),
     "c4": (50_000_000, "bf16", 256),
+    "c5": (10_000_000, "bf16", 256),   # encoder-in-loop: sentence-encoder forward feeds the C3 index
 }
 D = 768
 K = 10
@@ -57,6 +58,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--gen-threads", type=int, default=0)
+    ap.add_argument("--seq-len", type=int, default=32, help="c5: tokens per synthetic query")
     ap.add_argument("--force-dist", action="store_true", help="debug: run the exchange + merge path even with one rank")
     ap.add_argument("--zero-queries", action="store_true", help="diagnostic: all-zero queries (power probe)")
     ap.add_argument("--zero-corpus", action="store_true", help="diagnostic: all-zero corpus (power probe)")
@@ -139,7 +141,23 @@ def main():
         fin_i = [torch.empty((nq, K), dtype=torch.int64, device="cuda") for _ in range(2)]
         ev_search = [torch.cuda.Event() for _ in range(2)]
         ev_done = [torch.cuda.Event() for _ in range(2)]
+    encoder = None
+    if args.workload == "c5":
+        # BASELINE.json configs[4]: encoder forward (PyTorch-ROCm, random-init BERT-base-shaped stand-in: no weights
+        # offline) on synthetic token sequences, pooled + normalised on the device, handed to the search by pointer
+        from theoremsearch_amd.encoder import SentenceEncoder
+        encoder = SentenceEncoder()
+        g = torch.Generator(device="cpu").manual_seed(5678)
+        tok_ids = torch.randint(1000, 30000, (nq, args.seq_len), generator=g).cuda()
+        tok_ids[:, 0], tok_ids[:, -1] = 101, 102
+        tok_mask = torch.ones_like(tok_ids)
     step_no = [0]
+
+    def encode_queries():
+        with torch.inference_mode():
+            hidden = encoder.model(input_ids=tok_ids, attention_mask=tok_mask).last_hidden_state.float()
+            emb = hidden.mean(dim=1)
+            return torch.nn.functional.normalize(emb, p=2, dim=1).contiguous()
 
     def step():
         i = step_no[0]
@@ -148,7 +166,11 @@ def main():
         if use_dist and i >= 2:
             main.wait_event(ev_done[b])        # step i-2's exchange has consumed res[b]
         base = res[b].data_ptr()
-        ix.search_device(q_dev.data_ptr(), dtype, nq, K, base, base + idx_off, main.cuda_stream, algo=args.algo)
+        if encoder is not None:
+            emb = encode_queries()
+            ix.search_device(emb.data_ptr(), "f32", nq, K, base, base + idx_off, main.cuda_stream, algo=args.algo)
+        else:
+            ix.search_device(q_dev.data_ptr(), dtype, nq, K, base, base + idx_off, main.cuda_stream, algo=args.algo)
         if use_dist:
             ev_search[b].record(main)
             with torch.cuda.stream(side):
@@ -210,6 +232,8 @@ def main():
         res_s = raw[: nq * K * 4].view(np.float32).reshape(nq, K)
         res_i = raw[idx_off: idx_off + nq * K * 8].view(np.int64).reshape(nq, K)
     recall = None
+    if not args.no_recall and encoder is not None:
+        q_host = oracle.f32_to_bf16_bits(encode_queries().cpu().numpy())     # what the index multiplies: bf16-rounded
     if not args.no_recall:
         nchk = min(nq, 8)
         qf = oracle.bf16_bits_to_f32(q_host[:nchk]) if bf16 else q_host[:nchk]
@@ -278,7 +302,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"{rows_total}x{D} {dtype} corpus, batch-{nq} queries, top-{K} "
-                                   f"(BASELINE.json configs[{ {'c2': 1, 'c3': 2, 'c4': 3}[args.workload] }])",
+                                   f"(BASELINE.json configs[{ {'c2': 1, 'c3': 2, 'c4': 3, 'c5': 4}[args.workload] }])" + (f", encoder forward in the loop ({args.seq_len} tokens/query, random-init BERT-base shape)" if encoder is not None else ""),
                        "rows": rows_total, "dim": D, "batch": nq, "k": K,
                        "parallelism": f"corpus row-sharded x{world}" + (", RCCL all-gather of per-shard top-k" if use_dist else "")},
             "recall_at_10": recall,
