@@ -514,3 +514,27 @@ def golden_inputs(N: int, B: int, d: int, seed: int, metric: str):
         c *= s
         q *= s
     return q, c
+
+
+# ----------------------------------------------------------------------------
+# C restatement of the pgvector scan (oracle/pgvector_ip.c), loaded on demand
+# ----------------------------------------------------------------------------
+
+def pgvector_c_search(query_vec: np.ndarray, embeddings: np.ndarray, top_k: int):
+    """``ORDER BY embedding <#> q LIMIT k`` by the sequential fp32 loop of oracle/pgvector_ip.c.
+    Returns (rows int64 [k], similarity float64 [k]) with similarity = 1 - distance."""
+    import ctypes
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libpgvector_ip.so")
+    lib = ctypes.CDLL(path)
+    lib.pgv_order_by_ip_limit.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                          ctypes.c_void_p, ctypes.c_void_p]
+    e = np.ascontiguousarray(embeddings, dtype=np.float32)
+    q = np.ascontiguousarray(query_vec, dtype=np.float32).reshape(-1)
+    rows = np.empty(top_k, dtype=np.int64)
+    dist = np.empty(top_k, dtype=np.float32)
+    rc = lib.pgv_order_by_ip_limit(e.ctypes.data, e.shape[0], e.shape[1], q.ctypes.data, int(top_k), rows.ctypes.data,
+                                   dist.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"pgv_order_by_ip_limit failed: {rc}")
+    return rows, 1.0 - dist.astype(np.float64)

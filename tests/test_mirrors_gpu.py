@@ -41,6 +41,15 @@ def test_pgvector_adapter_matches_sql_semantics():
         want_i, want_sim = oracle.pgvector_search(qv, e, 10)
         assert [r["row"] for r in rows] == want_i.tolist()
         assert np.allclose([r["similarity"] for r in rows], want_sim, atol=1e-5)     # 1 + <e, q>
+        # and the sequential fp32 scan of the C restatement of pgvector's "<#>" (oracle/pgvector_ip.c)
+        import subprocess
+        from conftest import ROOT
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+        c_rows, c_sim = oracle.pgvector_c_search(qv, e, 10)
+        truth = oracle.scores_fp64(qv[None, :], e)
+        oracle.check_topk_against_truth(truth, np.array([[r["row"] for r in rows]]), None, 10)
+        oracle.check_topk_against_truth(truth, c_rows[None, :], None, 10)
+        assert np.allclose([r["similarity"] for r in rows], c_sim, atol=1e-5)
         rows_w = pgvector.search(ix, qv, 5, citation_weight=0.02, citations=cit)
         pool_i, pool_sim = oracle.pgvector_search(qv, e, oracle.pool_size(5))
         ri, rs, rw = oracle.citation_weighted_rerank(pool_i, pool_sim, [cit[i] for i in pool_i], 0.02, 5)
