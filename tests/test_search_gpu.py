@@ -23,7 +23,7 @@ def ts():
 
 
 def algos_for(dtype, d):
-    return ["scan", "mfma"] if (dtype == "bf16" and d == 768) else ["scan"]
+    return ["scan", "mfma"] if (dtype == "bf16" and d in (768, 1024)) else ["scan"]
 
 
 def check(q, c, metric, dtype, k, scores, idx):
@@ -153,8 +153,28 @@ def test_mfma_and_scan_agree_and_levels_run(ts):
         assert np.mean(i1 == i2) > 0.999
         s3, i3 = ix.search(q, 200, algo="mfma")
         check(q, c, "ip", "bf16", 200, s3, i3)
-        s4, i4 = ix.search(q[:1], 5)                              # auto picks the MFMA path at this size
+        s4, i4, st4 = ix.search(q[:1], 5, return_stats=True)      # a single query goes through the scan ...
         check(q[:1], c, "ip", "bf16", 5, s4, i4)
+        s5, i5, st5 = ix.search(q[:9], 5, return_stats=True)      # ... a batch through the MFMA path
+        check(q[:9], c, "ip", "bf16", 5, s5, i5)
+        assert (st4["algo"], st5["algo"]) == (1, 2)
+
+
+def test_mfma_d1024_and_query_blocks(ts):
+    # Qwen-sized rows (vector(1024), rds_schema.sql:50-56): 128 queries per launch, so 300 queries = 3 blocks
+    q, c = oracle.golden_inputs(50_000, 300, 1024, 33, "ip")
+    with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as ix:
+        s1, i1, st = ix.search(q, 10, algo="mfma", return_stats=True)
+        assert st["algo"] == 2 and st["fallback_queries"] == 0
+        check(q, c, "ip", "bf16", 10, s1, i1)
+        s2, i2 = ix.search(q[:130], 10, algo="scan")
+        assert np.mean(i1[:130] == i2) > 0.999
+    # d = 768: 128 < nq <= 256 runs two query groups per wave, nq <= 128 one
+    q, c = oracle.golden_inputs(40_000, 200, 768, 34, "cos")
+    with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="cos") as ix:
+        for nq in (128, 129, 200):
+            s, i = ix.search(q[:nq], 7, algo="mfma")
+            check(q[:nq], c, "cos", "bf16", 7, s, i)
 
 
 def test_candidate_overflow_falls_back_exactly(ts):

@@ -16,7 +16,6 @@
 #include "../../include/tsearch.h"
 #include "common.h"
 #include "kernels_mfma.h"
-#include "kernels_mfma16.h"
 #include "kernels_prep.h"
 #include "kernels_scan.h"
 #include "kernels_select.h"
@@ -381,7 +380,7 @@ static int ensure_search_scratch(ts_index* ix, int k) {
         TS_TRY(ensure(&p, &z, 16));
         ix->stat = (unsigned long long*)p;
     }
-    if (!ix->cand && ix->dtype == TS_BF16 && ix->d == kMfmaD) {
+    if (!ix->cand && ix->dtype == TS_BF16 && (ix->d == 768 || ix->d == 1024)) {
         void* p = nullptr;
         z = 0;
         TS_TRY(ensure(&p, &z, (size_t)kQBlock * kCandCap * 8));
@@ -546,28 +545,47 @@ static std::vector<Level> plan_levels(int64_t n, int kk) {
     return lv;
 }
 
+template <int D, int GROUPS>
+static int launch_mfma(bool full_pass, int variant, int grid, hipStream_t st, const MfmaArgs& a) {
+    constexpr int lds = MfmaDims<D>::kLds;
+    static bool attr_done = false;  // per instantiation; the attribute is a property of the code object
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<D, GROUPS, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<D, GROUPS, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<D, GROUPS, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<D, GROUPS, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<D, GROUPS, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_done = true;
+    }
+    if (!full_pass) mfma_topk_kernel<D, GROUPS, 0, true><<<grid, kMfmaThreads, lds, st>>>(a);
+    else if (variant == 1) mfma_topk_kernel<D, GROUPS, 1, false><<<grid, kMfmaThreads, lds, st>>>(a);
+    else if (variant == 2) mfma_topk_kernel<D, GROUPS, 2, false><<<grid, kMfmaThreads, lds, st>>>(a);
+    else if (variant == 3) mfma_topk_kernel<D, GROUPS, 3, false><<<grid, kMfmaThreads, lds, st>>>(a);
+    else mfma_topk_kernel<D, GROUPS, 0, false><<<grid, kMfmaThreads, lds, st>>>(a);
+    HIP_TRY(hipGetLastError());
+    return TS_OK;
+}
+
+// Queries one launch of the MFMA kernel serves for this index / batch: d = 768 holds two query groups per wave
+// (256 queries; one group = half the matrix work when the batch is <= 128), d = 1024 one (128 queries).
+static int mfma_block_queries(const ts_index* ix, int nq) {
+    if (ix->d == 1024) return 128;
+    return nq <= 128 && env_int("TS_MFMA_GROUPS", 0) != 2 ? 128 : 256;
+}
+
 static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* out_idx, hipStream_t st, ts_search_stats* stats) {
     // threshold rank: the k-th best of a sample is already a valid lower bound of the final k-th best; private
     // lists + spill absorb the run-to-run spread of the candidate count, so no safety margin in the rank
     const int kk = std::max(k, env_int("TS_MFMA_MIN_RANK", 1));
     const int variant = env_int("TS_MFMA_VARIANT", 0);
+    const int groups = mfma_block_queries(ix, nq) / 128;
     if (!ix->attr_done) {
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfmaLds));
         HIP_TRY(hipFuncSetAttribute((const void*)level_select_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelLds));
         HIP_TRY(hipFuncSetAttribute((const void*)level_select_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelLds));
         ix->attr_done = true;
     }
     const int grid = std::max(1, std::min(env_int("TS_MFMA_GRID", ix->cu_count), 2048));
-    const int shape = env_int("TS_MFMA_SHAPE", 32);            // 32 = 32x32x16 MFMA, 16 = 16x16x32
-    const int nwriters = (shape == 16 ? 4 : 2) * grid;
+    const int nwriters = 2 * grid;
     if (ix->priv_writers != nwriters) {
         if (ix->priv) HIP_TRY(hipFree(ix->priv));
         if (ix->pcount) HIP_TRY(hipFree(ix->pcount));
@@ -600,21 +618,12 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
             a.dbg = g_dbg;
         }
         hipEvent_t stop = full_pass ? prof_begin(ix, st, ix->n) : nullptr;  // only the full pass is bracketed
-        if (shape == 16) {
-            if (!full_pass) mfma16_topk_kernel<0, true><<<grid, kMfmaThreads, kMfmaLds, st>>>(a);
-            else if (variant == 1) mfma16_topk_kernel<1, false><<<grid, kMfmaThreads, kMfmaLds, st>>>(a);
-            else if (variant == 2) mfma16_topk_kernel<2, false><<<grid, kMfmaThreads, kMfmaLds, st>>>(a);
-            else mfma16_topk_kernel<0, false><<<grid, kMfmaThreads, kMfmaLds, st>>>(a);
-        } else if (!full_pass) {
-            mfma_topk_kernel<0, true><<<grid, kMfmaThreads, kMfmaLds, st>>>(a);
-        } else switch (variant) {
-            case 1: mfma_topk_kernel<1, false><<<grid, kMfmaThreads, kMfmaLds, st>>>(a); break;
-            case 2: mfma_topk_kernel<2, false><<<grid, kMfmaThreads, kMfmaLds, st>>>(a); break;
-            case 3: mfma_topk_kernel<3, false><<<grid, kMfmaThreads, kMfmaLds, st>>>(a); break;
-            default: mfma_topk_kernel<0, false><<<grid, kMfmaThreads, kMfmaLds, st>>>(a); break;
-        }
+        int rc;
+        if (ix->d == 1024) rc = launch_mfma<1024, 1>(full_pass, variant, grid, st, a);
+        else if (groups == 1) rc = launch_mfma<768, 1>(full_pass, variant, grid, st, a);
+        else rc = launch_mfma<768, 2>(full_pass, variant, grid, st, a);
         prof_end(stop, st);
-        HIP_TRY(hipGetLastError());
+        TS_TRY(rc);
         if (a.dbg && full_pass) {
             std::vector<unsigned long long> h((size_t)grid * 16);
             HIP_TRY(hipStreamSynchronize(st));
@@ -662,16 +671,20 @@ static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_
     if (nq < 0) return fail(TS_ERR_INVALID, "nq = %d", nq);
     if (k < 1 || k > TS_MAX_K) return fail(TS_ERR_INVALID, "k = %d outside [1, %d]", k, TS_MAX_K);
     if (algo < TS_ALGO_AUTO || algo > TS_ALGO_MFMA) return fail(TS_ERR_INVALID, "algo %d", algo);
-    const bool mfma_ok = ix->dtype == TS_BF16 && ix->d == kMfmaD && ix->n >= 1;
+    const bool mfma_ok = ix->dtype == TS_BF16 && (ix->d == 768 || ix->d == 1024) && ix->n >= 1;
     if (algo == TS_ALGO_MFMA && !mfma_ok)
-        return fail(TS_ERR_UNSUPPORTED, "the MFMA path needs a bf16 index with d = %d", kMfmaD);
+        return fail(TS_ERR_UNSUPPORTED, "the MFMA path needs a bf16 index with d = 768 or 1024");
     if (nq == 0) return TS_OK;
     std::lock_guard<std::mutex> lock(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
     TS_TRY(ensure_search_scratch(ix, k));
     int use = algo;
-    if (use == TS_ALGO_AUTO) use = (mfma_ok && ix->n >= env_int("TS_MFMA_MIN_ROWS", 16384)) ? TS_ALGO_MFMA : TS_ALGO_SCAN;
+    // The scan serves 4 queries per pass at the HBM rate; the MFMA path serves up to 256 per pass but its pass is
+    // ~1.7x longer (matrix + HBM load drops the clock): a handful of queries is faster through the scan.
+    if (use == TS_ALGO_AUTO)
+        use = (mfma_ok && ix->n >= env_int("TS_MFMA_MIN_ROWS", 16384) && nq > env_int("TS_SCAN_MAX_QUERIES", 4)) ? TS_ALGO_MFMA
+                                                                                                          : TS_ALGO_SCAN;
     if (stats) stats->algo = use;
 
     float* dscores = out_scores;
@@ -692,8 +705,10 @@ static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_
     const size_t q_elem = q_dtype == TS_BF16 ? 2 : 4;
     if (!q_on_device) TS_TRY(ensure(&ix->stage, &ix->stage_bytes, kStageBytes));
 
-    for (int q0 = 0; q0 < nq; q0 += kQBlock) {
-        const int nb = std::min(kQBlock, nq - q0);
+    // queries are served in blocks: 256 per pass, or what one launch of the MFMA kernel holds
+    const int block = (use == TS_ALGO_MFMA) ? mfma_block_queries(ix, nq) : kQBlock;
+    for (int q0 = 0; q0 < nq; q0 += block) {
+        const int nb = std::min(block, nq - q0);
         const void* qsrc = (const char*)queries + (size_t)q0 * ix->d * q_elem;
         if (!q_on_device) {
             HIP_TRY(hipMemcpyAsync(ix->stage, qsrc, (size_t)nb * ix->d * q_elem, hipMemcpyHostToDevice, st));
