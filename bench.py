@@ -36,7 +36,7 @@ WORKLOADS = {
     "c4": (50_000_000, "bf16", 256),
     "c5": (10_000_000, "bf16", 256),   # encoder-in-loop: sentence-encoder forward feeds the C3 index
 }
-D = 768
+D = 768   # overridden by --dim (diagnostic: the production table of the reference is vector(1024), rds_schema.sql:50)
 K = 10
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -58,11 +58,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--gen-threads", type=int, default=0)
+    ap.add_argument("--dim", type=int, default=768, help="embedding dimension (diagnostic; BASELINE configs use 768)")
     ap.add_argument("--seq-len", type=int, default=32, help="c5: tokens per synthetic query")
     ap.add_argument("--force-dist", action="store_true", help="debug: run the exchange + merge path even with one rank")
     ap.add_argument("--zero-queries", action="store_true", help="diagnostic: all-zero queries (power probe)")
     ap.add_argument("--zero-corpus", action="store_true", help="diagnostic: all-zero corpus (power probe)")
     args = ap.parse_args()
+    global D
+    D = args.dim
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -72,6 +72,46 @@ def test_encoder_to_index_without_host_hop(encoder):
         assert idx[:, 0].tolist() == list(range(40)) and np.allclose(scores[:, 0], 1.0, atol=1e-5)
 
 
+def test_generate_embeddings_driver_upserts_pages(encoder):
+    import theoremsearch_amd as ts
+    from theoremsearch_amd import generate_embeddings as ge
+    rows = [{"slogan_id": i, "slogan": f"Slogan {i}: a bound for the {i}-th eigenvalue."} for i in range(200)]
+    pages = [rows[i:i + 128] for i in range(0, 200, 128)]                     # page size 128 (__main__.py:75)
+    with ts.TheoremIndex(200, 768, dtype="f32", metric="cos") as ix:
+        assert ge.generate_embeddings(pages, "gemma", ix, embedder=encoder) == 200
+        assert ge.generate_embeddings(pages, "gemma", ix, embedder=encoder) == 0   # NOT EXISTS filter: nothing left
+        first = ix.download()
+        changed = [dict(rows[5], slogan="A completely different statement.")]
+        assert ge.generate_embeddings([changed], "gemma", ix, embedder=encoder, overwrite=True) == 1
+        second = ix.download()
+        assert not np.allclose(first[5], second[5], atol=1e-3) and np.array_equal(first[6:], second[6:])
+        q = np.array(ge.embed_texts(encoder, [rows[77]["slogan"]]), dtype=np.float32)
+        scores, idx = ix.search(q, 1)
+        assert idx[0, 0] == 77
+
+
+def test_concurrent_searches_on_one_handle():
+    # Streamlit runs every session on its own thread against one shared library (streamlit_app.py:52)
+    import threading
+    import theoremsearch_amd as ts
+    q, c = oracle.golden_inputs(60_000, 64, 768, 91, "ip")
+    want_s, want_i = oracle.search(q, c, 5, "ip", "bf16")
+    errors = []
+    with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as ix:
+        def worker(t):
+            try:
+                for rep in range(5):
+                    lo = (7 * t + rep) % 60
+                    s, i = ix.search(q[lo:lo + 1 + t], 5)
+                    assert np.array_equal(i, want_i[lo:lo + 1 + t]), (t, rep)
+            except Exception as e:  # noqa: BLE001
+                errors.append(repr(e))
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+        [t.start() for t in threads]
+        [t.join() for t in threads]
+    assert not errors, errors
+
+
 def test_embedding_library_round_trip(tmp_path, monkeypatch, encoder):
     from theoremsearch_amd import app_create_embeddings as ace
     papers = tmp_path / "app_papers"

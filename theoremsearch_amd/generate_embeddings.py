@@ -45,3 +45,41 @@ def embed_into_index(embedder: SentenceEncoder, index: TheoremIndex, texts: list
         torch.cuda.current_stream().synchronize()
     else:
         index.upload(emb.numpy(), row0)
+
+
+def generate_embeddings(pages, embedder_alias: str, index: TheoremIndex, slot_of=None, batch_size: int = 16,
+                        overwrite: bool = False, embedder=None) -> int:
+    """The loop of ``ec2/generate_embeddings/__main__.py:10-105`` with the RDS calls factored out.
+
+    The reference pages ``{"slogan_id", "slogan"}`` rows out of Postgres with keyset pagination
+    (page size 128, ``__main__.py:70-77``), skips slogans that already have an embedding unless
+    ``--overwrite`` (``:32-41``), embeds each page (``:78``) and upserts ``{"slogan_id", "embedding"}``
+    into ``theorem_embedding_<alias>`` with ``ON CONFLICT (slogan_id) DO UPDATE`` (``:85-99``).
+    Here ``pages`` is any iterable of such pages (the database cursor stays the caller's business),
+    the destination is the HBM index, and ``slot_of(slogan_id) -> row`` is the upsert key (default:
+    the slogan id is the row).  Rows are written device-to-device.  Returns the number of rows embedded.
+    """
+    if embedder is None:
+        embedder = get_embedder(embedder_alias)
+    slot_of = slot_of or (lambda slogan_id: int(slogan_id))
+    seen = getattr(index, "_filled", None)
+    if seen is None:
+        seen = index._filled = set()
+    n_done = 0
+    for page in pages:
+        todo = [r for r in page if overwrite or slot_of(r["slogan_id"]) not in seen]
+        if not todo:
+            continue
+        todo.sort(key=lambda r: slot_of(r["slogan_id"]))
+        # contiguous runs of slots go down in one upload each
+        start = 0
+        while start < len(todo):
+            end = start + 1
+            while end < len(todo) and slot_of(todo[end]["slogan_id"]) == slot_of(todo[end - 1]["slogan_id"]) + 1:
+                end += 1
+            run = todo[start:end]
+            embed_into_index(embedder, index, [r["slogan"] for r in run], slot_of(run[0]["slogan_id"]), batch_size=batch_size)
+            seen.update(slot_of(r["slogan_id"]) for r in run)
+            n_done += len(run)
+            start = end
+    return n_done
