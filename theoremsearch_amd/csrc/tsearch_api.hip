@@ -527,9 +527,11 @@ static std::vector<Level> plan_levels(int64_t n, int kk) {
     target = std::max(target, 8 * kk);  // large k: keep the level ratio >= 8, or the sparse levels cost as much as the pass
     target = std::min(2048, std::max(64, env_int("TS_MFMA_TARGET_CANDS", target)));
     auto pow2_ratio = [&](int cands) { int64_t r = 2; while (r * 2 * kk <= cands) r *= 2; return r; };
-    // (a larger ratio between the sparse levels was tried: their selects then sort 4x the keys and cost more
-    // than the extra level)
-    const int64_t r_last = pow2_ratio(target), r_rest = pow2_ratio(env_int("TS_MFMA_TARGET_SPARSE", target));
+    const int64_t r_last = pow2_ratio(target);
+    // The sparsest level runs unthresholded: every score becomes a candidate, so it may hold at most
+    // kLevelSortMax rows (what one select sorts) and one tile per workgroup (16 entries per private list).
+    const int64_t first_rows = std::min<int64_t>(kLevelSortMax, (int64_t)env_int("TS_MFMA_FIRST_ROWS", kLevelSortMax));
+    const int64_t r_cap = std::max<int64_t>(2, pow2_ratio(env_int("TS_MFMA_TARGET_SPARSE", 1280)));
     std::vector<Level> lv;
     int64_t stride = 1;
     for (;;) {
@@ -538,8 +540,15 @@ static std::vector<Level> plan_levels(int64_t n, int kk) {
         // single tiles; kept as a knob
         const int run = (stride > 1 && nt >= 8 * 256) ? env_int("TS_MFMA_RUN", 1) : 1;
         lv.push_back({stride, nt, run});
-        if (nt * kTileRows <= kCandCap / 2) break;  // every score of this level fits: it can run unthresholded
-        stride *= lv.size() == 1 ? r_last : r_rest;
+        if (nt * kTileRows <= first_rows) break;  // every score of this level fits: it can run unthresholded
+        if (lv.size() == 1) {
+            stride *= r_last;
+        } else {
+            // smallest ratio that reaches the unthresholded size in one step, if the cap allows it
+            int64_t need = 2;
+            while (need < r_cap && ((T + stride * need - 1) / (stride * need)) * kTileRows > first_rows) need *= 2;
+            stride *= need;
+        }
     }
     std::reverse(lv.begin(), lv.end());
     return lv;
