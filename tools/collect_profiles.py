@@ -33,7 +33,7 @@ def main(src, tag):
     if os.path.exists(tpath):
         traffic = json.load(open(tpath))
     notes = []
-    for w, kern in (("c3", "mfma_topk_kernel<0, false>"), ("c2", "scan_kernel")):
+    for w, kern in (("c3", "mfma_topk_kernel<768, 2, 0, false>"), ("c2", "scan_kernel")):
         stats = glob.glob(os.path.join(src, f"trace_{w}", "**", "*kernel_stats.csv"), recursive=True)
         if stats:
             shutil.copy(stats[0], os.path.join(out, f"{tag}_{w}_kernel_stats.csv"))
