@@ -137,6 +137,22 @@ int ts_merge_topk_packed(int device, const void *packed, int64_t part_stride_byt
                          int32_t nparts, int32_t nq, int32_t k_in, int32_t k_out, float *out_scores,
                          int64_t *out_idx, void *stream);
 
+/* ---- encoder epilogue ------------------------------------------------
+ * Pooling + optional L2 normalisation + cast of a transformer's last hidden state, fused in one kernel that
+ * writes straight into a buffer the search (or ts_index_upload_device) consumes - what sentence-transformers
+ * does with mean pooling / last-token pooling + F.normalize + .to(dtype) after the forward
+ * (SentenceTransformer.encode(..., normalize_embeddings=True): parsed_papers_to_vector_rds/embeddings.py:31-37,
+ * ec2/generate_embeddings/embeddings.py:24-30, streamlit_app.py:173).
+ * hidden: device [n x seq x d], h_dtype TS_F32 | TS_BF16, dense.  attention_mask: device int64 [n x seq]
+ * (1 = token, 0 = padding).  pooling: TS_POOL_MEAN (sum of unmasked tokens / max(count, 1e-9)),
+ * TS_POOL_LAST (last unmasked token), TS_POOL_CLS (token 0).  out: device [n x out_ld], out_dtype TS_F32 | TS_BF16. */
+#define TS_POOL_MEAN 0
+#define TS_POOL_LAST 1
+#define TS_POOL_CLS 2
+int ts_pool_normalize(int device, const void *hidden, int h_dtype, const int64_t *attention_mask, int64_t n,
+                      int32_t seq, int32_t d, int pooling, int normalize, void *out, int out_dtype,
+                      int64_t out_ld, void *stream);
+
 /* ---- kernel timing inside the library ----------------------------------------------------------
  * With profiling enabled, every launch of the dominant kernel of a search (the full-corpus pass of
  * the MFMA path, or the scan kernel) is bracketed by a hipEvent pair on the stream it runs on.

@@ -29,6 +29,39 @@ def test_cos_sim_and_semantic_search_match_oracle():
     oracle.check_topk_against_truth(truth, idx, scores, 5)
 
 
+def test_fused_pooling_epilogue_matches_torch():
+    import ctypes as C
+    import torch
+    from theoremsearch_amd import _ffi
+    lib = _ffi.load()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for dtype in (torch.float32, torch.bfloat16):
+        for d in (768, 1024):
+            hidden = torch.randn((37, 19, d), generator=g).to(dtype).cuda()
+            lens = torch.randint(1, 20, (37,), generator=g)
+            mask = (torch.arange(19)[None, :] < lens[:, None]).to(torch.int64).cuda()
+            hf, mf = hidden.double(), mask.unsqueeze(-1).double()          # fp64 reference of the same inputs
+            refs = {0: (hf * mf).sum(1) / mf.sum(1).clamp(min=1e-9),
+                    1: hf[torch.arange(37, device="cuda"), mask.sum(1) - 1], 2: hf[:, 0]}
+            for pooling, ref in refs.items():
+                for normalize in (0, 1):
+                    want = (torch.nn.functional.normalize(ref, p=2, dim=1) if normalize else ref).float()
+                    out = torch.empty((37, d), dtype=torch.float32, device="cuda")
+                    _ffi.check(lib.ts_pool_normalize(0, C.c_void_p(hidden.data_ptr()), 1 if dtype == torch.bfloat16 else 0,
+                                                     C.c_void_p(mask.data_ptr()), 37, 19, d, pooling, normalize,
+                                                     C.c_void_p(out.data_ptr()), 0, d,
+                                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                    torch.cuda.synchronize()
+                    assert torch.allclose(out, want, atol=1e-5, rtol=1e-5), (dtype, d, pooling, normalize, (out - want).abs().max().item())
+                    outb = torch.empty((37, d), dtype=torch.bfloat16, device="cuda")
+                    _ffi.check(lib.ts_pool_normalize(0, C.c_void_p(hidden.data_ptr()), 1 if dtype == torch.bfloat16 else 0,
+                                                     C.c_void_p(mask.data_ptr()), 37, 19, d, pooling, normalize,
+                                                     C.c_void_p(outb.data_ptr()), 1, d,
+                                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                    torch.cuda.synchronize()
+                    assert torch.allclose(outb.float(), want, atol=1e-5, rtol=2 ** -7), (dtype, d, pooling, normalize)   # one bf16 rounding
+
+
 def test_pgvector_adapter_matches_sql_semantics():
     import theoremsearch_amd as ts
     from theoremsearch_amd import pgvector

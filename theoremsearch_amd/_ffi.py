@@ -61,6 +61,8 @@ _SIGNATURES = {
                                 C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ts_merge_topk_packed": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ts_pool_normalize": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     "ts_index_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "ts_index_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "ts_timer_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
@@ -75,11 +77,35 @@ def lib_path() -> str:
     return _LIB_PATH
 
 
+def _preload_torch_hip_runtime() -> None:
+    """One HIP runtime per process.  The PyTorch-ROCm wheel bundles its own libamdhip64 under torch/lib; if
+    libtsearch.so pulls in the system runtime (/opt/rocm) first, a later ``import torch`` binds to that copy and
+    its device discovery fails ("No HIP GPUs are available").  So when torch is installed but not imported yet,
+    load its bundled runtime first (globally): libtsearch then resolves against it, exactly as it does when the
+    application imported torch first."""
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+        for name in ("libamdhip64.so",):
+            path = os.path.join(libdir, name)
+            if os.path.exists(path):
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass   # fall back to the system runtime
+
+
 def load() -> C.CDLL:
     """Load libtsearch.so (once).  Raises if it has not been built."""
     global _lib
     with _lock:
         if _lib is None:
+            _preload_torch_hip_runtime()
             if not os.path.exists(_LIB_PATH):
                 raise TSearchError(-4, f"{_LIB_PATH} not found: build it first (make -C theoremsearch_amd/csrc); "
                                        "there is no CPU fallback")

@@ -59,6 +59,72 @@ __global__ void __launch_bounds__(256) prep_rows_kernel(const void* __restrict__
     }
 }
 
+// Encoder epilogue: pooling over the sequence + L2 normalisation + cast, one workgroup per sequence.
+// Columns are spread over the threads (coalesced reads of every token row); the squared norm is reduced
+// in fp64 through LDS like the index rows.
+template <int HDT, int ODT>
+__global__ void __launch_bounds__(256) pool_normalize_kernel(const void* __restrict__ hidden, const int64_t* __restrict__ mask,
+                                                              int seq, int d, int pooling, int normalize, void* __restrict__ out,
+                                                              int64_t out_ld) {
+    __shared__ double red[4];
+    __shared__ int s_count, s_last;
+    const int64_t row = blockIdx.x;
+    const int64_t* m = mask + row * seq;
+    if (threadIdx.x == 0) {
+        int cnt = 0, last = 0;
+        for (int t = 0; t < seq; ++t)
+            if (m[t] != 0) {
+                ++cnt;
+                last = t;
+            }
+        s_count = cnt;
+        s_last = last;
+    }
+    __syncthreads();
+    const int count = s_count, last = s_last;
+    constexpr int kMaxPerThread = 16;  // d <= 4096
+    float val[kMaxPerThread];
+    double ss = 0.0;
+#pragma unroll
+    for (int j = 0; j < kMaxPerThread; ++j) {
+        const int c = threadIdx.x + j * 256;
+        float v = 0.0f;
+        if (c < d) {
+            auto load = [&](int t) -> float {
+                const int64_t off = (row * seq + t) * (int64_t)d + c;
+                return (HDT == 0) ? ((const float*)hidden)[off] : bf16_to_f32(((const unsigned short*)hidden)[off]);
+            };
+            if (pooling == 0) {
+                float acc = 0.0f;
+                for (int t = 0; t < seq; ++t)
+                    if (m[t] != 0) acc += load(t);
+                v = acc / fmaxf((float)count, 1e-9f);
+            } else {
+                v = load(pooling == 1 ? last : 0);
+            }
+            ss += (double)v * (double)v;
+        }
+        val[j] = v;
+    }
+    float denom = 1.0f;
+    if (normalize) {
+        ss = wave_sum_f64(ss);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+        __syncthreads();
+        const double total = red[0] + red[1] + red[2] + red[3];
+        denom = fmaxf((float)sqrt(total), 1e-12f);
+    }
+#pragma unroll
+    for (int j = 0; j < kMaxPerThread; ++j) {
+        const int c = threadIdx.x + j * 256;
+        if (c < d) {
+            const float v = normalize ? (float)((double)val[j] / (double)denom) : val[j];
+            if (ODT == 0) ((float*)out)[row * out_ld + c] = v;
+            else ((unsigned short*)out)[row * out_ld + c] = f32_to_bf16(v);
+        }
+    }
+}
+
 // Dense device rows -> dense host-layout rows of the storage dtype (for ts_index_download).
 template <int DT>
 __global__ void __launch_bounds__(256) unpad_rows_kernel(const void* __restrict__ src, int64_t ld, void* __restrict__ dst, int d,

@@ -848,6 +848,31 @@ extern "C" int ts_merge_topk(int device, const float* scores, const int64_t* idx
     return TS_OK;
 }
 
+extern "C" int ts_pool_normalize(int device, const void* hidden, int h_dtype, const int64_t* attention_mask, int64_t n,
+                                 int32_t seq, int32_t d, int pooling, int normalize, void* out, int out_dtype, int64_t out_ld,
+                                 void* stream) {
+    if (!hidden || !attention_mask || !out) return fail(TS_ERR_INVALID, "NULL argument");
+    if ((h_dtype != TS_F32 && h_dtype != TS_BF16) || (out_dtype != TS_F32 && out_dtype != TS_BF16))
+        return fail(TS_ERR_INVALID, "dtype");
+    if (n < 0 || seq < 1 || d < 1 || d > 4096 || out_ld < d) return fail(TS_ERR_INVALID, "bad shape (d must be <= 4096)");
+    if (pooling < TS_POOL_MEAN || pooling > TS_POOL_CLS) return fail(TS_ERR_INVALID, "pooling %d", pooling);
+    if (n == 0) return TS_OK;
+    TS_TRY(check_device(device));
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)n);
+    if (h_dtype == TS_F32 && out_dtype == TS_F32)
+        pool_normalize_kernel<0, 0><<<grid, 256, 0, st>>>(hidden, attention_mask, seq, d, pooling, normalize, out, out_ld);
+    else if (h_dtype == TS_F32)
+        pool_normalize_kernel<0, 1><<<grid, 256, 0, st>>>(hidden, attention_mask, seq, d, pooling, normalize, out, out_ld);
+    else if (out_dtype == TS_F32)
+        pool_normalize_kernel<1, 0><<<grid, 256, 0, st>>>(hidden, attention_mask, seq, d, pooling, normalize, out, out_ld);
+    else
+        pool_normalize_kernel<1, 1><<<grid, 256, 0, st>>>(hidden, attention_mask, seq, d, pooling, normalize, out, out_ld);
+    HIP_TRY(hipGetLastError());
+    return TS_OK;
+}
+
 extern "C" int ts_index_profile_enable(ts_index* ix, int enable) {
     if (!ix) return fail(TS_ERR_INVALID, "index is NULL");
     std::lock_guard<std::mutex> lock(ix->mu);

@@ -123,17 +123,36 @@ class SentenceEncoder:
         for start in range(0, len(texts), batch_size):
             sel = order[start:start + batch_size]
             enc = {k: v.to(self.device) for k, v in self._tokenize([texts[i] for i in sel]).items()}
-            hidden = self.model(**enc).last_hidden_state.float()
-            mask = enc["attention_mask"].unsqueeze(-1).float()
-            if self.pooling == "last":
-                last = enc["attention_mask"].sum(dim=1) - 1
-                emb = hidden[torch.arange(hidden.shape[0], device=self.device), last]
-            else:
-                emb = (hidden * mask).sum(dim=1) / mask.sum(dim=1).clamp(min=1e-9)
-            if normalize_embeddings:
-                emb = torch.nn.functional.normalize(emb, p=2, dim=1)
-            out[torch.as_tensor(sel, device=self.device)] = emb
+            hidden = self.model(**enc).last_hidden_state
+            out[torch.as_tensor(sel, device=self.device)] = self.pool(hidden, enc["attention_mask"], normalize_embeddings)
         return out
+
+    def pool(self, hidden: torch.Tensor, attention_mask: torch.Tensor, normalize: bool) -> torch.Tensor:
+        """Pooling + optional L2 normalisation of a last hidden state -> fp32 ``[n x d]``.  On a GPU this is ONE
+        fused HIP kernel (``ts_pool_normalize``) instead of five torch ops; on CPU the torch expression of
+        sentence-transformers' Pooling + Normalize modules."""
+        if hidden.is_cuda and hidden.dtype in (torch.float32, torch.bfloat16):
+            import ctypes as C
+            from . import _ffi
+            hidden = hidden.contiguous()
+            mask = attention_mask.to(torch.int64).contiguous()
+            n, seq, d = hidden.shape
+            emb = torch.empty((n, d), dtype=torch.float32, device=hidden.device)
+            _ffi.check(_ffi.load().ts_pool_normalize(
+                hidden.device.index or 0, C.c_void_p(hidden.data_ptr()), 1 if hidden.dtype == torch.bfloat16 else 0,
+                C.c_void_p(mask.data_ptr()), n, seq, d, 1 if self.pooling == "last" else 0, 1 if normalize else 0,
+                C.c_void_p(emb.data_ptr()), 0, d, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            return emb
+        hidden = hidden.float()
+        mask = attention_mask.unsqueeze(-1).float()
+        if self.pooling == "last":
+            last = attention_mask.sum(dim=1) - 1
+            emb = hidden[torch.arange(hidden.shape[0], device=hidden.device), last]
+        else:
+            emb = (hidden * mask).sum(dim=1) / mask.sum(dim=1).clamp(min=1e-9)
+        if normalize:
+            emb = torch.nn.functional.normalize(emb, p=2, dim=1)
+        return emb
 
     def encode(self, sentences: Union[str, Iterable[str]], batch_size: int = 32, show_progress_bar: Optional[bool] = None,
                convert_to_numpy: bool = True, convert_to_tensor: bool = False, normalize_embeddings: bool = False,
