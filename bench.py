@@ -66,6 +66,11 @@ def main():
     args = ap.parse_args()
     global D
     D = args.dim
+    # Exactly ONE line goes to stdout (the JSON): libraries print banners there (RCCL prints its version / host /
+    # library path on communicator creation), so fd 1 points at stderr until the result line is written.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -312,7 +317,8 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if world > 1 or args.force_dist:
         dist.destroy_process_group()
 
