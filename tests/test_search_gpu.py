@@ -177,6 +177,28 @@ def test_mfma_d1024_and_query_blocks(ts):
             check(q[:nq], c, "cos", "bf16", 7, s, i)
 
 
+@pytest.mark.parametrize("kind", ["outliers", "light_tail", "shifted"])
+def test_estimated_threshold_is_verified_not_trusted(ts, kind):
+    # The full pass's threshold is extrapolated from one sample (Gaussian tail).  Distributions that break the
+    # estimate must still give the exact answer: too many candidates or too few both end in the exact re-run.
+    rng = np.random.default_rng(44)
+    n, d = 120_000, 768
+    c = rng.standard_normal((n, d), dtype=np.float32) * np.float32(1 / np.sqrt(d))
+    q = rng.standard_normal((24, d), dtype=np.float32) * np.float32(1 / np.sqrt(d))
+    if kind == "outliers":            # 1 % of the rows 20x longer: sample variance inflated, heavy tail
+        c[rng.choice(n, n // 100, replace=False)] *= np.float32(20.0)
+    elif kind == "light_tail":        # scores bounded: rows are signed unit vectors of 4 coordinates
+        c = np.zeros((n, d), np.float32)
+        cols = rng.integers(0, d, size=(n, 4))
+        c[np.arange(n)[:, None], cols] = rng.choice([-0.5, 0.5], size=(n, 4)).astype(np.float32)
+    else:                             # every score shifted far from zero by a common component
+        c += q.mean(axis=0) * np.float32(30.0)
+    with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as ix:
+        scores, idx, st = ix.search(q, 10, algo="mfma", return_stats=True)
+        assert st["algo"] == 2
+        check(q, c, "ip", "bf16", 10, scores, idx)
+
+
 def test_candidate_overflow_falls_back_exactly(ts):
     # 20,000 copies of one row that matches query 0: far more ties above any threshold than the
     # candidate buffer holds -> that query must be re-run by the exact scan

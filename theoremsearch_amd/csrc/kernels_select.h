@@ -14,6 +14,12 @@ namespace ts {
 
 #define TS_MAX_K_INTERNAL 256
 
+__device__ __forceinline__ double wave_sum_f64_sel(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
 struct SelectArgs {
     const u64* in;       // [slot][in_stride] keys (any order; 0 = empty)
     int64_t in_stride;
@@ -73,6 +79,8 @@ struct LevelArgs {
     int kk;              // threshold rank, >= k_user
     float* thr;          // [256]
     int final_level;
+    float z_tail;        // sample level: > 0 = also apply the Gaussian-tail estimate mean + z * std of the sample
+    int min_fill;        // final level: fewer candidates than this = the estimate was too high: exact re-run
     float* out_scores;
     int64_t* out_idx;
     int k_user;
@@ -160,15 +168,45 @@ __global__ void __launch_bounds__(kLevelThreads) level_select_kernel(LevelArgs a
 
     if (threadIdx.x == 0) a.count[q] = 0;
     if (!a.final_level) {
-        // any subset of the candidates still gives a valid (lower) bound, so `lost` is harmless here
-        if (threadIdx.x == 0) {
-            const u64 key = best[kk - 1];
-            a.thr[q] = key ? key_score(key) : -INFINITY;
+        // the kk-th best of a sample is a lower bound of the final kk-th best: a guaranteed threshold (any subset
+        // of the candidates still gives a valid bound, so `lost` is harmless here)
+        const u64 kth = best[kk - 1];
+        float thr = kth ? key_score(kth) : -INFINITY;
+        if (a.z_tail > 0.0f && cnt >= 256) {
+            // ... and usually far too low for the next level when that level is much bigger.  The scores of one
+            // query over the corpus are close to Gaussian (normalised, high-dimensional rows), so the sample's
+            // mean + z * std estimates the score that only the wanted number of rows exceed.  NOT a bound: the
+            // final level checks that at least min_fill candidates came back and re-runs the query exactly if not.
+            double s1 = 0.0, s2 = 0.0;
+            for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+                const double v = (double)key_score(keys[i]);
+                s1 += v;
+                s2 += v * v;
+            }
+            s1 = wave_sum_f64_sel(s1);
+            s2 = wave_sum_f64_sel(s2);
+            double* red = (double*)best;  // the sorted list has been read (kth) by every thread that needs it
+            __syncthreads();
+            if (lane == 0) {
+                red[2 * wave] = s1;
+                red[2 * wave + 1] = s2;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double t1 = 0.0, t2 = 0.0;
+                for (int w = 0; w < nw; ++w) {
+                    t1 += red[2 * w];
+                    t2 += red[2 * w + 1];
+                }
+                const double mean = t1 / cnt, var = fmax(t2 / cnt - mean * mean, 0.0);
+                thr = fmaxf(thr, (float)(mean + (double)a.z_tail * sqrt(var)));
+            }
         }
+        if (threadIdx.x == 0) a.thr[q] = thr;
         return;
     }
     if (threadIdx.x == 0) atomicAdd(a.stat_candidates, (unsigned long long)produced);
-    if (lost) {
+    if (lost || (int)total < a.min_fill) {
         if (threadIdx.x == 0) a.fb_list[atomicAdd(a.fb_count, 1)] = q;
         return;
     }

@@ -518,14 +518,39 @@ struct Level { int64_t stride, ntiles; int run; };
 // kk * rows(i+1) / rows(i): the full pass is planned for `target` candidates (few trips through
 // the append path), the sparser levels for up to kCandCap / 4 (they are short anyway); the first
 // level is small enough to run unthresholded.
-static std::vector<Level> plan_levels(int64_t n, int kk) {
-    const int64_t T = (n + kTileRows - 1) / kTileRows;
+// Inverse of the standard normal CDF (Acklam's rational approximation, |error| < 1.2e-9): the z with P(X > z) = p.
+static double normal_tail_z(double p) {
+    if (p <= 0.0) return 8.0;
+    if (p >= 0.5) return 0.0;
+    const double q = std::sqrt(-2.0 * std::log(p));
+    static const double c[] = {-7.784894002430293e-03, -3.223964580411365e-01, -2.400758277161838e+00,
+                               -2.549732539343734e+00, 4.374664141464968e+00, 2.938163982698783e+00};
+    static const double d[] = {7.784695709041462e-03, 3.224671290700398e-01, 2.445134137142996e+00, 3.754408661907416e+00};
+    if (p < 0.02425)
+        return -(((((c[0] * q + c[1]) * q + c[2]) * q + c[3]) * q + c[4]) * q + c[5]) /
+               ((((d[0] * q + d[1]) * q + d[2]) * q + d[3]) * q + 1.0);
+    // central region
+    static const double a[] = {-3.969683028665376e+01, 2.209460984245205e+02, -2.759285104469687e+02,
+                               1.383577518672690e+02, -3.066479806614716e+01, 2.506628277459239e+00};
+    static const double b[] = {-5.447609879822406e+01, 1.615858368580409e+02, -1.556989798598866e+02,
+                               6.680131188771972e+01, -1.328068155288572e+01};
+    const double x = (1.0 - p) - 0.5, r = x * x;
+    return (((((a[0] * r + a[1]) * r + a[2]) * r + a[3]) * r + a[4]) * r + a[5]) * x /
+           (((((b[0] * r + b[1]) * r + b[2]) * r + b[3]) * r + b[4]) * r + 1.0);
+}
+
+static int mfma_target_cands(int64_t n, int kk) {
     // Cost model fitted on 10M / 1.25M x 768, batch 256: a sample row costs ~0.4 ns, a candidate of the next
     // level ~0.27 us per query (the append path is ~1 us of wave time).  Minimising kk * N * c_row / F + c_cand * F
     // gives F ~ 512 * sqrt(N / 1e7) candidates per query for the full pass.
     int target = (int)(512.0 * std::sqrt(std::max<double>((double)n, 1.0) / 1e7));
     target = std::max(target, 8 * kk);  // large k: keep the level ratio >= 8, or the sparse levels cost as much as the pass
-    target = std::min(2048, std::max(64, env_int("TS_MFMA_TARGET_CANDS", target)));
+    return std::min(2048, std::max(64, env_int("TS_MFMA_TARGET_CANDS", target)));
+}
+
+static std::vector<Level> plan_levels(int64_t n, int kk, bool statistical) {
+    const int64_t T = (n + kTileRows - 1) / kTileRows;
+    const int target = mfma_target_cands(n, kk);
     auto pow2_ratio = [&](int cands) { int64_t r = 2; while (r * 2 * kk <= cands) r *= 2; return r; };
     const int64_t r_last = pow2_ratio(target);
     // The sparsest level runs unthresholded: every score becomes a candidate, so it may hold at most
@@ -541,7 +566,12 @@ static std::vector<Level> plan_levels(int64_t n, int kk) {
         const int run = (stride > 1 && nt >= 8 * 256) ? env_int("TS_MFMA_RUN", 1) : 1;
         lv.push_back({stride, nt, run});
         if (nt * kTileRows <= first_rows) break;  // every score of this level fits: it can run unthresholded
-        if (lv.size() == 1) {
+        if (statistical) {
+            // one unthresholded sample of up to first_rows rows; its select extrapolates the threshold of the full pass
+            int64_t need = 2;
+            while (((T + need - 1) / need) * kTileRows > first_rows) need *= 2;
+            stride = need;
+        } else if (lv.size() == 1) {
             stride *= r_last;
         } else {
             // smallest ratio that reaches the unthresholded size in one step, if the cap allows it
@@ -604,7 +634,17 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         ix->priv_writers = nwriters;
     }
     init_thr_kernel<<<1, 256, 0, st>>>(ix->thr, nq, ix->fb_count, ix->stat);
-    const std::vector<Level> lv = plan_levels(ix->n, kk);
+    // Threshold of the full pass: by default extrapolated from ONE unthresholded sample (Gaussian tail of the
+    // sample's scores, verified afterwards by the candidate count); TS_MFMA_STAT=0 selects the chain of
+    // guaranteed lower bounds (more sample rows to scan, no re-runs ever).
+    const bool statistical = env_int("TS_MFMA_STAT", 1) != 0;
+    const std::vector<Level> lv = plan_levels(ix->n, kk, statistical);
+    // expected candidates per query of the full pass under the estimate: 25x the k that must come back (an
+    // under-filled query costs an exact scan pass), few enough that the append path stays cheap
+    const int stat_cands = std::min(2048, std::max(env_int("TS_MFMA_STAT_CANDS", 256), 16 * kk));
+    const float z_tail = (statistical && lv.size() == 2)
+                             ? (float)normal_tail_z(std::min(0.25, (double)stat_cands / (double)std::max<int64_t>(ix->n, 1)))
+                             : 0.0f;
     static unsigned long long* g_dbg = nullptr;  // diagnostics (TS_MFMA_VARIANT=3): per-wave cycle sums
     for (size_t i = 0; i < lv.size(); ++i) {
         const bool full_pass = (i + 1 == lv.size());
@@ -654,6 +694,8 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         l.kk = kk;
         l.thr = ix->thr;
         l.final_level = full_pass;
+        l.z_tail = full_pass ? 0.0f : z_tail;
+        l.min_fill = (z_tail > 0.0f) ? (int)std::min<int64_t>(k, ix->n) : 0;
         l.out_scores = out_scores;
         l.out_idx = out_idx;
         l.k_user = k;
