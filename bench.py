@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--dim", type=int, default=768, help="embedding dimension (diagnostic; BASELINE configs use 768)")
     ap.add_argument("--seq-len", type=int, default=32, help="c5: tokens per synthetic query")
     ap.add_argument("--force-dist", action="store_true", help="debug: run the exchange + merge path even with one rank")
+    ap.add_argument("--mask-frac", type=float, default=0.0,
+                    help="diagnostic: filtered search with this fraction of rows allowed (device bitmask)")
     ap.add_argument("--zero-queries", action="store_true", help="diagnostic: all-zero queries (power probe)")
     ap.add_argument("--zero-corpus", action="store_true", help="diagnostic: all-zero corpus (power probe)")
     args = ap.parse_args()
@@ -160,6 +162,14 @@ def main():
         tok_ids[:, 0], tok_ids[:, -1] = 101, 102
         tok_mask = torch.ones_like(tok_ids)
     step_no = [0]
+    mask_ptr, mask_host = 0, None
+    if args.mask_frac > 0:
+        mask_host = np.random.default_rng(99 + rank).random(n_local) < args.mask_frac
+        bits = np.packbits(mask_host, bitorder="little")
+        words = np.zeros((n_local + 31) // 32 * 4, dtype=np.uint8)
+        words[: bits.shape[0]] = bits
+        mask_dev = torch.from_numpy(words).cuda()
+        mask_ptr = mask_dev.data_ptr()
 
     def encode_queries():
         with torch.inference_mode():
@@ -178,7 +188,8 @@ def main():
             emb = encode_queries()
             ix.search_device(emb.data_ptr(), "f32", nq, K, base, base + idx_off, main.cuda_stream, algo=args.algo)
         else:
-            ix.search_device(q_dev.data_ptr(), dtype, nq, K, base, base + idx_off, main.cuda_stream, algo=args.algo)
+            ix.search_device(q_dev.data_ptr(), dtype, nq, K, base, base + idx_off, main.cuda_stream, algo=args.algo,
+                             mask_ptr=mask_ptr)
         if use_dist:
             ev_search[b].record(main)
             with torch.cuda.stream(side):
@@ -222,10 +233,10 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes per launch from rocprofv3 --pmc (offline pass)
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(f"{args.workload}_n{world}")
+            traffic = json.load(open(tpath)).get(f"{args.workload}_n{world}") if (not args.nq and not args.rows) else None
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "mfma_topk_kernel" if bf16 else "scan_kernel",
+    roofline = {"bound": "hbm", "kernel": "mfma_topk_kernel" if (bf16 and nq > 4 and args.algo != "scan" and not mask_ptr) else "scan_kernel",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel_ms": round(kern_ms, 4), "launches_per_step": launches_per_step,
@@ -254,6 +265,8 @@ def main():
             blk = data[a - c * CH:b - c * CH]
             blk = oracle.bf16_bits_to_f32(blk) if bf16 else blk
             s = qf.astype(np.float64) @ blk.astype(np.float64).T
+            if mask_host is not None:
+                s[:, ~mask_host[a - lo:b - lo]] = -np.inf
             top = -np.sort(-s, axis=1)[:, :K] if s.shape[1] > K else s
             # fp64 scores of the rows the GPU returned that live in this chunk
             got = {}
@@ -312,6 +325,7 @@ def main():
             "config": {"workload": f"{rows_total}x{D} {dtype} corpus, batch-{nq} queries, top-{K} "
                                    f"(BASELINE.json configs[{ {'c2': 1, 'c3': 2, 'c4': 3, 'c5': 4}[args.workload] }])" + (f", encoder forward in the loop ({args.seq_len} tokens/query, random-init BERT-base shape)" if encoder is not None else ""),
                        "rows": rows_total, "dim": D, "batch": nq, "k": K,
+                       **({"mask_frac": args.mask_frac} if args.mask_frac > 0 else {}),
                        "parallelism": f"corpus row-sharded x{world}" + (", RCCL all-gather of per-shard top-k" if use_dist else "")},
             "recall_at_10": recall,
             "roofline": roofline,

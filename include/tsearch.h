@@ -117,6 +117,16 @@ int ts_search_ex(ts_index *ix, const void *queries, int q_dtype, int q_on_device
                  float *out_scores, int64_t *out_idx, int out_on_device, void *stream, int algo,
                  ts_search_stats *stats);
 
+/* Search restricted to the rows whose bit is set in row_mask (uint32 words, bit r & 31 of word r >> 5 = row r,
+ * ceil(n / 32) words, host or device memory): the k best ALLOWED rows, exactly.  Stands in for the metadata
+ * filters of the apps - the WHERE clause in front of ORDER BY ... LIMIT k (streamlit_app.py:175-243,253-283) and
+ * the post-filter loop over the top-200 (app_showcase_model.py:96-129), which can return fewer than top_k hits
+ * although more exist.  The caller evaluates the predicates to the bitmask; the scan kernel tests the bit before
+ * a row can enter a top-k list (N / 8 extra bytes per pass). */
+int ts_search_filtered(ts_index *ix, const void *queries, int q_dtype, int q_on_device, int32_t nq, int32_t k,
+                       const uint32_t *row_mask, int mask_on_device, float *out_scores, int64_t *out_idx,
+                       int out_on_device, void *stream);
+
 /* Full [nq x n] fp32 score matrix (small N only): util.cos_sim(q_emb, s_emb) of
  * compare_embeddings.py:24,61.  out row stride is n. */
 int ts_scores(ts_index *ix, const void *queries, int q_dtype, int q_on_device, int32_t nq,

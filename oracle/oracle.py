@@ -538,3 +538,33 @@ def pgvector_c_search(query_vec: np.ndarray, embeddings: np.ndarray, top_k: int)
     if rc != 0:
         raise RuntimeError(f"pgv_order_by_ip_limit failed: {rc}")
     return rows, 1.0 - dist.astype(np.float64)
+
+
+def showcase_filter_search(cos_scores, theorems_data, filters, pool=200):
+    """The reference's filtered search, restated (app_showcase_model.py:93-129): rank all rows, keep the best
+    min(pool, N), walk them in order and keep those passing every sidebar predicate until top_k are found.
+    Returns (rows, exhausted) - `exhausted` is True when the pool ran out before top_k matches."""
+    cos_scores = np.asarray(cos_scores)
+    n = len(theorems_data)
+    order = topk_canonical(cos_scores[None, :].astype(np.float64), min(pool, n))[1][0]
+    want = filters["top_k"]
+    rows = []
+    for i in order:
+        it = theorems_data[int(i)]
+        ok = (not filters["types"] or it["type"].lower() in filters["types"])
+        ok = ok and (not filters["tags"] or it["primary_math_tag"] in filters["tags"])
+        ok = ok and (not filters["authors"] or any(a in it["authors"] for a in filters["authors"]))
+        ok = ok and it["source"] in filters["sources"]
+        ok = ok and filters["citation_range"][0] <= it["citations"] <= filters["citation_range"][1]
+        if it["source"] == "arXiv":
+            if filters["year_range"]:
+                ok = ok and filters["year_range"][0] <= it.get("year", 0) <= filters["year_range"][1]
+            if filters["journal_status"] == "Journal Article":
+                ok = ok and bool(it.get("journal_published", False))
+            elif filters["journal_status"] == "Preprint Only":
+                ok = ok and not it.get("journal_published", False)
+        if ok:
+            rows.append(int(i))
+        if len(rows) >= want:
+            break
+    return rows, len(rows) < want

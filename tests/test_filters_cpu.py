@@ -1,0 +1,38 @@
+"""filter_mask (the bitmask the scan kernel consumes) against the restated reference loop
+(oracle.showcase_filter_search, app_showcase_model.py:93-129) - host logic only."""
+import numpy as np
+import pytest
+
+from filters_common import filter_states, make_theorems
+from oracle import oracle
+from theoremsearch_amd.filters import filter_mask
+
+
+@pytest.mark.parametrize("state", list(filter_states()))
+def test_mask_agrees_with_reference_loop(state):
+    n = 3000
+    data = make_theorems(n)
+    f = filter_states(top_k=10)[state]
+    mask = filter_mask(data, f)
+    assert mask.dtype == bool and mask.shape == (n,)
+    rng = np.random.default_rng(3)
+    cos = rng.standard_normal(n).astype(np.float32)
+    # with the pool widened to N the reference loop IS "best top_k rows that pass"
+    rows, exhausted = oracle.showcase_filter_search(cos, data, f, pool=n)
+    allowed = np.flatnonzero(mask)
+    best = allowed[np.argsort(-cos[allowed].astype(np.float64), kind="stable")][: f["top_k"]]
+    assert rows == [int(i) for i in best]
+    assert exhausted == (mask.sum() < f["top_k"])
+    # and every row the 200-pool loop returns passes the mask
+    rows200, _ = oracle.showcase_filter_search(cos, data, f)
+    assert all(mask[i] for i in rows200)
+    assert rows200 == rows[: len(rows200)]
+
+
+def test_states_cover_empty_full_and_selective():
+    data = make_theorems(3000)
+    s = filter_states()
+    assert filter_mask(data, s["open"]).all()
+    assert not filter_mask(data, s["nothing"]).any()
+    sel = filter_mask(data, s["selective"]).mean()
+    assert 0 < sel < 0.01

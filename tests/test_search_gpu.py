@@ -266,6 +266,63 @@ def test_sharded_search_equals_whole(ts):
         assert np.array_equal(mi, wi) and np.array_equal(ms, ws), algo
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_filtered_search_equals_search_of_the_allowed_rows(ts, dtype):
+    """ts_search_filtered: the k best rows whose mask bit is set = an unfiltered oracle search over exactly
+    those rows (ids mapped back); masks from dense to empty, n not a multiple of 32."""
+    n, d, nq, k = 20011, 768, 6, 10
+    q, c = oracle.golden_inputs(n, nq, d, 77, "cos")
+    rng = np.random.default_rng(8)
+    with ts.TheoremIndex.from_embeddings(c, dtype=dtype, metric="cos") as ix:
+        for frac in (1.0, 0.5, 0.03, 0.0004, 0.0):
+            mask = rng.random(n) < frac
+            if frac == 0.0004:
+                mask[-1] = True  # last row, last partial mask word
+            allowed = np.flatnonzero(mask)
+            scores, idx = ix.search(q, k, mask=mask)
+            m = min(k, allowed.size)
+            assert (idx[:, m:] == -1).all() and np.isneginf(scores[:, m:]).all()
+            if m == 0:
+                continue
+            assert mask[idx[:, :m]].all()
+            qp, cp = oracle.prepared_inputs(q, c[allowed], "cos", dtype)
+            truth = oracle.scores_fp64(qp, cp)
+            local = np.searchsorted(allowed, idx[:, :m])
+            pad = np.full((nq, k - m), -1, dtype=np.int64)
+            stats = oracle.check_topk_against_truth(truth, np.concatenate([local, pad], 1), scores, k, gap=GAP,
+                                                    score_tol=SCORE_TOL)
+            assert stats["recall"] == 1.0
+        # unfiltered search afterwards is unaffected by the previous mask
+        s0, i0 = ix.search(q, k, algo="scan")
+        check(q, c, "cos", dtype, k, s0, i0)
+
+
+def test_showcase_filters_return_topk_where_the_reference_pool_runs_dry(ts):
+    """filters.search_filtered against the restated app loop (app_showcase_model.py:93-129): same rows whenever the
+    top-200 pool held top_k matches; when it ran dry, ours continues with the next best matching rows."""
+    from filters_common import filter_states, make_theorems
+    from theoremsearch_amd import filters as flt
+    n, d = 6000, 768
+    q, c = oracle.golden_inputs(n, 1, d, 31, "cos")
+    data = make_theorems(n)
+    qp, cp = oracle.prepared_inputs(q, c, "cos", "f32")
+    cos = oracle.scores_fp64(qp, cp)[0]
+    saw_dry = False
+    with ts.TheoremIndex.from_embeddings(c, dtype="f32", metric="cos") as ix:
+        for name, f in filter_states(top_k=10).items():
+            got = flt.search_filtered(ix, q, data, f)
+            ref_rows, dry = oracle.showcase_filter_search(cos, data, f)
+            full_rows, _ = oracle.showcase_filter_search(cos, data, f, pool=n)
+            got_ids = [next(i for i in full_rows if data[i] is g["info"]) for g in got]
+            assert got_ids == full_rows, name
+            assert got_ids[: len(ref_rows)] == ref_rows, name
+            if dry and len(full_rows) > len(ref_rows):
+                saw_dry = True
+            for g, i in zip(got, got_ids):
+                assert abs(g["similarity"] - cos[i]) <= SCORE_TOL
+    assert saw_dry
+
+
 def test_empty_and_invalid_arguments(ts):
     from theoremsearch_amd import _ffi
     c = np.random.default_rng(1).standard_normal((10, 16), dtype=np.float32)

@@ -26,6 +26,7 @@ struct ScanArgs {
     int k;                // entries kept per wave / written per workgroup
     u64* partial;         // [slot][gridDim.x][k] keys, descending
     float* scores;        // EMIT: [nq x n]
+    const u32* row_mask;  // optional filter: bit (row & 31) of word row >> 5 set = the row may be returned
 };
 
 template <int DT> struct Elem;
@@ -144,6 +145,8 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanArgs a) {
             const int myrow = rho<G>(lane);
             const int64_t row = row0 + myrow;
             const bool rep = (lane & (G / 4 - 1)) == 0;
+            // metadata filter: one bit per row, N / 8 bytes per pass
+            const bool allowed = !a.row_mask || (rep && row < a.n && ((a.row_mask[row >> 5] >> (row & 31)) & 1u));
 #pragma unroll
             for (int q = 0; q < QB; ++q) {
                 float acc[kScanRB];
@@ -158,7 +161,7 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanArgs a) {
                 if (EMIT) {
                     if (rep && row < a.n && g0 + q < count) a.scores[(int64_t)qid[q] * a.n + row] = s;
                 } else {
-                    const u64 key = (rep && row < a.n && s == s) ? make_key(s, (u32)row) : 0ull;
+                    const u64 key = (rep && row < a.n && s == s && allowed) ? make_key(s, (u32)row) : 0ull;
                     u64 m = __ballot(key > tk[q].thr);
                     while (m) {
                         const int src = __ffsll((long long)m) - 1;
@@ -221,7 +224,8 @@ __global__ void __launch_bounds__(256) scan_generic_kernel(ScanArgs a) {
             if (EMIT) {
                 if (rep && row < a.n) a.scores[(int64_t)qid * a.n + row] = s;
             } else {
-                const u64 key = (rep && row < a.n && s == s) ? make_key(s, (u32)row) : 0ull;
+                const bool allowed = !a.row_mask || (rep && row < a.n && ((a.row_mask[row >> 5] >> (row & 31)) & 1u));
+                const u64 key = (rep && row < a.n && s == s && allowed) ? make_key(s, (u32)row) : 0ull;
                 u64 m = __ballot(key > tk.thr);
                 while (m) {
                     const int src = __ffsll((long long)m) - 1;

@@ -78,6 +78,8 @@ struct ts_index {
     int* fb_list = nullptr;     int* fb_count = nullptr;     unsigned long long* stat = nullptr;
     u64* partial = nullptr;     u64* partial2 = nullptr;     size_t partial_bytes = 0;
     float* res_scores = nullptr; int64_t* res_idx = nullptr; size_t res_cap = 0;  // device result buffers (entries)
+    u32* mask_dev = nullptr;    size_t mask_bytes = 0;       // filtered search: device copy of a host bitmask
+    const u32* active_mask = nullptr;                        // bitmask of the search in progress (under `mu`)
     bool attr_done = false;
     // optional event brackets around the dominant kernel (ts_index_profile_*)
     bool profiling = false;
@@ -209,7 +211,7 @@ extern "C" int ts_index_destroy(ts_index* ix) {
     if (!ix) return TS_OK;
     hipSetDevice(ix->device);
     if (ix->stream) hipStreamSynchronize(ix->stream);
-    void* ptrs[] = {ix->rows,  ix->stage,   ix->qstore,   ix->qf32,     ix->cand,       ix->count,  ix->thr, ix->priv, ix->pcount,
+    void* ptrs[] = {ix->rows,  ix->stage,   ix->qstore,   ix->qf32,     ix->cand,       ix->count,  ix->thr, ix->priv, ix->pcount, ix->mask_dev,
                     ix->fb_list, ix->fb_count, ix->stat, ix->partial, ix->partial2, ix->res_scores, ix->res_idx};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -501,6 +503,7 @@ static int scan_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
     a.nq = nq;
     a.k = k;
     a.partial = ix->partial;
+    a.row_mask = ix->active_mask;
     const int qb = (nq >= 2 || qcount) ? 4 : 1;
     hipEvent_t stop = qcount ? nullptr : prof_begin(ix, st, ix->n);  // the MFMA path's fall-back pass is not bracketed
     launch_scan<false>(ix, a, qb, st, grid);
@@ -716,7 +719,7 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
 
 static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_device, int32_t nq, int32_t k,
                        float* out_scores, int64_t* out_idx, int out_on_device, void* stream, int algo,
-                       ts_search_stats* stats) {
+                       ts_search_stats* stats, const uint32_t* row_mask = nullptr, int mask_on_device = 0) {
     if (stats) memset(stats, 0, sizeof(*stats));
     if (!ix || !queries || !out_scores || !out_idx) return fail(TS_ERR_INVALID, "NULL argument");
     if (q_dtype != TS_F32 && q_dtype != TS_BF16) return fail(TS_ERR_INVALID, "q_dtype %d", q_dtype);
@@ -731,6 +734,21 @@ static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
     TS_TRY(ensure_search_scratch(ix, k));
+    struct MaskScope {  // the bitmask is a property of this call only
+        ts_index* ix;
+        ~MaskScope() { ix->active_mask = nullptr; }
+    } mask_scope{ix};
+    if (row_mask) {
+        const size_t words = (size_t)((ix->n + 31) / 32);
+        if (mask_on_device) {
+            ix->active_mask = row_mask;
+        } else {
+            TS_TRY(ensure((void**)&ix->mask_dev, &ix->mask_bytes, std::max<size_t>(words * 4, 4)));
+            HIP_TRY(hipMemcpyAsync(ix->mask_dev, row_mask, words * 4, hipMemcpyHostToDevice, st));
+            ix->active_mask = ix->mask_dev;
+        }
+        algo = TS_ALGO_SCAN;  // the filter is applied by the scan kernel
+    }
     int use = algo;
     // The scan serves 4 queries per pass at the HBM rate; the MFMA path serves up to 256 per pass but its pass is
     // ~1.7x longer (matrix + HBM load drops the clock): a handful of queries is faster through the scan.
@@ -804,6 +822,14 @@ extern "C" int ts_search(ts_index* ix, const void* queries, int q_dtype, int q_o
                          float* out_scores, int64_t* out_idx, int out_on_device, void* stream) {
     return search_impl(ix, queries, q_dtype, q_on_device, nq, k, out_scores, out_idx, out_on_device, stream, TS_ALGO_AUTO,
                        nullptr);
+}
+
+extern "C" int ts_search_filtered(ts_index* ix, const void* queries, int q_dtype, int q_on_device, int32_t nq, int32_t k,
+                                  const uint32_t* row_mask, int mask_on_device, float* out_scores, int64_t* out_idx,
+                                  int out_on_device, void* stream) {
+    if (!row_mask) return fail(TS_ERR_INVALID, "row_mask is NULL");
+    return search_impl(ix, queries, q_dtype, q_on_device, nq, k, out_scores, out_idx, out_on_device, stream, TS_ALGO_SCAN,
+                       nullptr, row_mask, mask_on_device);
 }
 
 extern "C" int ts_scores(ts_index* ix, const void* queries, int q_dtype, int q_on_device, int32_t nq, float* out,

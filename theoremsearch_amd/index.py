@@ -102,15 +102,27 @@ class TheoremIndex:
         return self._h
 
     # -- search -----------------------------------------------------------------------------
-    def search(self, queries, k: int, algo: str = "auto", return_stats: bool = False):
+    def search(self, queries, k: int, algo: str = "auto", return_stats: bool = False, mask=None):
         """Exact top-k.  Returns ``(scores [nq x k] float32, indices [nq x k] int64)`` ordered by
-        score descending then index ascending; padding is ``(-inf, -1)``."""
+        score descending then index ascending; padding is ``(-inf, -1)``.  ``mask`` (bool per row)
+        restricts the search to the rows where it is true (metadata filters): the k best allowed rows."""
         q = _host_rows(queries)
         if q.shape[1] != self.d:
             raise ValueError(f"queries have d={q.shape[1]}, index has d={self.d}")
         nq, k = q.shape[0], int(k)
         scores = np.empty((nq, k), dtype=np.float32)
         idx = np.empty((nq, k), dtype=np.int64)
+        if mask is not None:
+            m = np.asarray(mask, dtype=bool).reshape(-1)
+            if m.shape[0] != self.n:
+                raise ValueError(f"mask has {m.shape[0]} entries, index has {self.n} rows")
+            bits = np.packbits(m, bitorder="little")
+            words = np.zeros((self.n + 31) // 32 * 4, dtype=np.uint8)
+            words[: bits.shape[0]] = bits
+            words = words.view(np.uint32)
+            _ffi.check(self._lib.ts_search_filtered(self._h, _ffi.as_ptr(q), _ffi.np_dtype_code(q), 0, nq, k,
+                                                    _ffi.as_ptr(words), 0, _ffi.as_ptr(scores), _ffi.as_ptr(idx), 0, None))
+            return scores, idx
         stats = _ffi.SearchStats()
         _ffi.check(self._lib.ts_search_ex(self._h, _ffi.as_ptr(q), _ffi.np_dtype_code(q), 0, nq, k,
                                           _ffi.as_ptr(scores), _ffi.as_ptr(idx), 0, None, _ALGOS[algo],
@@ -121,9 +133,15 @@ class TheoremIndex:
         return scores, idx
 
     def search_device(self, q_ptr: int, q_dtype: str, nq: int, k: int, out_scores_ptr: int, out_idx_ptr: int,
-                      stream: int = 0, algo: str = "auto") -> None:
+                      stream: int = 0, algo: str = "auto", mask_ptr: int = 0) -> None:
         """Asynchronous search on device buffers (queries [nq x d] dense; outputs [nq x k] f32 / i64),
-        enqueued on ``stream`` (0 = the index's own stream)."""
+        enqueued on ``stream`` (0 = the index's own stream).  ``mask_ptr``: device uint32 bitmask
+        (ceil(n / 32) words) restricting the rows, see `search`."""
+        if mask_ptr:
+            _ffi.check(self._lib.ts_search_filtered(self._h, C.c_void_p(q_ptr), _DTYPES[q_dtype], 1, int(nq), int(k),
+                                                    C.c_void_p(mask_ptr), 1, C.c_void_p(out_scores_ptr),
+                                                    C.c_void_p(out_idx_ptr), 1, C.c_void_p(stream)))
+            return
         _ffi.check(self._lib.ts_search_ex(self._h, C.c_void_p(q_ptr), _DTYPES[q_dtype], 1, int(nq), int(k),
                                           C.c_void_p(out_scores_ptr), C.c_void_p(out_idx_ptr), 1,
                                           C.c_void_p(stream), _ALGOS[algo], None))
