@@ -13,7 +13,7 @@ are exchanged with one RCCL all-gather, and every rank merges them.
 Other workloads: --workload c2 (1M x 768 fp32, batch 1), --workload c4 (50M x 768 bf16, batch 256).
 
 Synthetic data: corpus chunk c (250,000 rows) = default_rng([1234, c]).standard_normal, rows
-L2-normalised in fp32, rounded to bf16 for the bf16 workloads (oracle.synth_chunk); queries from
+L2-normalised in fp32, rounded to bf16 for the bf16 workloads (synthetic.synth_chunk); queries from
 default_rng([5678, 0]) the same way.  Rows are stored as given (metric = inner product on
 normalised rows = cosine).
 """
@@ -84,7 +84,8 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from oracle import oracle  # synthetic-data recipe + checker + cpu_baseline only
+    import synthetic                # input generator (plain numpy)
+    from oracle import oracle       # checker legs only: recall@10 and cpu_baseline
     import theoremsearch_amd as ts
     from theoremsearch_amd import _ffi
 
@@ -108,7 +109,7 @@ def main():
     lo = rows_total * rank // world
     hi = rows_total * (rank + 1) // world
     n_local = hi - lo
-    CH = oracle.CHUNK_ROWS
+    CH = synthetic.CHUNK_ROWS
     chunks = list(range(lo // CH, (hi + CH - 1) // CH))
     ix = ts.TheoremIndex(n_local, D, dtype=dtype, metric="ip", device=local_rank, row_offset=lo)
     ncpu = len(os.sched_getaffinity(0))
@@ -118,7 +119,7 @@ def main():
     cache_ok = n_local * D * elem <= (40 << 30) and not args.no_recall
 
     def make(c):
-        data = oracle.synth_chunk(c, CH, D, bf16=bf16) if not args.zero_corpus else np.zeros((CH, D), np.uint16 if bf16 else np.float32)
+        data = synthetic.synth_chunk(c, CH, D, bf16=bf16) if not args.zero_corpus else np.zeros((CH, D), np.uint16 if bf16 else np.float32)
         a, b = max(lo, c * CH), min(hi, (c + 1) * CH)
         ix.upload(data[a - c * CH:b - c * CH], a - lo)
         if cache_ok or (c == 0 and rank == 0):
@@ -131,7 +132,7 @@ def main():
                 log(rank, f"generated+uploaded {i + 1}/{len(chunks)} chunks ({time.time() - t_gen:.0f}s)")
     log(rank, f"corpus ready: {n_local} rows/rank x {D} {dtype} in {time.time() - t_gen:.1f}s ({nthreads} threads)")
 
-    q_host = oracle.synth_queries(0, nq, D, bf16=bf16)      # uint16 bits or float32
+    q_host = synthetic.synth_queries(0, nq, D, bf16=bf16)      # uint16 bits or float32
     if args.zero_queries:
         q_host = np.zeros_like(q_host)
     main = torch.cuda.current_stream()
@@ -260,7 +261,7 @@ def main():
         t_chk = time.time()
 
         def local_truth(c):
-            data = cache[c] if c in cache else oracle.synth_chunk(c, CH, D, bf16=bf16)
+            data = cache[c] if c in cache else synthetic.synth_chunk(c, CH, D, bf16=bf16)
             a, b = max(lo, c * CH), min(hi, (c + 1) * CH)
             blk = data[a - c * CH:b - c * CH]
             blk = oracle.bf16_bits_to_f32(blk) if bf16 else blk

@@ -127,6 +127,15 @@ int ts_search_filtered(ts_index *ix, const void *queries, int q_dtype, int q_on_
                        const uint32_t *row_mask, int mask_on_device, float *out_scores, int64_t *out_idx,
                        int out_on_device, void *stream);
 
+/* Rank of one given row per query in the canonical order of that query's scores over the whole index (0 = best):
+ * the number of rows whose (score, -row) beats the target's.  One streaming pass that counts; replaces ranking the
+ * full [nq x N] matrix and looking the relevant document up - np.argsort(-sim_matrix) followed by the position of
+ * the exact document in mrr_at_k with k=None (compare_embeddings.py:96-123) - for corpora whose score matrix
+ * does not fit.  target_rows are global ids (row_offset applies); out_rank[i] = -1 and out_score[i] = NaN when
+ * the row is not in this index or its score is NaN.  Host pointers; out_score may be NULL. */
+int ts_rank_of(ts_index *ix, const void *queries, int q_dtype, int q_on_device, int32_t nq, const int64_t *target_rows,
+               int64_t *out_rank, float *out_score, void *stream);
+
 /* Full [nq x n] fp32 score matrix (small N only): util.cos_sim(q_emb, s_emb) of
  * compare_embeddings.py:24,61.  out row stride is n. */
 int ts_scores(ts_index *ix, const void *queries, int q_dtype, int q_on_device, int32_t nq,

@@ -478,10 +478,8 @@ CHUNK_ROWS = 250_000
 
 def synth_chunk(chunk_id: int, rows: int = CHUNK_ROWS, d: int = 768, seed: int = 1234,
                 bf16: bool = False) -> np.ndarray:
-    """Chunk ``chunk_id`` of the synthetic corpus: random-normal rows, each
-    L2-normalised in fp32 (``l2_normalize``); bf16 configs round after the normalisation.
-    Returns fp32 (``bf16=False``) or uint16 bf16 bit patterns (``bf16=True``).
-    Works in sub-blocks so that many chunks can be generated by concurrent threads."""
+    """The benchmark's synthetic rows, restated with the oracle's own `l2_normalize` / `f32_to_bf16_bits` (the
+    generator bench.py uses lives in /synthetic.py; tests/test_oracle_golden.py checks the two agree bit for bit)."""
     x = np.random.default_rng([seed, chunk_id]).standard_normal((rows, d), dtype=np.float32)
     out = np.empty((rows, d), dtype=np.uint16) if bf16 else x
     for r0 in range(0, rows, 16384):
@@ -568,3 +566,16 @@ def showcase_filter_search(cos_scores, theorems_data, filters, pool=200):
         if len(rows) >= want:
             break
     return rows, len(rows) < want
+
+
+def rank_of(truth: np.ndarray, rows) -> np.ndarray:
+    """0-based position of rows[q] in the canonical order (score desc, index asc) of truth[q] - what
+    ``np.flatnonzero(np.argsort(-truth[q], kind="stable") == rows[q])[0]`` gives (the lookup inside the reference's
+    mrr_at_k, compare_embeddings.py:104-123); -1 when the row is out of range or its score is NaN."""
+    truth = _as_2d(truth)
+    out = np.full(truth.shape[0], -1, dtype=np.int64)
+    for q, t in enumerate(np.asarray(rows, dtype=np.int64)):
+        if 0 <= t < truth.shape[1] and truth[q, t] == truth[q, t]:
+            s = truth[q]
+            out[q] = int(np.sum(s > s[t]) + np.sum(s[:t] == s[t]))
+    return out

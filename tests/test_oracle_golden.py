@@ -166,3 +166,17 @@ def test_c_pgvector_scan_agrees_with_numpy_oracle():
     e2[[1, 3]] = [1, 0, 0, 0]
     rows, sim = oracle.pgvector_c_search(np.array([1, 0, 0, 0], np.float32), e2, 7)
     assert rows.tolist() == [1, 3, 0, 2, 4, -1, -1] and sim[:2].tolist() == [2.0, 2.0]
+
+
+def test_bench_generator_agrees_with_the_oracle_restatement():
+    """bench.py draws its corpus from /synthetic.py; the checkers regenerate rows through the oracle's own
+    normalisation and bf16 rounding.  The two must agree bit for bit."""
+    import synthetic
+    for bf16 in (False, True):
+        a = synthetic.synth_chunk(3, 20000, 768, bf16=bf16)
+        b = oracle.synth_chunk(3, 20000, 768, bf16=bf16)
+        assert a.dtype == b.dtype and np.array_equal(a, b)
+    assert np.array_equal(synthetic.synth_queries(0, 7), oracle.synth_queries(0, 7))
+    x = np.random.default_rng(0).standard_normal(1000).astype(np.float32)
+    assert np.array_equal(synthetic.bf16_bits(x), oracle.f32_to_bf16_bits(x))
+    assert np.array_equal(synthetic.bf16_bits_to_f32(synthetic.bf16_bits(x)), oracle.round_to_bf16(x))

@@ -323,6 +323,62 @@ def test_showcase_filters_return_topk_where_the_reference_pool_runs_dry(ts):
     assert saw_dry
 
 
+@pytest.mark.parametrize("dtype,d,n", [("f32", 768, 20011), ("bf16", 768, 20011), ("bf16", 1024, 5003), ("f32", 384, 3001)])
+def test_rank_of_matches_position_in_the_full_ranking(ts, dtype, d, n):
+    """ts_rank_of = position of the row in the full ranking of the fp64 truth, wherever the truth separates the
+    target from its neighbours by more than GAP; consistent with ts_search (rank r <=> idx[r] == row)."""
+    nq = 9
+    q, c = oracle.golden_inputs(n, nq, d, 41, "cos")
+    qp, cp = oracle.prepared_inputs(q, c, "cos", dtype)
+    truth = oracle.scores_fp64(qp, cp)
+    rng = np.random.default_rng(12)
+    order = np.argsort(-truth, axis=1, kind="stable")
+    # targets: the best row, the worst row, a top-10 row, random rows, one outside the index
+    targets = np.array([order[0, 0], order[1, -1], order[2, 7]] + [int(x) for x in rng.integers(0, n, nq - 4)] + [n + 5])
+    with ts.TheoremIndex.from_embeddings(c, dtype=dtype, metric="cos") as ix:
+        ranks, scores = ix.rank_of(q, targets)
+        exp = oracle.rank_of(truth, targets)
+        assert ranks[-1] == -1 and np.isnan(scores[-1]) and exp[-1] == -1
+        s_idx = ix.search(q, 10, algo="scan")[1]
+        for b in range(nq - 1):
+            t = targets[b]
+            assert abs(scores[b] - truth[b, t]) <= SCORE_TOL
+            close = np.sum(np.abs(truth[b] - truth[b, t]) <= GAP) - 1   # rows the truth cannot separate from the target
+            assert abs(int(ranks[b]) - int(exp[b])) <= close, (b, ranks[b], exp[b])
+            if ranks[b] < 10:
+                assert s_idx[b, ranks[b]] == t
+        assert ranks[0] == 0 and ranks[1] == n - 1 and ranks[2] == 7
+
+
+def test_metrics_from_the_index_equal_metrics_from_the_matrix(ts):
+    """IndexRanking (top-k searches + counting pass) through the six metric functions = the same functions on the
+    full similarity matrix (the reference's formulation, compare_embeddings.py:55-371)."""
+    from theoremsearch_amd import compare_embeddings as ce
+    n, nq, d = 4000, 24, 768
+    q, c = oracle.golden_inputs(n, nq, d, 53, "cos")
+    rng = np.random.default_rng(4)
+    qrels = {}
+    qp, cp = oracle.prepared_inputs(q, c, "cos", "f32")
+    truth = oracle.scores_fp64(qp, cp)
+    order = np.argsort(-truth, axis=1, kind="stable")
+    for i in range(nq):
+        exact = int(order[i, [0, 1, 2, 5, 40, 900][i % 6]])      # exact doc at assorted depths of the ranking
+        rels = {exact: 1}
+        for j in rng.integers(0, n, 6):
+            rels.setdefault(int(j), 0.5)
+        for j in order[i, 1:4]:
+            rels.setdefault(int(j), 0.5)
+        qrels[i] = rels
+    with ts.TheoremIndex.from_embeddings(c, dtype="f32", metric="cos") as ix:
+        sim = ix.scores(q)
+        ranking = ce.IndexRanking(ix, q)
+        for k in (1, 3, 10):
+            for fn in (ce.precision_at_k, ce.hit_at_k, ce.mrr_at_k, ce.ndcg_at_k, ce.err_at_k, ce.q_measure_at_k):
+                assert fn(ranking, qrels, k=k) == pytest.approx(fn(sim, qrels, k=k), abs=1e-12), (fn.__name__, k)
+        assert ce.mrr_at_k(ranking, qrels, k=None) == pytest.approx(ce.mrr_at_k(sim, qrels, k=None), abs=1e-12)
+        assert ce.mrr_at_k(ranking, qrels, k=None) == pytest.approx(oracle.mrr_at_k(truth, qrels, k=None), abs=1e-12)
+
+
 def test_empty_and_invalid_arguments(ts):
     from theoremsearch_amd import _ffi
     c = np.random.default_rng(1).standard_normal((10, 16), dtype=np.float32)

@@ -58,6 +58,8 @@ _SIGNATURES = {
                                C.c_int, C.c_void_p, C.c_int, C.POINTER(SearchStats)]),
     "ts_search_filtered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "ts_rank_of": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                             C.c_void_p]),
     "ts_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_void_p, C.c_int, C.c_void_p]),
     "ts_merge_topk": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                 C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

@@ -43,8 +43,37 @@ def rank_concepts(sim_matrix):
     return [np.argsort(-np.asarray(row)) for row in sim_matrix]
 
 
+class IndexRanking:
+    """Stands in for the ``[Q x N]`` similarity matrix when the corpus lives in a `TheoremIndex` and the matrix
+    would not fit (10M slogans x 1k queries = 40 GB): the metric functions below only ever need the k best docs
+    per query (``index.search``) or the position of one relevant doc in the full ranking (``index.rank_of``, a
+    counting pass), never the matrix itself.  Pass it wherever they take ``sim_matrix`` / ``ranked``."""
+
+    def __init__(self, index, query_emb):
+        self.index = index
+        self.query_emb = np.asarray(query_emb.detach().cpu().float().numpy() if hasattr(query_emb, "detach") else query_emb,
+                                    dtype=np.float32)
+        self.shape = (self.query_emb.shape[0], index.n)
+        self._cache = {}
+
+    def top(self, k):
+        k = min(int(k), self.index.n)
+        if k > 256:
+            raise ValueError("IndexRanking serves k <= 256; use rank_of for positions further down")
+        if k not in self._cache:
+            self._cache[k] = self.index.search(self.query_emb, k)[1]
+        return self._cache[k]
+
+    def rank_of(self, docs):
+        return self.index.rank_of(self.query_emb, docs)[0]
+
+
 def _top(sim_matrix, k):
     """Indices of the k best docs per query, best first (all docs when k is None)."""
+    if isinstance(sim_matrix, IndexRanking):
+        if k is None:
+            raise ValueError("a full ranking is not materialised for an IndexRanking")
+        return sim_matrix.top(k)
     s = np.asarray(sim_matrix)
     if k is None or k >= s.shape[1]:
         return np.argsort(-s, axis=1)
@@ -83,6 +112,23 @@ def evaluate_retrieval(model, theorems, queries, qrels, top_k_report=3):
         print(f"{item} | {res}")
 
 
+def evaluate_retrieval_index(model, index, queries, qrels, top_k_report=3):
+    """`evaluate_retrieval` against a corpus that is already a `TheoremIndex` (10M slogans rather than the script's
+    few hundred): same six metrics and printed report, from top-k searches and one counting pass - no ``[Q x N]``
+    similarity matrix.  Returns the metrics as a dict as well."""
+    q_emb = model.encode([item[0] for item in queries], convert_to_numpy=True)
+    ranking = IndexRanking(index, q_emb)
+    out = {"P@1": precision_at_k(ranking, qrels, k=1), f"H@{top_k_report}": hit_at_k(ranking, qrels, k=top_k_report),
+           f"MRR@{top_k_report}": mrr_at_k(ranking, qrels, k=top_k_report), "MRR": mrr_at_k(ranking, qrels, k=None),
+           f"nDCG@{top_k_report}": ndcg_at_k(ranking, qrels, k=top_k_report),
+           f"ERR@{top_k_report}": err_at_k(ranking, qrels, k=top_k_report),
+           f"Q-measure@{top_k_report}": q_measure_at_k(ranking, qrels, k=top_k_report)}
+    print("=" * 50)
+    for item, res in out.items():
+        print(f"{item} | {res}")
+    return out
+
+
 def precision_at_k(sim_matrix, qrels, k=5):
     top = _top(sim_matrix, k)
     return float(np.mean([(1 if _exact_doc(qrels[q]) in top[q] else 0) / k for q in range(top.shape[0])]))
@@ -94,6 +140,11 @@ def hit_at_k(sim_matrix, qrels, k=5):
 
 
 def mrr_at_k(sim_matrix, qrels, k=None):
+    if isinstance(sim_matrix, IndexRanking) and (k is None or k > 256):
+        # position of the exact doc in the full ranking, by counting the rows that beat it
+        docs = [_exact_doc(qrels[q]) for q in range(sim_matrix.shape[0])]
+        ranks = sim_matrix.rank_of(docs)
+        return float(np.mean([1.0 / (r + 1) if (r >= 0 and (k is None or r < k)) else 0.0 for r in ranks]))
     top = _top(sim_matrix, k)
     rr = []
     for q in range(top.shape[0]):

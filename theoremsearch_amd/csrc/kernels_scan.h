@@ -239,4 +239,160 @@ __global__ void __launch_bounds__(256) scan_generic_kernel(ScanArgs a) {
     }
 }
 
+// ---- rank of a given row ("rank of gold") -----------------------------------------------------------------
+// The evaluation script ranks the whole corpus per query and looks up where the relevant document landed
+// (compare_embeddings.py:104-123 mrr_at_k with k=None: np.argsort(-sim) then the position of the exact doc).
+// The position of row t in the canonical order is the number of rows whose key beats key(t): one streaming
+// pass that counts, no [nq x N] matrix and no sort.  The score arithmetic is the scan kernel's (same chunk
+// order, same reduce4), so the rank is consistent with what ts_search returns through the scan path.
+struct RankArgs {
+    const void* corpus;
+    int64_t ld, n;
+    const float* qbuf;            // prepared queries, fp32 [nq x ld]
+    int nq;
+    const int64_t* target;        // [nq] local row of each query's document; outside [0, n) = none
+    unsigned long long* counts;   // [nq] zeroed by the host; += rows ranked strictly before the target
+    float* tscore;                // [nq] score of the target row (NaN when there is none)
+};
+
+template <int DT, int CH, int G, int QB>
+__global__ void __launch_bounds__(256) rank_kernel(RankArgs a) {
+    constexpr int VEC = Elem<DT>::VEC;
+    constexpr int GROUPS = 64 / G;
+    constexpr int RW = kScanRB * GROUPS;
+    const int lane = threadIdx.x & 63;
+    const int gl = lane & (G - 1);
+    const int grp = lane / G;
+    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t W = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t nblocks = (a.n + RW - 1) / RW;
+    const uint4* __restrict__ base = (const uint4*)a.corpus;
+    const int64_t ld16 = a.ld / VEC;
+    const int myrow = rho<G>(lane);
+    const bool rep = (lane & (G / 4 - 1)) == 0;
+    __shared__ unsigned int wg_cnt[QB];
+
+    for (int g0 = 0; g0 < a.nq; g0 += QB) {
+        float qv[QB][CH][VEC];
+        int qid[QB];
+        u64 gkey[QB];
+        unsigned int cnt[QB];
+#pragma unroll
+        for (int q = 0; q < QB; ++q) {
+            qid[q] = (g0 + q < a.nq) ? (g0 + q) : g0;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) qv[q][c][e] = a.qbuf[(int64_t)qid[q] * a.ld + (int64_t)(gl + c * G) * VEC + e];
+            // key of the target row: its 4-row block goes through the same arithmetic as the pass below
+            const int64_t t = a.target[qid[q]];
+            const bool has = t >= 0 && t < a.n;
+            const int64_t tb = has ? (t & ~(int64_t)3) : 0;
+            float acc[kScanRB];
+#pragma unroll
+            for (int r = 0; r < kScanRB; ++r) {
+                float s = 0.0f;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) s = chunk_dot<DT>(stream_load(base + (tb + r) * ld16 + gl + c * G), qv[q][c], s);
+                acc[r] = s;
+            }
+            const float s4 = reduce4<G>(acc[0], acc[1], acc[2], acc[3], lane);
+            const int tr = (int)(t & 3);
+            const float st = __shfl(s4, ((tr & 2) ? G / 2 : 0) + ((tr & 1) ? G / 4 : 0), 64);
+            gkey[q] = (has && st == st) ? make_key(st, (u32)t) : ~0ull;
+            cnt[q] = 0;
+            if (gw == 0 && lane == 0 && g0 + q < a.nq) a.tscore[qid[q]] = (has ? st : __uint_as_float(0x7FC00000u));
+        }
+        for (int64_t blk = gw; blk < nblocks; blk += W) {
+            const int64_t row0 = blk * RW + grp * kScanRB;
+            uint4 v[kScanRB][CH];
+#pragma unroll
+            for (int r = 0; r < kScanRB; ++r)
+#pragma unroll
+                for (int c = 0; c < CH; ++c) v[r][c] = stream_load(base + (row0 + r) * ld16 + gl + c * G);
+            const int64_t row = row0 + myrow;
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                float acc[kScanRB];
+#pragma unroll
+                for (int r = 0; r < kScanRB; ++r) {
+                    float s = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) s = chunk_dot<DT>(v[r][c], qv[q][c], s);
+                    acc[r] = s;
+                }
+                const float s = reduce4<G>(acc[0], acc[1], acc[2], acc[3], lane);
+                const u64 key = (rep && row < a.n && s == s) ? make_key(s, (u32)row) : 0ull;
+                cnt[q] += (unsigned int)__popcll(__ballot(key > gkey[q]));
+            }
+        }
+        // one atomic per workgroup and query: thousands of waves adding to one address serialise in L2
+        __syncthreads();
+        if (threadIdx.x < QB) wg_cnt[threadIdx.x] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < QB; ++q)
+            if (lane == 0 && cnt[q]) atomicAdd(&wg_cnt[q], cnt[q]);
+        __syncthreads();
+        if (threadIdx.x < QB && wg_cnt[threadIdx.x] && g0 + threadIdx.x < a.nq)
+            atomicAdd(&a.counts[g0 + threadIdx.x], (unsigned long long)wg_cnt[threadIdx.x]);
+    }
+}
+
+// Any ld: one query per pass, query staged in LDS (the arithmetic of scan_generic_kernel).
+template <int DT>
+__global__ void __launch_bounds__(256) rank_generic_kernel(RankArgs a) {
+    constexpr int VEC = Elem<DT>::VEC;
+    constexpr int RW = kScanRB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* lds_q = (float*)smem;
+    const int lane = threadIdx.x & 63;
+    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t W = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t nblocks = (a.n + RW - 1) / RW;
+    const uint4* __restrict__ base = (const uint4*)a.corpus;
+    const int64_t ld16 = a.ld / VEC;
+    const bool rep = (lane & 15) == 0;
+
+    auto block_score = [&](int64_t row0) -> float {
+        float acc[kScanRB] = {0.f, 0.f, 0.f, 0.f};
+        for (int64_t c = lane; c < ld16; c += 64) {
+            float qreg[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) qreg[e] = lds_q[c * VEC + e];
+#pragma unroll
+            for (int r = 0; r < kScanRB; ++r) acc[r] = chunk_dot<DT>(stream_load(base + (row0 + r) * ld16 + c), qreg, acc[r]);
+        }
+        return reduce4<64>(acc[0], acc[1], acc[2], acc[3], lane);
+    };
+
+    for (int qid = 0; qid < a.nq; ++qid) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < a.ld; i += blockDim.x) lds_q[i] = a.qbuf[(int64_t)qid * a.ld + i];
+        __syncthreads();
+        const int64_t t = a.target[qid];
+        const bool has = t >= 0 && t < a.n;
+        const float s4 = block_score(has ? (t & ~(int64_t)3) : 0);
+        const int tr = (int)(t & 3);
+        const float st = __shfl(s4, ((tr & 2) ? 32 : 0) + ((tr & 1) ? 16 : 0), 64);
+        const u64 gkey = (has && st == st) ? make_key(st, (u32)t) : ~0ull;
+        if (gw == 0 && lane == 0) a.tscore[qid] = has ? st : __uint_as_float(0x7FC00000u);
+        unsigned int cnt = 0;
+        for (int64_t blk = gw; blk < nblocks; blk += W) {
+            const int64_t row0 = blk * RW;
+            const float s = block_score(row0);
+            const int64_t row = row0 + rho<64>(lane);
+            const u64 key = (rep && row < a.n && s == s) ? make_key(s, (u32)row) : 0ull;
+            cnt += (unsigned int)__popcll(__ballot(key > gkey));
+        }
+        __shared__ unsigned int wg_cnt;
+        __syncthreads();
+        if (threadIdx.x == 0) wg_cnt = 0;
+        __syncthreads();
+        if (lane == 0 && cnt) atomicAdd(&wg_cnt, cnt);
+        __syncthreads();
+        if (threadIdx.x == 0 && wg_cnt) atomicAdd(&a.counts[qid], (unsigned long long)wg_cnt);
+    }
+}
+
 }  // namespace ts

@@ -79,6 +79,7 @@ struct ts_index {
     u64* partial = nullptr;     u64* partial2 = nullptr;     size_t partial_bytes = 0;
     float* res_scores = nullptr; int64_t* res_idx = nullptr; size_t res_cap = 0;  // device result buffers (entries)
     u32* mask_dev = nullptr;    size_t mask_bytes = 0;       // filtered search: device copy of a host bitmask
+    void* rank_buf = nullptr;   size_t rank_bytes = 0;       // ts_rank_of: targets | counts | target scores, one query block
     const u32* active_mask = nullptr;                        // bitmask of the search in progress (under `mu`)
     bool attr_done = false;
     // optional event brackets around the dominant kernel (ts_index_profile_*)
@@ -211,7 +212,7 @@ extern "C" int ts_index_destroy(ts_index* ix) {
     if (!ix) return TS_OK;
     hipSetDevice(ix->device);
     if (ix->stream) hipStreamSynchronize(ix->stream);
-    void* ptrs[] = {ix->rows,  ix->stage,   ix->qstore,   ix->qf32,     ix->cand,       ix->count,  ix->thr, ix->priv, ix->pcount, ix->mask_dev,
+    void* ptrs[] = {ix->rows,  ix->stage,   ix->qstore,   ix->qf32,     ix->cand,       ix->count,  ix->thr, ix->priv, ix->pcount, ix->mask_dev, ix->rank_buf,
                     ix->fb_list, ix->fb_count, ix->stat, ix->partial, ix->partial2, ix->res_scores, ix->res_idx};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -830,6 +831,90 @@ extern "C" int ts_search_filtered(ts_index* ix, const void* queries, int q_dtype
     if (!row_mask) return fail(TS_ERR_INVALID, "row_mask is NULL");
     return search_impl(ix, queries, q_dtype, q_on_device, nq, k, out_scores, out_idx, out_on_device, stream, TS_ALGO_SCAN,
                        nullptr, row_mask, mask_on_device);
+}
+
+template <int DT, int CH, int G>
+static void launch_rank_spec(int qb, int grid, hipStream_t st, const RankArgs& a) {
+    if (qb == 4) rank_kernel<DT, CH, G, 4><<<grid, 256, 0, st>>>(a);
+    else rank_kernel<DT, CH, G, 1><<<grid, 256, 0, st>>>(a);
+}
+
+static void launch_rank(const ts_index* ix, const RankArgs& a, hipStream_t st, int grid) {
+    const int qb = a.nq >= 2 ? 4 : 1;
+    const bool force_generic = env_int("TS_SCAN_GENERIC", 0) != 0;
+    if (!force_generic && ix->dtype == TS_F32 && ix->ld == 768) return launch_rank_spec<0, 3, 64>(qb, grid, st, a);
+    if (!force_generic && ix->dtype == TS_F32 && ix->ld == 1024) return launch_rank_spec<0, 4, 64>(qb, grid, st, a);
+    if (!force_generic && ix->dtype == TS_BF16 && ix->ld == 768) return launch_rank_spec<1, 3, 32>(qb, grid, st, a);
+    if (!force_generic && ix->dtype == TS_BF16 && ix->ld == 1024) return launch_rank_spec<1, 2, 64>(qb, grid, st, a);
+    const size_t lds = (size_t)a.ld * 4;
+    if (ix->dtype == TS_F32) {
+        hipFuncSetAttribute((const void*)rank_generic_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        rank_generic_kernel<0><<<grid, 256, lds, st>>>(a);
+    } else {
+        hipFuncSetAttribute((const void*)rank_generic_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        rank_generic_kernel<1><<<grid, 256, lds, st>>>(a);
+    }
+}
+
+extern "C" int ts_rank_of(ts_index* ix, const void* queries, int q_dtype, int q_on_device, int32_t nq, const int64_t* target_rows,
+                          int64_t* out_rank, float* out_score, void* stream) {
+    if (!ix || !queries || !target_rows || !out_rank) return fail(TS_ERR_INVALID, "NULL argument");
+    if (q_dtype != TS_F32 && q_dtype != TS_BF16) return fail(TS_ERR_INVALID, "q_dtype %d", q_dtype);
+    if (nq < 0) return fail(TS_ERR_INVALID, "nq = %d", nq);
+    if (nq == 0) return TS_OK;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
+    TS_TRY(ensure_search_scratch(ix, 1));
+    constexpr size_t kPer = 8 + 8 + 4;
+    TS_TRY(ensure(&ix->rank_buf, &ix->rank_bytes, (size_t)kQBlock * kPer));
+    int64_t* d_target = (int64_t*)ix->rank_buf;
+    unsigned long long* d_counts = (unsigned long long*)(d_target + kQBlock);
+    float* d_tscore = (float*)(d_counts + kQBlock);
+    const size_t q_elem = q_dtype == TS_BF16 ? 2 : 4;
+    if (!q_on_device) TS_TRY(ensure(&ix->stage, &ix->stage_bytes, kStageBytes));
+    std::vector<int64_t> local(kQBlock);
+    std::vector<unsigned long long> counts(kQBlock);
+    std::vector<float> tscore(kQBlock);
+    for (int q0 = 0; q0 < nq; q0 += kQBlock) {
+        const int nb = std::min(kQBlock, nq - q0);
+        const void* qsrc = (const char*)queries + (size_t)q0 * ix->d * q_elem;
+        if (!q_on_device) {
+            HIP_TRY(hipMemcpyAsync(ix->stage, qsrc, (size_t)nb * ix->d * q_elem, hipMemcpyHostToDevice, st));
+            qsrc = ix->stage;
+        }
+        TS_TRY(prep_dispatch(q_dtype, ix->dtype, ix->metric == TS_METRIC_COS, qsrc, ix->d, ix->qstore, ix->qf32, ix->ld, ix->d, nb,
+                             kQBlock, st));
+        for (int i = 0; i < nb; ++i) {
+            const int64_t r = target_rows[q0 + i] - ix->row_offset;
+            local[i] = (r >= 0 && r < ix->n) ? r : -1;
+        }
+        HIP_TRY(hipMemcpyAsync(d_target, local.data(), (size_t)nb * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)nb * 8, st));
+        RankArgs a;
+        memset(&a, 0, sizeof(a));
+        a.corpus = ix->rows;
+        a.ld = ix->ld;
+        a.n = ix->n;
+        a.qbuf = ix->qf32;
+        a.nq = nb;
+        a.target = d_target;
+        a.counts = d_counts;
+        a.tscore = d_tscore;
+        hipEvent_t stop = prof_begin(ix, st, ix->n);
+        launch_rank(ix, a, st, ix->cu_count * kScanGridPerCU);
+        prof_end(stop, st);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, (size_t)nb * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(tscore.data(), d_tscore, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));  // `local` is reused by the next block
+        for (int i = 0; i < nb; ++i) {
+            const bool ok = local[i] >= 0 && tscore[i] == tscore[i];
+            out_rank[q0 + i] = ok ? (int64_t)counts[i] : -1;
+            if (out_score) out_score[q0 + i] = tscore[i];
+        }
+    }
+    return TS_OK;
 }
 
 extern "C" int ts_scores(ts_index* ix, const void* queries, int q_dtype, int q_on_device, int32_t nq, float* out,

@@ -146,6 +146,22 @@ class TheoremIndex:
                                           C.c_void_p(out_scores_ptr), C.c_void_p(out_idx_ptr), 1,
                                           C.c_void_p(stream), _ALGOS[algo], None))
 
+    def rank_of(self, queries, rows) -> Tuple[np.ndarray, np.ndarray]:
+        """0-based rank of ``rows[i]`` among all index rows for query ``i`` (score descending, index ascending)
+        and its score: what ``np.flatnonzero(np.argsort(-sim[i]) == rows[i])`` yields on the full score matrix
+        (compare_embeddings.py:96-123), computed by one counting pass.  ``-1`` / NaN for rows not in the index."""
+        q = _host_rows(queries)
+        if q.shape[1] != self.d:
+            raise ValueError(f"queries have d={q.shape[1]}, index has d={self.d}")
+        t = np.ascontiguousarray(np.asarray(rows, dtype=np.int64).reshape(-1))
+        if t.shape[0] != q.shape[0]:
+            raise ValueError("one target row per query")
+        ranks = np.empty(q.shape[0], dtype=np.int64)
+        scores = np.empty(q.shape[0], dtype=np.float32)
+        _ffi.check(self._lib.ts_rank_of(self._h, _ffi.as_ptr(q), _ffi.np_dtype_code(q), 0, q.shape[0], _ffi.as_ptr(t),
+                                        _ffi.as_ptr(ranks), _ffi.as_ptr(scores), None))
+        return ranks, scores
+
     def scores(self, queries) -> np.ndarray:
         """Full ``[nq x N]`` fp32 score matrix (small N): ``util.cos_sim(q_emb, s_emb)`` of
         compare_embeddings.py:24,61 when the index metric is "cos"."""
