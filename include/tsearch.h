@@ -117,6 +117,14 @@ int ts_search_ex(ts_index *ix, const void *queries, int q_dtype, int q_on_device
                  float *out_scores, int64_t *out_idx, int out_on_device, void *stream, int algo,
                  ts_search_stats *stats);
 
+/* A second index holding copies of the given rows of `src` (global ids, strictly ascending, host memory); searches
+ * of it return the ORIGINAL global ids, in the same canonical order.  The filtered search for query batches and for
+ * filters that stay fixed over many searches (a sidebar state, app_showcase_model.py:96-129; the WHERE clause of
+ * streamlit_app.py:175-283): the copy costs 2 * nrows * ld * elem bytes of HBM traffic once, after which every
+ * search runs the unfiltered kernels over nrows rows.  Rows are copied as stored (no second normalisation).
+ * Uploading into a subset index and ts_rank_of on it are not supported. */
+int ts_index_subset(ts_index *src, const int64_t *rows, int64_t nrows, ts_index **out);
+
 /* Search restricted to the rows whose bit is set in row_mask (uint32 words, bit r & 31 of word r >> 5 = row r,
  * ceil(n / 32) words, host or device memory): the k best ALLOWED rows, exactly.  Stands in for the metadata
  * filters of the apps - the WHERE clause in front of ORDER BY ... LIMIT k (streamlit_app.py:175-243,253-283) and

@@ -297,6 +297,47 @@ def test_filtered_search_equals_search_of_the_allowed_rows(ts, dtype):
         check(q, c, "cos", dtype, k, s0, i0)
 
 
+def test_subset_index_returns_the_ids_of_the_parent(ts):
+    """ts_index_subset: a batch search of the copy = the filtered scan of the parent = the oracle over the allowed
+    rows, with the parent's global ids (row_offset included); MFMA path and scan path of the copy."""
+    n, d, nq, k = 30011, 768, 40, 10
+    q, c = oracle.golden_inputs(n, nq, d, 88, "cos")
+    rng = np.random.default_rng(2)
+    mask = rng.random(n) < 0.6
+    mask[0] = mask[-1] = True
+    allowed = np.flatnonzero(mask)
+    off = 1000
+    with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="cos", row_offset=off) as ix:
+        with ix.subset(mask) as sub:
+            assert sub.n == allowed.size
+            qp, cp = oracle.prepared_inputs(q, c[allowed], "cos", "bf16")
+            truth = oracle.scores_fp64(qp, cp)
+            for algo in ("mfma", "scan"):
+                scores, idx = sub.search(q, k, algo=algo)
+                assert mask[idx - off].all()
+                local = np.searchsorted(allowed, idx - off)
+                stats = oracle.check_topk_against_truth(truth, local, scores, k, gap=GAP, score_tol=SCORE_TOL)
+                assert stats["recall"] == 1.0
+            # same answer as the masked scan of the parent (same arithmetic: bitwise)
+            s_par, i_par = ix.search(q[:4], k, mask=mask)
+            s_sub, i_sub = sub.search(q[:4], k, algo="scan")
+            assert np.array_equal(i_par, i_sub) and np.array_equal(s_par, s_sub)
+            with pytest.raises(ts.TSearchError):
+                sub.upload(c[:1], 0)
+            with pytest.raises(ts.TSearchError):
+                sub.subset(np.arange(3))
+        with ix.subset(np.array([off + 5, off + 9])) as two:
+            s2, i2 = two.search(q[:2], 5)
+            assert set(i2[:, :2].ravel()) == {off + 5, off + 9} and (i2[:, 2:] == -1).all()
+        with ix.subset(np.zeros(n, bool)) as none:
+            s0, i0 = none.search(q[:2], 3)
+            assert (i0 == -1).all()
+        with pytest.raises(ts.TSearchError):
+            ix.subset(np.array([off + 9, off + 5]))   # not ascending
+        with pytest.raises(ts.TSearchError):
+            ix.subset(np.array([5]))                  # below row_offset
+
+
 def test_showcase_filters_return_topk_where_the_reference_pool_runs_dry(ts):
     """filters.search_filtered against the restated app loop (app_showcase_model.py:93-129): same rows whenever the
     top-200 pool held top_k matches; when it ran dry, ours continues with the next best matching rows."""

@@ -140,4 +140,19 @@ __global__ void __launch_bounds__(256) unpad_rows_kernel(const void* __restrict_
     }
 }
 
+// Subset index: copy the stored (already prepared) rows src[ids[i] - id_base] -> dst[i], one wave per row,
+// 16 bytes per lane.  row_bytes is a multiple of 128 (ld is a multiple of 64 elements).
+__global__ void __launch_bounds__(256) gather_rows_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
+                                                           const int64_t* __restrict__ ids, int64_t id_base, int64_t nrows,
+                                                           int64_t row_bytes) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t i = wave; i < nrows; i += nwaves) {
+        const uint4* s = (const uint4*)(src + (ids[i] - id_base) * row_bytes);
+        uint4* d = (uint4*)(dst + i * row_bytes);
+        for (int64_t c = lane; c < row_bytes / 16; c += 64) d[c] = s[c];
+    }
+}
+
 }  // namespace ts

@@ -31,6 +31,7 @@ struct SelectArgs {
     int64_t* out_idx;
     int k_user;
     int64_t row_offset;
+    const int64_t* id_map;  // optional: local row -> global id (subset indexes); replaces row + row_offset
     const int* qlist;    // optional slot -> query id
     const int* qcount;   // optional device-side slot count
 };
@@ -55,7 +56,7 @@ __global__ void __launch_bounds__(256) select_kernel(SelectArgs a) {
         for (int i = threadIdx.x; i < a.k_user; i += blockDim.x) {
             const u64 key = (i < P) ? keys[i] : 0ull;
             a.out_scores[(int64_t)qid * a.k_user + i] = key ? key_score(key) : -INFINITY;
-            a.out_idx[(int64_t)qid * a.k_user + i] = key ? (int64_t)key_row(key) + a.row_offset : -1;
+            a.out_idx[(int64_t)qid * a.k_user + i] = !key ? -1 : a.id_map ? a.id_map[key_row(key)] : (int64_t)key_row(key) + a.row_offset;
         }
     } else {
         u64* dst = a.out + (int64_t)slot * a.out_stride + (int64_t)seg * a.kout;
@@ -85,6 +86,7 @@ struct LevelArgs {
     int64_t* out_idx;
     int k_user;
     int64_t row_offset;
+    const int64_t* id_map;
     int* fb_list;
     int* fb_count;
     unsigned long long* stat_candidates;  // sum of candidates seen at the final level
@@ -213,7 +215,7 @@ __global__ void __launch_bounds__(kLevelThreads) level_select_kernel(LevelArgs a
     for (int i = threadIdx.x; i < a.k_user; i += blockDim.x) {
         const u64 key = best[i];
         a.out_scores[(int64_t)q * a.k_user + i] = key ? key_score(key) : -INFINITY;
-        a.out_idx[(int64_t)q * a.k_user + i] = key ? (int64_t)key_row(key) + a.row_offset : -1;
+        a.out_idx[(int64_t)q * a.k_user + i] = !key ? -1 : a.id_map ? a.id_map[key_row(key)] : (int64_t)key_row(key) + a.row_offset;
     }
 }
 

@@ -79,6 +79,7 @@ struct ts_index {
     u64* partial = nullptr;     u64* partial2 = nullptr;     size_t partial_bytes = 0;
     float* res_scores = nullptr; int64_t* res_idx = nullptr; size_t res_cap = 0;  // device result buffers (entries)
     u32* mask_dev = nullptr;    size_t mask_bytes = 0;       // filtered search: device copy of a host bitmask
+    int64_t* id_map = nullptr;                               // subset index: local row -> global id
     void* rank_buf = nullptr;   size_t rank_bytes = 0;       // ts_rank_of: targets | counts | target scores, one query block
     const u32* active_mask = nullptr;                        // bitmask of the search in progress (under `mu`)
     bool attr_done = false;
@@ -212,7 +213,7 @@ extern "C" int ts_index_destroy(ts_index* ix) {
     if (!ix) return TS_OK;
     hipSetDevice(ix->device);
     if (ix->stream) hipStreamSynchronize(ix->stream);
-    void* ptrs[] = {ix->rows,  ix->stage,   ix->qstore,   ix->qf32,     ix->cand,       ix->count,  ix->thr, ix->priv, ix->pcount, ix->mask_dev, ix->rank_buf,
+    void* ptrs[] = {ix->rows,  ix->stage,   ix->qstore,   ix->qf32,     ix->cand,       ix->count,  ix->thr, ix->priv, ix->pcount, ix->mask_dev, ix->rank_buf, ix->id_map,
                     ix->fb_list, ix->fb_count, ix->stat, ix->partial, ix->partial2, ix->res_scores, ix->res_idx};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -225,6 +226,41 @@ extern "C" int ts_index_destroy(ts_index* ix) {
 extern "C" int ts_index_set_row_offset(ts_index* ix, int64_t off) {
     if (!ix || off < 0) return fail(TS_ERR_INVALID, "bad argument");
     ix->row_offset = off;
+    return TS_OK;
+}
+
+extern "C" int ts_index_subset(ts_index* src, const int64_t* rows, int64_t nrows, ts_index** out) {
+    if (!out) return fail(TS_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!src || (!rows && nrows > 0) || nrows < 0) return fail(TS_ERR_INVALID, "bad argument");
+    if (src->id_map) return fail(TS_ERR_UNSUPPORTED, "subset of a subset index: take the subset of the original index");
+    for (int64_t i = 0; i < nrows; ++i) {
+        const int64_t r = rows[i] - src->row_offset;
+        if (r < 0 || r >= src->n) return fail(TS_ERR_INVALID, "rows[%lld] = %lld is not in the index", (long long)i, (long long)rows[i]);
+        if (i && rows[i] <= rows[i - 1]) return fail(TS_ERR_INVALID, "rows must be strictly ascending (at %lld)", (long long)i);
+    }
+    ts_index* ix = nullptr;
+    TS_TRY(ts_index_create(src->device, nrows, src->d, src->dtype, src->metric, &ix));
+    if (nrows == 0) {
+        *out = ix;
+        return TS_OK;
+    }
+    std::lock_guard<std::mutex> lock(src->mu);
+    hipStreamSynchronize(src->stream);  // uploads enqueued on the source's own stream
+    hipError_t e = hipMalloc((void**)&ix->id_map, (size_t)nrows * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(ix->id_map, rows, (size_t)nrows * 8, hipMemcpyHostToDevice, ix->stream);
+    if (e == hipSuccess) {
+        const int grid = (int)std::min<int64_t>((nrows + 3) / 4, 8192);
+        gather_rows_kernel<<<grid, 256, 0, ix->stream>>>((const unsigned char*)src->rows, (unsigned char*)ix->rows, ix->id_map,
+                                                         src->row_offset, nrows, (int64_t)src->ld * src->elem());
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+    if (e != hipSuccess) {
+        ts_index_destroy(ix);
+        return fail(TS_ERR_HIP, "subset copy failed: %s", hipGetErrorString(e));
+    }
+    *out = ix;
     return TS_OK;
 }
 
@@ -275,6 +311,7 @@ static int prep_dispatch(int src_dtype, int dst_dtype, bool normalize, const voi
 static int check_rows(const ts_index* ix, const void* p, int src_dtype, int64_t row0, int64_t nrows) {
     if (!ix || !p) return fail(TS_ERR_INVALID, "NULL argument");
     if (src_dtype != TS_F32 && src_dtype != TS_BF16) return fail(TS_ERR_INVALID, "src_dtype %d", src_dtype);
+    if (ix->id_map) return fail(TS_ERR_UNSUPPORTED, "a subset index is read-only");
     if (row0 < 0 || nrows < 0 || row0 + nrows > ix->n)
         return fail(TS_ERR_INVALID, "rows [%lld, %lld) outside the index of %lld rows", (long long)row0,
                     (long long)(row0 + nrows), (long long)ix->n);
@@ -464,6 +501,7 @@ static int run_select_rounds(ts_index* ix, int slots, int m, int k, float* out_s
         a.kout = k;
         a.k_user = k;
         a.row_offset = ix->row_offset;
+        a.id_map = ix->id_map;
         a.qlist = qlist;
         a.qcount = qcount;
         if (m <= 1024 || (k > 64 && m <= 4096)) {
@@ -705,6 +743,7 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         l.out_idx = out_idx;
         l.k_user = k;
         l.row_offset = ix->row_offset;
+        l.id_map = ix->id_map;
         l.fb_list = ix->fb_list;
         l.fb_count = ix->fb_count;
         l.stat_candidates = ix->stat;
@@ -862,6 +901,7 @@ extern "C" int ts_rank_of(ts_index* ix, const void* queries, int q_dtype, int q_
     if (q_dtype != TS_F32 && q_dtype != TS_BF16) return fail(TS_ERR_INVALID, "q_dtype %d", q_dtype);
     if (nq < 0) return fail(TS_ERR_INVALID, "nq = %d", nq);
     if (nq == 0) return TS_OK;
+    if (ix->id_map) return fail(TS_ERR_UNSUPPORTED, "ts_rank_of on a subset index");
     std::lock_guard<std::mutex> lock(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = stream ? (hipStream_t)stream : ix->stream;

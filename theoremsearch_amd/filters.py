@@ -48,6 +48,13 @@ def filter_mask(theorems_data: Sequence[Mapping], filters: Mapping) -> np.ndarra
     return np.fromiter((_passes(it, filters) for it in theorems_data), dtype=bool, count=len(theorems_data))
 
 
+def filtered_index(index, theorems_data: Sequence[Mapping], filters: Mapping):
+    """A sub-index of the rows that pass ``filters`` (`TheoremIndex.subset`): for query batches, or a filter state that
+    stays put over many searches - each search then costs only the allowed rows and runs the batched MFMA path.
+    Its results carry the ids of ``index``."""
+    return index.subset(filter_mask(theorems_data, filters))
+
+
 def search_filtered(index, query_emb, theorems_data: Sequence[Mapping], filters: Mapping, mask: np.ndarray | None = None):
     """The filtered result list of the showcase app: ``[{"info": item, "similarity": cos}]``, best first,
     at most ``filters["top_k"]`` entries, exact over ALL rows that pass (not only a top-200 pool)."""

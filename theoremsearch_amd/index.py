@@ -68,6 +68,21 @@ class TheoremIndex:
         ix.upload(rows, 0)
         return ix
 
+    def subset(self, rows_or_mask) -> "TheoremIndex":
+        """A new index over a subset of this one's rows (bool mask of length n, or ascending global row ids).
+        Its searches return this index's ids: the filtered search for query batches / long-lived filters."""
+        a = np.asarray(rows_or_mask)
+        if a.dtype == bool:
+            if a.shape[0] != self.n:
+                raise ValueError(f"mask has {a.shape[0]} entries, index has {self.n} rows")
+            a = np.flatnonzero(a) + self.row_offset
+        ids = np.ascontiguousarray(a, dtype=np.int64).reshape(-1)
+        sub = object.__new__(TheoremIndex)
+        sub._lib, sub._h = self._lib, C.c_void_p()
+        sub.n, sub.d, sub.dtype, sub.metric, sub.device, sub.row_offset = int(ids.shape[0]), self.d, self.dtype, self.metric, self.device, 0
+        _ffi.check(self._lib.ts_index_subset(self._h, _ffi.as_ptr(ids), ids.shape[0], C.byref(sub._h)))
+        return sub
+
     def upload(self, rows, row0: int = 0) -> None:
         rows = _host_rows(rows)
         if rows.shape[1] != self.d:
