@@ -81,6 +81,8 @@ struct MfmaArgs {
     u64* cand;                     // [256][cap] shared spill lists
     u32* count;                    // [256]
     int cap;
+    int ahead;                     // units kept in flight by the DMA ring (1 .. kSlots - 1)
+    int nq;                        // real queries of this launch: waves / groups holding only padding skip the matrix work
     unsigned long long* dbg;       // VARIANT 3 only: per-wave cycle sums
 };
 
@@ -199,6 +201,10 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma_topk_kernel(MfmaArgs a) 
     const int nwriters = 2 * G;
     const int writer = 2 * blockIdx.x + h;
     const int qid_a = wave * 32 + r, qid_b = 128 + qid_a;
+    // small batches: a wave (or its second group) whose 32 queries are all padding keeps feeding the DMA ring and
+    // the barriers but issues no MFMAs and no fragment reads - the pass is power-bound, idle matrix work costs time
+    const bool idle_a = wave * 32 >= a.nq;
+    const bool idle_b = 128 + wave * 32 >= a.nq;  // second query group of this wave (GROUPS == 2)
 
     // this workgroup's contiguous share of the level's tiles (sequential pages: a round-robin deal of
     // tiles to workgroups measured 1.4x slower on the DMA stream)
@@ -273,7 +279,8 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma_topk_kernel(MfmaArgs a) 
     } while (0)
 
     // prologue: kSlots - 1 units in flight; unit 0 must have landed before its fragments are read
-    for (int i = 0; i < kSlots - 1 && issue_u < nu; ++i) {
+    const int ahead = (a.ahead >= 1 && a.ahead < kSlots) ? a.ahead : kSlots - 1;
+    for (int i = 0; i < ahead && issue_u < nu; ++i) {
         const unsigned char* src = tile_src + issue_ui * (kUnitK * 2);
 #pragma unroll
         for (int j = 0; j < kPieces; ++j) lds_dma16(src + j * 128, lds0 + issue_slot * kUnitBytes + j * 4096);
@@ -285,7 +292,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma_topk_kernel(MfmaArgs a) 
 
     bf16x8 af[kAhead];
 #pragma unroll
-    for (int s = 0; s < kAhead; ++s) af[s] = *(const bf16x8*)(smem + (s >> 2) * 4096 + xo[s & 3]);
+    for (int s = 0; s < kAhead; ++s) af[s] = *(const bf16x8*)(smem + (s >> 2) * 4096 + xo[s & 3]);  // (idle waves: unused)
 
     f32x16 acc_a, acc_b;
     u32 cnt_a = 0, cnt_b = 0;
@@ -295,7 +302,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma_topk_kernel(MfmaArgs a) 
     if (VARIANT == 3) t_begin = cycle_stamp();
 
     // One unit (compile-time index UI inside the tile, so that every qa/qb index is static).
-#define TS_UNIT(UI)                                                                                               \
+#define TS_UNIT(UI, IDLE, NOB)                                                                                            \
     do {                                                                                                          \
         const int nslot = (slot + 1 == kSlots) ? 0 : slot + 1;                                                    \
         const unsigned char* unit = smem + slot * kUnitBytes;                                                     \
@@ -317,18 +324,18 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma_topk_kernel(MfmaArgs a) 
         /* one A fragment feeds both query groups; the ring runs kAhead k-steps ahead and its tail already */     \
         /* fetches the head of unit u+1; the DMA pieces of the next unit to fetch go out between MFMAs */         \
         _Pragma("unroll") for (int s = 0; s < kUnitSteps; ++s) {                                                  \
-            if (VARIANT == 2) {                                                                                   \
+            if (VARIANT == 2 || (IDLE)) {                                                                         \
             } else if ((UI) == 0 && s == 0) {                                                                     \
                 mfma_av_first(acc_a, af[s % kAhead], qa[0]);                                                      \
-                if (GROUPS == 2) mfma_aa_first(acc_b, af[s % kAhead], qb[0]);                                     \
+                if (GROUPS == 2 && !(NOB)) mfma_aa_first(acc_b, af[s % kAhead], qb[0]);                           \
             } else {                                                                                              \
                 constexpr int ks_ = (UI) * kUnitSteps;                                                            \
                 if (ks_ + s < kAV) mfma_av(acc_a, af[s % kAhead], qa[ks_ + s < kAV ? ks_ + s : 0]);               \
                 else mfma_aa(acc_a, af[s % kAhead], qa_hi[ks_ + s >= kAV ? ks_ + s - kAV : 0]);                   \
-                if (GROUPS == 2) mfma_aa(acc_b, af[s % kAhead], qb[GROUPS == 2 ? ks_ + s : 0]);                   \
+                if (GROUPS == 2 && !(NOB)) mfma_aa(acc_b, af[s % kAhead], qb[GROUPS == 2 ? ks_ + s : 0]);         \
             }                                                                                                     \
             const int n = s + kAhead;                                                                             \
-            if (VARIANT == 2) {                                                                                   \
+            if (VARIANT == 2 || (IDLE)) {                                                                         \
             } else if (n < kUnitSteps)                                                                            \
                 af[s % kAhead] = *(const bf16x8*)(unit + (n >> 2) * 4096 + xo[n & 3]);                            \
             else                                                                                                  \
@@ -341,38 +348,57 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma_topk_kernel(MfmaArgs a) 
         ++u;                                                                                                      \
     } while (0)
 
-    for (int t = 0; t < nt; ++t) {
-        TS_UNIT(0);
-        TS_UNIT(1);
-        if (kUnits == 4) {
-            TS_UNIT(2 % kUnits);
-            TS_UNIT(3 % kUnits);
-        }
-        if (VARIANT == 2) continue;
-        if (GROUPS == 2) mfma_settle(acc_a, acc_b);
-        else mfma_settle(acc_a);
-        if (VARIANT == 1) {
-            if (GROUPS == 2) asm volatile("" ::"a"(acc_a), "a"(acc_b));
-            else asm volatile("" ::"a"(acc_a));
-            continue;
-        }
-        // lane holds rows (g & 3) + 8 (g >> 2) + 4 h of this tile for queries qid_a / qid_b
-        const bool hit_a = __any(max16(acc_a) >= thr_a);
-        bool hit_b = false;
-        if (GROUPS == 2) hit_b = __any(max16(acc_b) >= thr_b);
-        if (__builtin_expect(hit_a || hit_b, 0)) {
-            const int64_t lt = t0 + t;  // level tile -> global tile -> first row
-            const int64_t tile_row = ((lt / a.run) * a.run * a.tile_stride + lt % a.run) * kTileRows;
-            const int64_t row_base = tile_row + 4 * h;
-            if (tile_row + kTileRows <= a.n) {
-                if (hit_a) mfma_append<true>(acc_a, thr_a, qid_a, writer, nwriters, cnt_a, row_base, a);
-                if (GROUPS == 2 && hit_b) mfma_append<true>(acc_b, thr_b, qid_b, writer, nwriters, cnt_b, row_base, a);
-            } else {
-                if (hit_a) mfma_append<false>(acc_a, thr_a, qid_a, writer, nwriters, cnt_a, row_base, a);
-                if (GROUPS == 2 && hit_b) mfma_append<false>(acc_b, thr_b, qid_b, writer, nwriters, cnt_b, row_base, a);
-            }
-        }
+    // After the units of a tile: settle the accumulators and pass on what beats the thresholds.
+    // lane holds rows (g & 3) + 8 (g >> 2) + 4 h of this tile for queries qid_a / qid_b
+#define TS_TILE_END(NOB)                                                                                          \
+    do {                                                                                                          \
+        if (VARIANT == 2) break;                                                                                  \
+        if (GROUPS == 2 && !(NOB)) mfma_settle(acc_a, acc_b);                                                     \
+        else mfma_settle(acc_a);                                                                                  \
+        if (VARIANT == 1) {                                                                                       \
+            if (GROUPS == 2 && !(NOB)) asm volatile("" ::"a"(acc_a), "a"(acc_b));                                 \
+            else asm volatile("" ::"a"(acc_a));                                                                   \
+            break;                                                                                                \
+        }                                                                                                         \
+        const bool hit_a = __any(max16(acc_a) >= thr_a);                                                          \
+        bool hit_b = false;                                                                                       \
+        if (GROUPS == 2 && !(NOB)) hit_b = __any(max16(acc_b) >= thr_b);                                          \
+        if (__builtin_expect(hit_a || hit_b, 0)) {                                                                \
+            const int64_t lt = t0 + t; /* level tile -> global tile -> first row */                               \
+            const int64_t tile_row = ((lt / a.run) * a.run * a.tile_stride + lt % a.run) * kTileRows;             \
+            const int64_t row_base = tile_row + 4 * h;                                                            \
+            if (tile_row + kTileRows <= a.n) {                                                                    \
+                if (hit_a) mfma_append<true>(acc_a, thr_a, qid_a, writer, nwriters, cnt_a, row_base, a);          \
+                if (GROUPS == 2 && !(NOB) && hit_b) mfma_append<true>(acc_b, thr_b, qid_b, writer, nwriters, cnt_b, row_base, a);  \
+            } else {                                                                                              \
+                if (hit_a) mfma_append<false>(acc_a, thr_a, qid_a, writer, nwriters, cnt_a, row_base, a);         \
+                if (GROUPS == 2 && !(NOB) && hit_b) mfma_append<false>(acc_b, thr_b, qid_b, writer, nwriters, cnt_b, row_base, a); \
+            }                                                                                                     \
+        }                                                                                                         \
+    } while (0)
+
+#define TS_TILE_LOOP(IDLE, NOB)                      \
+    for (int t = 0; t < nt; ++t) {                   \
+        TS_UNIT(0, IDLE, NOB);                       \
+        TS_UNIT(1, IDLE, NOB);                       \
+        if (kUnits == 4) {                           \
+            TS_UNIT(2 % kUnits, IDLE, NOB);          \
+            TS_UNIT(3 % kUnits, IDLE, NOB);          \
+        }                                            \
+        if (!(IDLE)) TS_TILE_END(NOB);               \
     }
+
+    // Three copies of the loop, chosen once per wave, so that the loop of a full batch compiles exactly as it
+    // would alone (a runtime test inside the loop cost the full batch 30 %).
+    if (idle_a) {
+        TS_TILE_LOOP(1, 1)
+    } else if (GROUPS == 2 && idle_b) {
+        TS_TILE_LOOP(0, 1)
+    } else {
+        TS_TILE_LOOP(0, 0)
+    }
+#undef TS_TILE_LOOP
+#undef TS_TILE_END
 #undef TS_UNIT
 #undef TS_ISSUED
     a.pcount[(int64_t)qid_a * nwriters + writer] = cnt_a;

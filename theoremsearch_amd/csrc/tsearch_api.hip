@@ -699,6 +699,8 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         a.run = lv[i].run;
         a.q = (const unsigned short*)ix->qstore;
         a.thr = ix->thr;
+        a.nq = env_int("TS_MFMA_NO_IDLE", 0) ? 256 : nq;
+        a.ahead = env_int("TS_MFMA_AHEAD", 0);
         a.priv = ix->priv;
         a.pcount = ix->pcount;
         a.cand = ix->cand;
@@ -720,10 +722,12 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
             std::vector<unsigned long long> h((size_t)grid * 16);
             HIP_TRY(hipStreamSynchronize(st));
             HIP_TRY(hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost));
-            double tot = 0, vm = 0, bar = 0, units = 0;
-            for (int w = 0; w < grid * 4; ++w) { tot += h[w * 4]; vm += h[w * 4 + 1]; bar += h[w * 4 + 2]; units += h[w * 4 + 3]; }
-            fprintf(stderr, "[tsearch stamps] per unit: total %.0f cycles, vmcnt wait %.0f, barrier wait %.0f (units/wave %.0f)\n",
-                    tot / units, vm / units, bar / units, units / (grid * 4));
+            for (int wv = 0; wv < 4; ++wv) {  // by wave of the workgroup: with small batches the waves differ
+                double tot = 0, vm = 0, bar = 0, units = 0;
+                for (int w = wv; w < grid * 4; w += 4) { tot += h[w * 4]; vm += h[w * 4 + 1]; bar += h[w * 4 + 2]; units += h[w * 4 + 3]; }
+                fprintf(stderr, "[tsearch stamps] wave %d per unit: total %.0f cycles, vmcnt wait %.0f, barrier wait %.0f (units/wave %.0f)\n",
+                        wv, tot / units, vm / units, bar / units, units / grid);
+            }
         }
         LevelArgs l;
         memset(&l, 0, sizeof(l));
