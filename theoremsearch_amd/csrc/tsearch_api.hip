@@ -543,7 +543,10 @@ static int scan_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
     a.k = k;
     a.partial = ix->partial;
     a.row_mask = ix->active_mask;
-    const int qb = (nq >= 2 || qcount) ? 4 : 1;
+    // k > 64 keeps 4 keys per lane and query: on bf16 x 768 four queries at once need all 256 VGPRs, one wave per SIMD
+    // (measured 0.18 of the HBM rate against 0.8 for one query per pass); the other shapes keep two waves
+    const bool wide_k_one_wave = k > 64 && ix->dtype == TS_BF16 && ix->ld == 768;
+    const int qb = ((nq >= 2 || qcount) && !wide_k_one_wave) ? 4 : 1;
     hipEvent_t stop = qcount ? nullptr : prof_begin(ix, st, ix->n);  // the MFMA path's fall-back pass is not bracketed
     launch_scan<false>(ix, a, qb, st, grid);
     prof_end(stop, st);
@@ -797,7 +800,7 @@ static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_
     // The scan serves 4 queries per pass at the HBM rate; the MFMA path serves up to 256 per pass but its pass is
     // ~1.7x longer (matrix + HBM load drops the clock): a handful of queries is faster through the scan.
     if (use == TS_ALGO_AUTO)
-        use = (mfma_ok && ix->n >= env_int("TS_MFMA_MIN_ROWS", 16384) && nq > env_int("TS_SCAN_MAX_QUERIES", 4)) ? TS_ALGO_MFMA
+        use = (mfma_ok && ix->n >= env_int("TS_MFMA_MIN_ROWS", 16384) && nq > (k > 64 ? 1 : env_int("TS_SCAN_MAX_QUERIES", 4))) ? TS_ALGO_MFMA
                                                                                                           : TS_ALGO_SCAN;
     if (stats) stats->algo = use;
 

@@ -52,6 +52,9 @@ def main():
         mask = rng.random(n) < 0.1
         res = {
             "search_b1": timed(ix, lambda: ix.search(q1, 10, algo="scan")),
+            "search_b1_k200": timed(ix, lambda: ix.search(q1, 200, algo="scan")),
+            "search_b4_k200_scan": timed(ix, lambda: ix.search(q4, 200, algo="scan")),
+            "search_b4_k200_auto": timed(ix, lambda: ix.search(q4, 200)),
             "search_b1_mask10pct": timed(ix, lambda: ix.search(q1, 10, mask=mask)),
             "search_b4_mask10pct": timed(ix, lambda: ix.search(q4, 10, mask=mask)),
             "rank_of_b1": timed(ix, lambda: ix.rank_of(q1, [n // 3])),
