@@ -189,6 +189,12 @@ __device__ __forceinline__ void mfma_append(const f32x16& acc, float thr, int qi
 template <int D, int GROUPS, int VARIANT, bool SPARSE>
 __global__ void __launch_bounds__(kMfmaThreads, 1) mfma_topk_kernel(MfmaArgs a) {
     using dims = MfmaDims<D>;
+    // loop-attribution diagnostics (timing only): 4 = no epilogue, no barrier; 5 = no epilogue, no vmcnt wait;
+    // 6 = neither; 7 = no epilogue, no DMA at all (MFMA + LDS reads + barrier)
+    constexpr bool kNoEpi = VARIANT == 1 || (VARIANT >= 4 && VARIANT <= 7);
+    constexpr bool kNoBar = VARIANT == 4 || VARIANT == 6;
+    constexpr bool kNoVm = VARIANT == 5 || VARIANT == 6 || VARIANT == 7;
+    constexpr bool kNoDma = VARIANT == 7;
     constexpr int kKSteps = dims::kKSteps, kUnitSteps = dims::kUnitSteps, kUnits = dims::kUnits;
     constexpr int kUnitBytes = dims::kUnitBytes, kSlots = dims::kSlots, kPieces = dims::kPieces;
     constexpr int kAhead = dims::kAhead, kUnitK = dims::kUnitK;
@@ -280,7 +286,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma_topk_kernel(MfmaArgs a) 
 
     // prologue: kSlots - 1 units in flight; unit 0 must have landed before its fragments are read
     const int ahead = (a.ahead >= 1 && a.ahead < kSlots) ? a.ahead : kSlots - 1;
-    for (int i = 0; i < ahead && issue_u < nu; ++i) {
+    for (int i = 0; i < ahead && issue_u < nu && !kNoDma; ++i) {
         const unsigned char* src = tile_src + issue_ui * (kUnitK * 2);
 #pragma unroll
         for (int j = 0; j < kPieces; ++j) lds_dma16(src + j * 128, lds0 + issue_slot * kUnitBytes + j * 4096);
@@ -299,7 +305,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma_topk_kernel(MfmaArgs a) 
     int slot = 0;
     int u = 0;
     unsigned long long t_vm = 0, t_bar = 0, t_begin = 0;
-    if (VARIANT == 3) t_begin = cycle_stamp();
+    if (VARIANT >= 3) t_begin = cycle_stamp();
 
     // One unit (compile-time index UI inside the tile, so that every qa/qb index is static).
 #define TS_UNIT(UI, IDLE, NOB)                                                                                            \
@@ -310,15 +316,15 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma_topk_kernel(MfmaArgs a) 
         /* certify unit u+1 (own pieces, then everyone's); every wave is past unit u-1: its slot is free */       \
         unsigned long long ts0 = 0, ts1 = 0;                                                                      \
         if (VARIANT == 3) ts0 = cycle_stamp();                                                                    \
-        if (u + 1 < nu) wait_keep_units<kPieces>(issue_u - (u + 2));                                              \
+        if (u + 1 < nu && !kNoVm) wait_keep_units<kPieces>(issue_u - (u + 2));                                    \
         if (VARIANT == 3) ts1 = cycle_stamp();                                                                    \
-        __builtin_amdgcn_s_barrier();                                                                             \
+        if (!kNoBar) __builtin_amdgcn_s_barrier();                                                                \
         asm volatile("" ::: "memory");                                                                            \
         if (VARIANT == 3) {                                                                                       \
             t_vm += ts1 - ts0;                                                                                    \
             t_bar += cycle_stamp() - ts1;                                                                         \
         }                                                                                                         \
-        const bool do_issue = issue_u < nu;                                                                       \
+        const bool do_issue = issue_u < nu && !kNoDma;                                                            \
         const unsigned char* isrc = tile_src + issue_ui * (kUnitK * 2);                                           \
         const unsigned idst = lds0 + issue_slot * kUnitBytes;                                                     \
         /* one A fragment feeds both query groups; the ring runs kAhead k-steps ahead and its tail already */     \
@@ -355,7 +361,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma_topk_kernel(MfmaArgs a) 
         if (VARIANT == 2) break;                                                                                  \
         if (GROUPS == 2 && !(NOB)) mfma_settle(acc_a, acc_b);                                                     \
         else mfma_settle(acc_a);                                                                                  \
-        if (VARIANT == 1) {                                                                                       \
+        if (kNoEpi) {                                                                                             \
             if (GROUPS == 2 && !(NOB)) asm volatile("" ::"a"(acc_a), "a"(acc_b));                                 \
             else asm volatile("" ::"a"(acc_a));                                                                   \
             break;                                                                                                \
@@ -403,7 +409,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma_topk_kernel(MfmaArgs a) 
 #undef TS_ISSUED
     a.pcount[(int64_t)qid_a * nwriters + writer] = cnt_a;
     if (GROUPS == 2) a.pcount[(int64_t)qid_b * nwriters + writer] = cnt_b;
-    if (VARIANT == 3 && lane == 0 && a.dbg) {
+    if (VARIANT >= 3 && lane == 0 && a.dbg) {
         unsigned long long* d = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 4;
         d[0] = cycle_stamp() - t_begin;
         d[1] = t_vm;

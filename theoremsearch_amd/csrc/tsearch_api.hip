@@ -639,12 +639,20 @@ static int launch_mfma(bool full_pass, int variant, int grid, hipStream_t st, co
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<D, GROUPS, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<D, GROUPS, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<D, GROUPS, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<D, GROUPS, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<D, GROUPS, 5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<D, GROUPS, 6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<D, GROUPS, 7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done = true;
     }
     if (!full_pass) mfma_topk_kernel<D, GROUPS, 0, true><<<grid, kMfmaThreads, lds, st>>>(a);
     else if (variant == 1) mfma_topk_kernel<D, GROUPS, 1, false><<<grid, kMfmaThreads, lds, st>>>(a);
     else if (variant == 2) mfma_topk_kernel<D, GROUPS, 2, false><<<grid, kMfmaThreads, lds, st>>>(a);
     else if (variant == 3) mfma_topk_kernel<D, GROUPS, 3, false><<<grid, kMfmaThreads, lds, st>>>(a);
+    else if (variant == 4) mfma_topk_kernel<D, GROUPS, 4, false><<<grid, kMfmaThreads, lds, st>>>(a);
+    else if (variant == 5) mfma_topk_kernel<D, GROUPS, 5, false><<<grid, kMfmaThreads, lds, st>>>(a);
+    else if (variant == 6) mfma_topk_kernel<D, GROUPS, 6, false><<<grid, kMfmaThreads, lds, st>>>(a);
+    else if (variant == 7) mfma_topk_kernel<D, GROUPS, 7, false><<<grid, kMfmaThreads, lds, st>>>(a);
     else mfma_topk_kernel<D, GROUPS, 0, false><<<grid, kMfmaThreads, lds, st>>>(a);
     HIP_TRY(hipGetLastError());
     return TS_OK;
@@ -710,7 +718,7 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         a.count = ix->count;
         a.cap = kCandCap;
         a.dbg = nullptr;
-        if (variant == 3) {
+        if (variant >= 3) {
             if (!g_dbg) HIP_TRY(hipMalloc((void**)&g_dbg, 2048 * 4 * 4 * 8));
             a.dbg = g_dbg;
         }
