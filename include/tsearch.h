@@ -117,6 +117,15 @@ int ts_search_ex(ts_index *ix, const void *queries, int q_dtype, int q_on_device
                  float *out_scores, int64_t *out_idx, int out_on_device, void *stream, int algo,
                  ts_search_stats *stats);
 
+/* Parses pgvector's text form of vectors - "[0.1,-2e-3,...]", one per row, whatever stands between the rows (ids, tabs,
+ * newlines: the output of COPY (SELECT slogan_id, embedding ...) TO STDOUT or of SELECT embedding::text) - into a dense
+ * fp32 matrix, each value by one strtof as pgvector's own vector_in does.  Feeds ts_index_upload from the RDS tables
+ * the upsert pipeline fills (ec2/generate_embeddings/embeddings.py:27-40 sends embedding.tolist(); rds_schema.sql
+ * embedding_* tables) without a Python float per value.  Stops after max_rows rows or at the last complete row of the
+ * buffer; *consumed = bytes up to the end of that row, so a stream can be fed in pieces.  Host only, no device. */
+int ts_parse_pgvector_text(const char *text, int64_t len, int32_t d, float *out, int64_t max_rows, int64_t *rows_parsed,
+                           int64_t *consumed);
+
 /* A second index holding copies of the given rows of `src` (global ids, strictly ascending, host memory); searches
  * of it return the ORIGINAL global ids, in the same canonical order.  The filtered search for query batches and for
  * filters that stay fixed over many searches (a sidebar state, app_showcase_model.py:96-129; the WHERE clause of

@@ -155,3 +155,32 @@ def test_partition_and_pool():
         assert all(a[1] == b[0] for a, b in zip(cuts[:-1], cuts[1:]))
         assert max(hi - lo for lo, hi in cuts) - min(hi - lo for lo, hi in cuts) <= 1
     assert pgvector.pool_size(3) == 50 and pgvector.pool_size(20) == 200
+
+
+def test_pgvector_text_rows_parse_like_vector_in():
+    """ts_parse_pgvector_text (host code of libtsearch): COPY-style rows -> fp32 matrix, one strtof per value; rows cut
+    by the end of a chunk are left for the next call; malformed rows raise."""
+    from theoremsearch_amd import TSearchError
+    rng = np.random.default_rng(0)
+    m = rng.standard_normal((37, 12)).astype(np.float32)
+    m[0, 0], m[1, 1], m[2, 2], m[3, 3] = 1e-30, -3.5e12, 0.0, 16777217.0
+    txt = "".join(f"{100 + i}\t[{', '.join(repr(float(v)) for v in row)}]\n" for i, row in enumerate(m))
+    out, used = pgvector.parse_vectors(txt, 12)
+    assert out.dtype == np.float32 and np.array_equal(out, m) and used == len(txt) - 1
+    # fed in pieces that cut rows anywhere
+    got, tail = [], b""
+    raw = txt.encode()
+    for lo in range(0, len(raw), 97):
+        buf = tail + raw[lo:lo + 97]
+        rows, used = pgvector.parse_vectors(buf, 12)
+        got.append(rows)
+        tail = buf[used:]
+    assert np.array_equal(np.concatenate(got), m)
+    # max_rows, exponent forms, no spaces
+    two, _ = pgvector.parse_vectors("[1,2e0,-3E-1][4,5,6][7,8,9]", 3, max_rows=2)
+    assert np.array_equal(two, np.array([[1, 2, -0.3], [4, 5, 6]], np.float32))
+    for bad in ("[1,2]", "[1,2,3,4]", "[1,x,3]"):
+        with pytest.raises(TSearchError):
+            pgvector.parse_vectors(bad, 3)
+    empty, used = pgvector.parse_vectors("no vectors here", 3)
+    assert empty.shape == (0, 3) and used == 0

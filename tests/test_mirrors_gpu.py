@@ -214,3 +214,45 @@ def test_sharded_hip_search_two_ranks():
     ret = mgr.dict()
     mp.spawn(_gpu_rank, args=(2, _free_port(), ret), nprocs=2, join=True)
     assert dict(ret) == {0: 1.0, 1: 1.0}
+
+
+def test_index_from_a_pgvector_copy_stream_searches_like_the_matrix():
+    """COPY-text rows -> index (pgvector.index_from_copy_stream) answers exactly like an index built from the matrix."""
+    import theoremsearch_amd as ts
+    from theoremsearch_amd import pgvector
+    n, d = 3000, 768
+    q, c = oracle.golden_inputs(n, 3, d, 17, "ip")
+    txt = "".join(f"{i}\t[{','.join(repr(float(v)) for v in row)}]\n" for i, row in enumerate(c)).encode()
+    chunks = [txt[lo:lo + 1_000_003] for lo in range(0, len(txt), 1_000_003)]
+    with pgvector.index_from_copy_stream(chunks, n, d) as ix, ts.TheoremIndex.from_embeddings(c, metric="ip") as ref:
+        assert np.array_equal(ix.download(), ref.download())
+        s1, i1 = ix.search(q, 10)
+        s2, i2 = ref.search(q, 10)
+        assert np.array_equal(i1, i2) and np.array_equal(s1, s2)
+
+
+def test_two_threads_share_one_index():
+    """a handle is thread-safe (internal mutex; ctypes releases the GIL)."""
+    import threading
+    import theoremsearch_amd as ts
+    n, d = 40000, 768
+    q, c = oracle.golden_inputs(n, 64, d, 23, "cos")
+    with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="cos") as ix:
+        want = [ix.search(q[:1], 10), ix.search(q, 10)]
+        errors = []
+
+        def worker(kind):
+            try:
+                for _ in range(25):
+                    s, i = ix.search(q[:1], 10) if kind == 0 else ix.search(q, 10)
+                    if not (np.array_equal(i, want[kind][1]) and np.array_equal(s, want[kind][0])):
+                        errors.append(kind)
+            except Exception as e:  # noqa: BLE001
+                errors.append(repr(e))
+
+        threads = [threading.Thread(target=worker, args=(k,)) for k in (0, 1, 0, 1)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors

@@ -910,6 +910,43 @@ static void launch_rank(const ts_index* ix, const RankArgs& a, hipStream_t st, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// ingestion: pgvector text rows (host code, no device)
+// ---------------------------------------------------------------------------------------------
+extern "C" int ts_parse_pgvector_text(const char* text, int64_t len, int32_t d, float* out, int64_t max_rows, int64_t* rows_parsed,
+                                      int64_t* consumed) {
+    if (!text || !out || !rows_parsed || len < 0 || d <= 0 || max_rows < 0) return fail(TS_ERR_INVALID, "bad argument");
+    int64_t pos = 0, rows = 0, done = 0;
+    char tok[64];
+    while (rows < max_rows) {
+        while (pos < len && text[pos] != '[') ++pos;  // anything before the bracket (ids, tabs, quotes, newlines) is skipped
+        if (pos >= len) break;
+        int64_t p = pos + 1;
+        int col = 0;
+        bool closed = false;
+        while (p < len) {
+            while (p < len && (text[p] == ' ' || text[p] == ',')) ++p;
+            if (p < len && text[p] == ']') { closed = true; ++p; break; }
+            int t = 0;
+            while (p < len && text[p] != ',' && text[p] != ']' && text[p] != ' ' && t < 63) tok[t++] = text[p++];
+            if (p >= len) break;  // value cut off by the end of the buffer: the caller resumes at `consumed`
+            tok[t] = 0;
+            char* end = nullptr;
+            const float v = strtof(tok, &end);  // what pgvector's vector_in does: one correctly rounded fp32 conversion
+            if (end == tok || *end != 0) return fail(TS_ERR_INVALID, "row %lld: cannot parse '%s'", (long long)rows, tok);
+            if (col >= d) return fail(TS_ERR_INVALID, "row %lld has more than %d values", (long long)rows, d);
+            out[rows * d + col++] = v;
+        }
+        if (!closed) break;  // incomplete row at the end of the buffer
+        if (col != d) return fail(TS_ERR_INVALID, "row %lld has %d values, expected %d", (long long)rows, col, d);
+        ++rows;
+        pos = done = p;
+    }
+    *rows_parsed = rows;
+    if (consumed) *consumed = done;
+    return TS_OK;
+}
+
 extern "C" int ts_rank_of(ts_index* ix, const void* queries, int q_dtype, int q_on_device, int32_t nq, const int64_t* target_rows,
                           int64_t* out_rank, float* out_score, void* stream) {
     if (!ix || !queries || !target_rows || !out_rank) return fail(TS_ERR_INVALID, "NULL argument");

@@ -16,6 +16,41 @@ import numpy as np
 from .index import TheoremIndex
 
 
+def parse_vectors(text, d: int, max_rows: Optional[int] = None):
+    """pgvector text rows (``[v1,v2,...]``, anything in between: ids, tabs, newlines) -> ``(fp32 [rows x d], bytes
+    consumed)``.  ``text``: bytes or str, e.g. a chunk of ``COPY (SELECT slogan_id, embedding FROM ...) TO STDOUT``;
+    a row cut off by the end of the chunk is left for the next call (resume at ``consumed``)."""
+    import ctypes as C
+
+    from . import _ffi
+    buf = text.encode() if isinstance(text, str) else bytes(text)
+    cap = buf.count(b"[") if max_rows is None else int(max_rows)
+    out = np.empty((cap, int(d)), dtype=np.float32)
+    rows, used = C.c_int64(0), C.c_int64(0)
+    _ffi.check(_ffi.load().ts_parse_pgvector_text(buf, len(buf), int(d), _ffi.as_ptr(out), cap, C.byref(rows), C.byref(used)))
+    return out[: rows.value], used.value
+
+
+def index_from_copy_stream(chunks, n: int, d: int, dtype: str = "f32", metric: str = "ip", device: int = 0) -> TheoremIndex:
+    """Build an index of ``n`` rows from an iterable of text chunks of a pgvector COPY / SELECT stream (chunks may cut
+    rows anywhere).  ``metric="ip"`` stores the rows as given - the RDS tables hold normalised vectors
+    (ec2/generate_embeddings/embeddings.py:27,35) and the app ranks by ``<#>``."""
+    ix = TheoremIndex(n, d, dtype=dtype, metric=metric, device=device)
+    row0, tail = 0, b""
+    for chunk in chunks:
+        buf = tail + (chunk.encode() if isinstance(chunk, str) else bytes(chunk))
+        rows, used = parse_vectors(buf, d)
+        if rows.shape[0]:
+            if row0 + rows.shape[0] > n:
+                raise ValueError(f"the stream holds more than n = {n} vectors")
+            ix.upload(rows, row0)
+            row0 += rows.shape[0]
+        tail = buf[used:]
+    if row0 != n:
+        raise ValueError(f"the stream held {row0} vectors, expected {n}")
+    return ix
+
+
 def pool_size(top_k: int) -> int:
     return max(50, int(top_k) * 10)  # streamlit_app.py:317
 
