@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--dim", type=int, default=768, help="embedding dimension (diagnostic; BASELINE configs use 768)")
     ap.add_argument("--seq-len", type=int, default=32, help="c5: tokens per synthetic query")
     ap.add_argument("--force-dist", action="store_true", help="debug: run the exchange + merge path even with one rank")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal of the N > 1 path on a one-GPU box: every rank uses device 0, exchange over gloo "
+                         "through host memory (timings meaningless)")
     ap.add_argument("--mask-frac", type=float, default=0.0,
                     help="diagnostic: filtered search with this fraction of rows allowed (device bitmask)")
     ap.add_argument("--zero-queries", action="store_true", help="diagnostic: all-zero queries (power probe)")
@@ -91,11 +94,16 @@ def main():
 
     if _ffi.device_count() <= 0:
         raise SystemExit("bench.py needs a HIP device (libtsearch has no CPU path)")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.share_gpu:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     rows_total, dtype, nq = WORKLOADS[args.workload]
     if args.rows:
@@ -195,7 +203,13 @@ def main():
             ev_search[b].record(main)
             with torch.cuda.stream(side):
                 side.wait_event(ev_search[b])
-                dist.all_gather_into_tensor(gat[b], res[b])          # ONE collective: 12 * nq * K bytes per rank
+                if args.share_gpu:                                   # rehearsal: gloo moves host memory
+                    side.synchronize()
+                    host = torch.empty(gat[b].shape, dtype=gat[b].dtype)
+                    dist.all_gather_into_tensor(host, res[b].cpu())
+                    gat[b].copy_(host)
+                else:
+                    dist.all_gather_into_tensor(gat[b], res[b])      # ONE collective: 12 * nq * K bytes per rank
                 _ffi.check(lib.ts_merge_topk_packed(local_rank, C.c_void_p(gat[b].data_ptr()), blk, idx_off, world, nq,
                                                     K, K, C.c_void_p(fin_s[b].data_ptr()), C.c_void_p(fin_i[b].data_ptr()),
                                                     C.c_void_p(side.cuda_stream)))
@@ -327,7 +341,7 @@ def main():
                                    f"(BASELINE.json configs[{ {'c2': 1, 'c3': 2, 'c4': 3, 'c5': 4}[args.workload] }])" + (f", encoder forward in the loop ({args.seq_len} tokens/query, random-init BERT-base shape)" if encoder is not None else ""),
                        "rows": rows_total, "dim": D, "batch": nq, "k": K,
                        **({"mask_frac": args.mask_frac} if args.mask_frac > 0 else {}),
-                       "parallelism": f"corpus row-sharded x{world}" + (", RCCL all-gather of per-shard top-k" if use_dist else "")},
+                       "parallelism": f"corpus row-sharded x{world}" + ((", gloo rehearsal on one GPU" if args.share_gpu else ", RCCL all-gather of per-shard top-k") if use_dist else "")},
             "recall_at_10": recall,
             "roofline": roofline,
             "cpu_baseline": cpu,
