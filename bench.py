@@ -182,9 +182,8 @@ def main():
 
     def encode_queries():
         with torch.inference_mode():
-            hidden = encoder.model(input_ids=tok_ids, attention_mask=tok_mask).last_hidden_state.float()
-            emb = hidden.mean(dim=1)
-            return torch.nn.functional.normalize(emb, p=2, dim=1).contiguous()
+            hidden = encoder.model(input_ids=tok_ids, attention_mask=tok_mask).last_hidden_state
+            return encoder.pool(hidden, tok_mask, True)       # fused mean-pool + L2 normalise (ts_pool_normalize)
 
     def step():
         i = step_no[0]
