@@ -153,6 +153,13 @@ int ts_search_filtered(ts_index *ix, const void *queries, int q_dtype, int q_on_
 int ts_rank_of(ts_index *ix, const void *queries, int q_dtype, int q_on_device, int32_t nq, const int64_t *target_rows,
                int64_t *out_rank, float *out_score, void *stream);
 
+/* The sharded form of ts_rank_of: how many rows of THIS index rank before a document with the given score and global id
+ * (score descending, global id ascending), wherever that document lives.  The shard that holds the document gets its
+ * score from ts_rank_of; the sum of ts_count_above over all shards is the document's rank in the whole corpus (the
+ * document itself never counts).  out_counts[i] = -1 for a NaN score.  Host pointers. */
+int ts_count_above(ts_index *ix, const void *queries, int q_dtype, int q_on_device, int32_t nq, const float *target_scores,
+                   const int64_t *target_ids, int64_t *out_counts, void *stream);
+
 /* Full [nq x n] fp32 score matrix (small N only): util.cos_sim(q_emb, s_emb) of
  * compare_embeddings.py:24,61.  out row stride is n. */
 int ts_scores(ts_index *ix, const void *queries, int q_dtype, int q_on_device, int32_t nq,

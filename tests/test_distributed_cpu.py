@@ -63,3 +63,52 @@ def test_sharded_search_two_gloo_ranks(n, nq, k):
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), n, nq, k, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+def _rank_worker(rank, world, port, n, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from theoremsearch_amd.distributed import ShardedSearcher, shard_bounds
+        nq = 7
+        q, c = oracle.golden_inputs(n, nq, 64, 321, "ip")
+        c[5] = c[n - 2]                     # an exact tie across the two shards: the lower global id ranks first
+        lo, hi = shard_bounds(n, world, rank)
+        truth = oracle.scores_fp64(q, c)
+        s32 = truth.astype(np.float32)      # the "kernel" scores of this stand-in
+
+        def local_rank_of(queries, rows):
+            ranks = np.full(len(rows), -1, np.int64)
+            scores = np.full(len(rows), np.nan, np.float32)
+            for i, r in enumerate(rows):
+                if lo <= r < hi:
+                    ranks[i] = oracle.rank_of(s32[i:i + 1, lo:hi], [r - lo])[0]
+                    scores[i] = s32[i, r]
+            return ranks, scores
+
+        def local_count_above(queries, sc, ids):
+            # queries arrive filtered: recover which ones by matching rows of q
+            out = np.empty(len(ids), np.int64)
+            for j, (qq, t, gid) in enumerate(zip(queries, sc, ids)):
+                i = int(np.flatnonzero((q == qq).all(axis=1))[0])
+                loc = s32[i, lo:hi]
+                gids = np.arange(lo, hi)
+                out[j] = int(np.sum((loc > t) | ((loc == t) & (gids < gid))))
+            return out
+
+        searcher = ShardedSearcher(lambda *_: None)
+        rows = np.array([0, n - 1, 5, n - 2, n // 2, n // 2 - 1, n + 3])
+        got = searcher.rank_of(q, rows, local_rank_of=local_rank_of, local_count_above=local_count_above)
+        want = oracle.rank_of(s32, rows)
+        ret[rank] = bool(np.array_equal(got, want)) and got[-1] == -1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_rank_of_two_gloo_ranks():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rank_worker, args=(world, _free_port(), 501, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}

@@ -391,6 +391,37 @@ def test_rank_of_matches_position_in_the_full_ranking(ts, dtype, d, n):
         assert ranks[0] == 0 and ranks[1] == n - 1 and ranks[2] == 7
 
 
+def test_count_above_summed_over_shards_is_the_rank(ts):
+    """ts_count_above: per-shard counts of rows that rank before (score, global id) add up to ts_rank_of of the whole
+    index - including an exact tie that straddles the shard boundary."""
+    n, d, nq = 9001, 768, 6
+    q, c = oracle.golden_inputs(n, nq, d, 61, "cos")
+    c[10] = c[n - 3]                                   # duplicate rows on different shards
+    rows = np.array([10, n - 3, 0, n - 1, 4500, 4499])
+    cuts = [0, 3000, 4500, n]
+    with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="cos") as whole:
+        want, want_scores = whole.rank_of(q, rows)
+        shards = [ts.TheoremIndex.from_embeddings(c[a:b], dtype="bf16", metric="cos", row_offset=a) for a, b in zip(cuts, cuts[1:])]
+        try:
+            total = np.zeros(nq, np.int64)
+            for sh in shards:
+                cnt = sh.count_above(q, want_scores, rows)
+                assert (cnt >= 0).all()
+                total += cnt
+            assert np.array_equal(total, want)
+            # one query, both copies of the duplicated row: the higher id ranks directly behind the lower one
+            q2 = np.repeat(q[:1], 2, axis=0)
+            r2, s2 = whole.rank_of(q2, [10, n - 3])
+            assert s2[0] == s2[1] and r2[1] == r2[0] + 1
+            t2 = sum(sh.count_above(q2, s2, [10, n - 3]) for sh in shards)
+            assert np.array_equal(t2, r2)
+            nan_cnt = shards[0].count_above(q[:1], [np.nan], [5])
+            assert nan_cnt[0] == -1
+        finally:
+            for sh in shards:
+                sh.close()
+
+
 def test_metrics_from_the_index_equal_metrics_from_the_matrix(ts):
     """IndexRanking (top-k searches + counting pass) through the six metric functions = the same functions on the
     full similarity matrix (the reference's formulation, compare_embeddings.py:55-371)."""

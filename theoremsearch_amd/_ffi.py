@@ -63,6 +63,8 @@ _SIGNATURES = {
                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ts_rank_of": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p]),
+    "ts_count_above": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p]),
     "ts_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_void_p, C.c_int, C.c_void_p]),
     "ts_merge_topk": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                 C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

@@ -251,6 +251,8 @@ struct RankArgs {
     const float* qbuf;            // prepared queries, fp32 [nq x ld]
     int nq;
     const int64_t* target;        // [nq] local row of each query's document; outside [0, n) = none
+    const u64* tkey;              // optional [nq]: ready-made target keys (a document that lives on another shard);
+                                  // `target` is not read then
     unsigned long long* counts;   // [nq] zeroed by the host; += rows ranked strictly before the target
     float* tscore;                // [nq] score of the target row (NaN when there is none)
 };
@@ -285,6 +287,11 @@ __global__ void __launch_bounds__(256) rank_kernel(RankArgs a) {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) qv[q][c][e] = a.qbuf[(int64_t)qid[q] * a.ld + (int64_t)(gl + c * G) * VEC + e];
             // key of the target row: its 4-row block goes through the same arithmetic as the pass below
+            cnt[q] = 0;
+            if (a.tkey) {  // uniform over the grid
+                gkey[q] = a.tkey[qid[q]];
+                continue;
+            }
             const int64_t t = a.target[qid[q]];
             const bool has = t >= 0 && t < a.n;
             const int64_t tb = has ? (t & ~(int64_t)3) : 0;
@@ -300,7 +307,6 @@ __global__ void __launch_bounds__(256) rank_kernel(RankArgs a) {
             const int tr = (int)(t & 3);
             const float st = __shfl(s4, ((tr & 2) ? G / 2 : 0) + ((tr & 1) ? G / 4 : 0), 64);
             gkey[q] = (has && st == st) ? make_key(st, (u32)t) : ~0ull;
-            cnt[q] = 0;
             if (gw == 0 && lane == 0 && g0 + q < a.nq) a.tscore[qid[q]] = (has ? st : __uint_as_float(0x7FC00000u));
         }
         for (int64_t blk = gw; blk < nblocks; blk += W) {
@@ -370,13 +376,18 @@ __global__ void __launch_bounds__(256) rank_generic_kernel(RankArgs a) {
         __syncthreads();
         for (int i = threadIdx.x; i < a.ld; i += blockDim.x) lds_q[i] = a.qbuf[(int64_t)qid * a.ld + i];
         __syncthreads();
-        const int64_t t = a.target[qid];
-        const bool has = t >= 0 && t < a.n;
-        const float s4 = block_score(has ? (t & ~(int64_t)3) : 0);
-        const int tr = (int)(t & 3);
-        const float st = __shfl(s4, ((tr & 2) ? 32 : 0) + ((tr & 1) ? 16 : 0), 64);
-        const u64 gkey = (has && st == st) ? make_key(st, (u32)t) : ~0ull;
-        if (gw == 0 && lane == 0) a.tscore[qid] = has ? st : __uint_as_float(0x7FC00000u);
+        u64 gkey;
+        if (a.tkey) {
+            gkey = a.tkey[qid];
+        } else {
+            const int64_t t = a.target[qid];
+            const bool has = t >= 0 && t < a.n;
+            const float s4 = block_score(has ? (t & ~(int64_t)3) : 0);
+            const int tr = (int)(t & 3);
+            const float st = __shfl(s4, ((tr & 2) ? 32 : 0) + ((tr & 1) ? 16 : 0), 64);
+            gkey = (has && st == st) ? make_key(st, (u32)t) : ~0ull;
+            if (gw == 0 && lane == 0) a.tscore[qid] = has ? st : __uint_as_float(0x7FC00000u);
+        }
         unsigned int cnt = 0;
         for (int64_t blk = gw; blk < nblocks; blk += W) {
             const int64_t row0 = blk * RW;

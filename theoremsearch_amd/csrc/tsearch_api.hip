@@ -947,20 +947,30 @@ extern "C" int ts_parse_pgvector_text(const char* text, int64_t len, int32_t d, 
     return TS_OK;
 }
 
-extern "C" int ts_rank_of(ts_index* ix, const void* queries, int q_dtype, int q_on_device, int32_t nq, const int64_t* target_rows,
-                          int64_t* out_rank, float* out_score, void* stream) {
-    if (!ix || !queries || !target_rows || !out_rank) return fail(TS_ERR_INVALID, "NULL argument");
+// host twin of ord_f32 (common.h): the score half of a key
+static u32 host_ord_f32(float s) {
+    s = s + 0.0f;
+    u32 u;
+    memcpy(&u, &s, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// target_rows != NULL: rank of that row (its score is computed by the kernel);  otherwise target_scores / target_ids:
+// number of rows of THIS index that rank before a document with that score and global id (it may live on another shard).
+static int rank_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_device, int32_t nq, const int64_t* target_rows,
+                     const float* target_scores, const int64_t* target_ids, int64_t* out_rank, float* out_score, void* stream) {
+    if (!ix || !queries || !out_rank) return fail(TS_ERR_INVALID, "NULL argument");
     if (q_dtype != TS_F32 && q_dtype != TS_BF16) return fail(TS_ERR_INVALID, "q_dtype %d", q_dtype);
     if (nq < 0) return fail(TS_ERR_INVALID, "nq = %d", nq);
     if (nq == 0) return TS_OK;
-    if (ix->id_map) return fail(TS_ERR_UNSUPPORTED, "ts_rank_of on a subset index");
+    if (ix->id_map) return fail(TS_ERR_UNSUPPORTED, "rank / count on a subset index");
     std::lock_guard<std::mutex> lock(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
     TS_TRY(ensure_search_scratch(ix, 1));
     constexpr size_t kPer = 8 + 8 + 4;
     TS_TRY(ensure(&ix->rank_buf, &ix->rank_bytes, (size_t)kQBlock * kPer));
-    int64_t* d_target = (int64_t*)ix->rank_buf;
+    int64_t* d_target = (int64_t*)ix->rank_buf;  // rows, or ready-made keys
     unsigned long long* d_counts = (unsigned long long*)(d_target + kQBlock);
     float* d_tscore = (float*)(d_counts + kQBlock);
     const size_t q_elem = q_dtype == TS_BF16 ? 2 : 4;
@@ -978,8 +988,17 @@ extern "C" int ts_rank_of(ts_index* ix, const void* queries, int q_dtype, int q_
         TS_TRY(prep_dispatch(q_dtype, ix->dtype, ix->metric == TS_METRIC_COS, qsrc, ix->d, ix->qstore, ix->qf32, ix->ld, ix->d, nb,
                              kQBlock, st));
         for (int i = 0; i < nb; ++i) {
-            const int64_t r = target_rows[q0 + i] - ix->row_offset;
-            local[i] = (r >= 0 && r < ix->n) ? r : -1;
+            if (target_rows) {
+                const int64_t r = target_rows[q0 + i] - ix->row_offset;
+                local[i] = (r >= 0 && r < ix->n) ? r : -1;
+            } else {
+                // key of (score, global id) in this shard's key space: a document before the shard loses every tie
+                // (low word all ones), one behind it wins every tie (low word zero)
+                const float sc = target_scores[q0 + i];
+                const int64_t r = target_ids[q0 + i] - ix->row_offset;
+                const u64 low = r < 0 ? 0xFFFFFFFFull : (r >= ix->n ? 0ull : (u64)(0xFFFFFFFFu - (u32)r));
+                local[i] = (sc == sc) ? (int64_t)(((u64)host_ord_f32(sc) << 32) | low) : -1;  // NaN: all ones, nothing counts
+            }
         }
         HIP_TRY(hipMemcpyAsync(d_target, local.data(), (size_t)nb * 8, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)nb * 8, st));
@@ -991,6 +1010,7 @@ extern "C" int ts_rank_of(ts_index* ix, const void* queries, int q_dtype, int q_
         a.qbuf = ix->qf32;
         a.nq = nb;
         a.target = d_target;
+        a.tkey = target_rows ? nullptr : (const u64*)d_target;
         a.counts = d_counts;
         a.tscore = d_tscore;
         hipEvent_t stop = prof_begin(ix, st, ix->n);
@@ -998,15 +1018,31 @@ extern "C" int ts_rank_of(ts_index* ix, const void* queries, int q_dtype, int q_
         prof_end(stop, st);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, (size_t)nb * 8, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(tscore.data(), d_tscore, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
+        if (target_rows) HIP_TRY(hipMemcpyAsync(tscore.data(), d_tscore, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));  // `local` is reused by the next block
         for (int i = 0; i < nb; ++i) {
-            const bool ok = local[i] >= 0 && tscore[i] == tscore[i];
-            out_rank[q0 + i] = ok ? (int64_t)counts[i] : -1;
-            if (out_score) out_score[q0 + i] = tscore[i];
+            if (target_rows) {
+                const bool ok = local[i] >= 0 && tscore[i] == tscore[i];
+                out_rank[q0 + i] = ok ? (int64_t)counts[i] : -1;
+                if (out_score) out_score[q0 + i] = tscore[i];
+            } else {
+                out_rank[q0 + i] = (target_scores[q0 + i] == target_scores[q0 + i]) ? (int64_t)counts[i] : -1;
+            }
         }
     }
     return TS_OK;
+}
+
+extern "C" int ts_rank_of(ts_index* ix, const void* queries, int q_dtype, int q_on_device, int32_t nq, const int64_t* target_rows,
+                          int64_t* out_rank, float* out_score, void* stream) {
+    if (!target_rows) return fail(TS_ERR_INVALID, "target_rows is NULL");
+    return rank_impl(ix, queries, q_dtype, q_on_device, nq, target_rows, nullptr, nullptr, out_rank, out_score, stream);
+}
+
+extern "C" int ts_count_above(ts_index* ix, const void* queries, int q_dtype, int q_on_device, int32_t nq, const float* target_scores,
+                              const int64_t* target_ids, int64_t* out_counts, void* stream) {
+    if (!target_scores || !target_ids) return fail(TS_ERR_INVALID, "NULL argument");
+    return rank_impl(ix, queries, q_dtype, q_on_device, nq, nullptr, target_scores, target_ids, out_counts, nullptr, stream);
 }
 
 extern "C" int ts_scores(ts_index* ix, const void* queries, int q_dtype, int q_on_device, int32_t nq, float* out,

@@ -73,3 +73,33 @@ class ShardedSearcher:
         all_scores = g[..., 0].astype(np.int32).view(np.float32)
         all_idx = np.ascontiguousarray(g[..., 1])
         return self.merge(np.ascontiguousarray(all_scores), all_idx, k)
+
+    def rank_of(self, queries: np.ndarray, rows, local_rank_of=None, local_count_above=None) -> np.ndarray:
+        """Rank of global row ``rows[i]`` for query ``i`` over the WHOLE sharded corpus (0 = best; -1 = no such row):
+        the owning shard scores the row (`TheoremIndex.rank_of`), one all-reduce (max) makes the scores known to every
+        rank, every other shard counts its rows that rank before ``(score, row)`` (`count_above`), one all-reduce
+        (sum) adds the counts.  The two callables default to this rank's index; they can be injected for CPU tests."""
+        import torch
+        ix = getattr(self, "index", None)
+        local_rank_of = local_rank_of or (lambda q, r: ix.rank_of(q, r))
+        local_count_above = local_count_above or (lambda q, s, r: ix.count_above(q, s, r))
+        rows = np.asarray(rows, dtype=np.int64).reshape(-1)
+        ranks, scores = local_rank_of(queries, rows)
+        if self.world == 1:
+            return ranks
+        dev = "cuda" if self.dist.get_backend(self.group) == "nccl" else "cpu"
+        mine = ranks >= 0
+        sc = torch.from_numpy(np.where(mine, scores, -np.inf).astype(np.float32)).to(dev)
+        self.dist.all_reduce(sc, op=self.dist.ReduceOp.MAX, group=self.group)  # exactly one shard owns each row
+        sc_host = sc.cpu().numpy()
+        known = np.isfinite(sc_host)
+        counts = np.where(mine, ranks, 0).astype(np.int64)
+        others = known & ~mine
+        if others.any():
+            c = local_count_above(queries[others], sc_host[others], rows[others])
+            counts[others] = c
+        total = torch.from_numpy(counts).to(dev)
+        self.dist.all_reduce(total, op=self.dist.ReduceOp.SUM, group=self.group)
+        out = total.cpu().numpy()
+        out[~known] = -1
+        return out

@@ -177,6 +177,21 @@ class TheoremIndex:
                                         _ffi.as_ptr(ranks), _ffi.as_ptr(scores), None))
         return ranks, scores
 
+    def count_above(self, queries, target_scores, target_ids) -> np.ndarray:
+        """Rows of this index that rank before a document with the given score and GLOBAL id (it may live on another
+        shard); summed over the shards of a corpus this is the document's rank (`rank_of` for one index)."""
+        q = _host_rows(queries)
+        if q.shape[1] != self.d:
+            raise ValueError(f"queries have d={q.shape[1]}, index has d={self.d}")
+        sc = np.ascontiguousarray(np.asarray(target_scores, dtype=np.float32).reshape(-1))
+        ids = np.ascontiguousarray(np.asarray(target_ids, dtype=np.int64).reshape(-1))
+        if sc.shape[0] != q.shape[0] or ids.shape[0] != q.shape[0]:
+            raise ValueError("one target per query")
+        out = np.empty(q.shape[0], dtype=np.int64)
+        _ffi.check(self._lib.ts_count_above(self._h, _ffi.as_ptr(q), _ffi.np_dtype_code(q), 0, q.shape[0], _ffi.as_ptr(sc),
+                                            _ffi.as_ptr(ids), _ffi.as_ptr(out), None))
+        return out
+
     def scores(self, queries) -> np.ndarray:
         """Full ``[nq x N]`` fp32 score matrix (small N): ``util.cos_sim(q_emb, s_emb)`` of
         compare_embeddings.py:24,61 when the index metric is "cos"."""
