@@ -1,6 +1,7 @@
 """The N > 1 path on CPU: world_size-2 gloo ranks exercise partition + exchange + merge of
 ShardedSearcher.  The per-shard search and the merge are injected (numpy oracle) because the HIP
 kernels need a GPU; what is tested is that the distributed plumbing returns the whole-corpus answer."""
+import datetime
 import os
 import socket
 
@@ -37,7 +38,7 @@ def _numpy_merge(scores, idx, k):
 def _worker(rank, world, port, n, nq, k, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     try:
         from theoremsearch_amd.distributed import ShardedSearcher, shard_bounds
         q, c = oracle.golden_inputs(n, nq, 64, 123, "ip")
@@ -68,7 +69,7 @@ def test_sharded_search_two_gloo_ranks(n, nq, k):
 def _rank_worker(rank, world, port, n, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     try:
         from theoremsearch_amd.distributed import ShardedSearcher, shard_bounds
         nq = 7

@@ -1,5 +1,6 @@
 """The reference-shaped host modules on a real GPU: every search below goes through libtsearch.so."""
 import json
+import datetime
 import os
 import socket
 
@@ -194,7 +195,7 @@ def _gpu_rank(rank, world, port, ret):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)       # both ranks share the one GPU of the box
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))       # both ranks share the one GPU of the box
     try:
         from theoremsearch_amd.distributed import ShardedSearcher, shard_bounds
         q, c = oracle.golden_inputs(30_000, 12, 768, 81, "ip")

@@ -81,6 +81,7 @@ struct LevelArgs {
     float* thr;          // [256]
     int final_level;
     float z_tail;        // sample level: > 0 = also apply the Gaussian-tail estimate mean + z * std of the sample
+    float tail_p;        // sample level: > 0 = also apply the exponential-tail fit for this exceedance probability
     int min_fill;        // final level: fewer candidates than this = the estimate was too high: exact re-run
     float* out_scores;
     int64_t* out_idx;
@@ -141,6 +142,10 @@ __global__ void __launch_bounds__(kLevelThreads) level_select_kernel(LevelArgs a
     const bool lost = raw > (u32)a.cap || total > (u32)kLevelSortMax;
     const int cnt = (int)min(total, (u32)kLevelSortMax);
     const int kk = a.kk;
+    // the sample level of the estimated threshold also needs the sample's 32 best for the tail fit
+    constexpr int kTailM = 32;
+    const bool tail_fit = !a.final_level && a.tail_p > 0.0f;
+    const int kl = tail_fit ? max(kk, kTailM) : kk;  // entries kept per wave
 
     // every wave streams its slice through a running top-kk (a key enters only if it beats the wave's
     // kk-th: about kk ln(n / kk) insertions for n keys), then the waves' lists are merged by one sort
@@ -154,17 +159,17 @@ __global__ void __launch_bounds__(kLevelThreads) level_select_kernel(LevelArgs a
             const int src = __ffsll((long long)m) - 1;
             m &= m - 1;
             const u64 K = shfl_u64(key, src);
-            if (K > tk.thr) tk.insert(K, kk, lane);
+            if (K > tk.thr) tk.insert(K, kl, lane);
         }
     }
     int P = 2;
-    while (P < nw * kk) P <<= 1;
+    while (P < nw * kl) P <<= 1;
     for (int i = threadIdx.x; i < P; i += blockDim.x) best[i] = 0ull;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < KR; ++r) {
         const int s = r * 64 + lane;
-        if (s < kk) best[wave * kk + s] = tk.key[r];
+        if (s < kl) best[wave * kl + s] = tk.key[r];
     }
     bitonic_sort_desc(best, P, threadIdx.x, blockDim.x);
 
@@ -174,6 +179,23 @@ __global__ void __launch_bounds__(kLevelThreads) level_select_kernel(LevelArgs a
         // of the candidates still gives a valid bound, so `lost` is harmless here)
         const u64 kth = best[kk - 1];
         float thr = kth ? key_score(kth) : -INFINITY;
+        // Heavier-than-Gaussian tails (clusters of near-duplicates: real corpora) make the Gaussian estimate far too
+        // low and the full pass would drown in candidates.  Second estimate, from the sample's order statistics 8..32
+        // (the top 7 are left out: outliers must not set the slope): an exponential tail fitted to their spacings
+        // (E[x_j - x_32] = e * sum_{i=j}^{31} 1/i) and extrapolated to the exceedance probability tail_p, which the
+        // host sets for ~2048 expected candidates - a quarter of the buffer, far above k - and only for corpora so large
+        // that the guaranteed bound alone would swamp the buffer.  On Gaussian scores the fit
+        // overshoots (their tail is lighter) yet stays below the Gaussian estimate, so nothing changes there; the
+        // larger of the two is used, and like the first it is only an estimate that the final level verifies.
+        float thr_tail = -INFINITY;
+        if (tail_fit && cnt >= 1024 && best[kTailM - 1] != 0ull) {
+            const float x_m = key_score(best[kTailM - 1]);
+            float spacing = 0.0f;
+            for (int j = 8; j < kTailM; ++j) spacing += key_score(best[j - 1]) - x_m;
+            const float e = spacing * (1.0f / 13.95928363f);
+            const float ratio = ((float)kTailM / (float)cnt) / a.tail_p;  // how far beyond the sample's 32nd best
+            if (ratio > 1.0f && e > 0.0f) thr_tail = x_m + e * __logf(ratio);
+        }
         if (a.z_tail > 0.0f && cnt >= 256) {
             // ... and usually far too low for the next level when that level is much bigger.  The scores of one
             // query over the corpus are close to Gaussian (normalised, high-dimensional rows), so the sample's
@@ -204,7 +226,7 @@ __global__ void __launch_bounds__(kLevelThreads) level_select_kernel(LevelArgs a
                 thr = fmaxf(thr, (float)(mean + (double)a.z_tail * sqrt(var)));
             }
         }
-        if (threadIdx.x == 0) a.thr[q] = thr;
+        if (threadIdx.x == 0) a.thr[q] = fmaxf(thr, thr_tail);
         return;
     }
     if (threadIdx.x == 0) atomicAdd(a.stat_candidates, (unsigned long long)produced);

@@ -699,6 +699,15 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
     const float z_tail = (statistical && lv.size() == 2)
                              ? (float)normal_tail_z(std::min(0.25, (double)stat_cands / (double)std::max<int64_t>(ix->n, 1)))
                              : 0.0f;
+    // Second estimate (exponential tail fit of the sample's order statistics, kernels_select.h), for score distributions
+    // with heavier tails than a Gaussian.  Only where it is needed: when the guaranteed bound alone (the kk-th best of
+    // the sample admits ~kk * N / sample rows) would swamp the candidate buffer - large corpora; it aims at
+    // max(2048, 8 kk) expected candidates, a quarter of the buffer.
+    const double sample_rows = (double)std::max<int64_t>(1, lv[0].ntiles * kTileRows);
+    const bool bound_swamps = (double)kk * (double)ix->n / sample_rows > 0.5 * kCandCap;
+    const float tail_p = (z_tail > 0.0f && bound_swamps && env_int("TS_MFMA_TAIL_FIT", 1))
+                             ? (float)std::min(0.25, (double)std::max(2048, 8 * kk) / (double)std::max<int64_t>(ix->n, 1))
+                             : 0.0f;
     static unsigned long long* g_dbg = nullptr;  // diagnostics (TS_MFMA_VARIANT=3): per-wave cycle sums
     for (size_t i = 0; i < lv.size(); ++i) {
         const bool full_pass = (i + 1 == lv.size());
@@ -753,6 +762,7 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         l.thr = ix->thr;
         l.final_level = full_pass;
         l.z_tail = full_pass ? 0.0f : z_tail;
+        l.tail_p = full_pass ? 0.0f : tail_p;
         l.min_fill = (z_tail > 0.0f) ? (int)std::min<int64_t>(k, ix->n) : 0;
         l.out_scores = out_scores;
         l.out_idx = out_idx;
