@@ -600,7 +600,10 @@ static std::vector<Level> plan_levels(int64_t n, int kk, bool statistical) {
     const int64_t r_last = pow2_ratio(target);
     // The sparsest level runs unthresholded: every score becomes a candidate, so it may hold at most
     // kLevelSortMax rows (what one select sorts) and one tile per workgroup (16 entries per private list).
-    const int64_t first_rows = std::min<int64_t>(kLevelSortMax, (int64_t)env_int("TS_MFMA_FIRST_ROWS", kLevelSortMax));
+    // sample size: 8192 rows for large corpora; below 4M rows half of that estimates the threshold as well (the
+    // guaranteed bound k * N / sample stays small) and its pass + select are 13 us shorter - 2 % of a 1.25M-row shard
+    const int first_default = (statistical && n < 4000000) ? kLevelSortMax / 2 : kLevelSortMax;
+    const int64_t first_rows = std::min<int64_t>(kLevelSortMax, (int64_t)env_int("TS_MFMA_FIRST_ROWS", first_default));
     const int64_t r_cap = std::max<int64_t>(2, pow2_ratio(env_int("TS_MFMA_TARGET_SPARSE", 1280)));
     std::vector<Level> lv;
     int64_t stride = 1;
