@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -635,8 +636,12 @@ static std::vector<Level> plan_levels(int64_t n, int kk, bool statistical) {
 template <int D, int GROUPS>
 static int launch_mfma(bool full_pass, int variant, int grid, hipStream_t st, const MfmaArgs& a) {
     constexpr int lds = MfmaDims<D>::kLds;
-    static bool attr_done = false;  // per instantiation; the attribute is a property of the code object
-    if (!attr_done) {
+    // the dynamic-LDS limit is set per function AND per device: one bit per device, per instantiation
+    static std::atomic<unsigned long long> attr_done{0};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_done.load(std::memory_order_acquire) & bit)) {
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<D, GROUPS, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<D, GROUPS, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<D, GROUPS, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -646,7 +651,7 @@ static int launch_mfma(bool full_pass, int variant, int grid, hipStream_t st, co
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<D, GROUPS, 5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<D, GROUPS, 6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<D, GROUPS, 7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_done = true;
+        attr_done.fetch_or(bit, std::memory_order_release);
     }
     if (!full_pass) mfma_topk_kernel<D, GROUPS, 0, true><<<grid, kMfmaThreads, lds, st>>>(a);
     else if (variant == 1) mfma_topk_kernel<D, GROUPS, 1, false><<<grid, kMfmaThreads, lds, st>>>(a);
