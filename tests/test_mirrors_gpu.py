@@ -257,3 +257,29 @@ def test_two_threads_share_one_index():
         for t in threads:
             t.join()
         assert not errors
+
+
+def test_bench_prints_one_json_line_with_the_contract_keys():
+    """bench.py's stdout is exactly one JSON line carrying the driver's keys plus roofline and cpu_baseline."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rows", "300000", "--nq", "16", "--steps", "2",
+                          "--warmup", "1"], capture_output=True, text=True, timeout=280, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    doc = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in doc, key
+    assert doc["n_gpus"] == 1 and doc["steps"] == 2 and doc["warmup"] == 1 and doc["higher_is_better"] is True
+    assert doc["unit"] == "queries/s" and doc["dtype"] == "bf16" and doc["data"] == "synthetic" and doc["vs_baseline"] is None
+    assert "workload" in doc["config"] and "model" not in doc["config"]
+    assert doc["value"] == pytest.approx(16 / (doc["ms_per_step"] * 1e-3), rel=1e-3)
+    roof = doc["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-3) and roof["achieved"] > 0
+    cpu = doc["cpu_baseline"]
+    assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
+    assert doc["recall_at_10"] == 1.0
