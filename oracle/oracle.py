@@ -579,3 +579,68 @@ def rank_of(truth: np.ndarray, rows) -> np.ndarray:
             s = truth[q]
             out[q] = int(np.sum(s > s[t]) + np.sum(s[:t] == s[t]))
     return out
+
+
+def sql_where(row, f) -> bool:
+    """The WHERE clause of the production app restated clause by clause with SQL's NULL semantics spelled out as
+    None-propagating values (streamlit_app.py:175-243); a row is kept when every clause evaluates to TRUE."""
+    def ilike(text, pat):            # text ILIKE '%pat%'  ->  True / False / None
+        return None if text is None else (pat.lower() in text.lower())
+
+    def NOT(v):
+        return None if v is None else (not v)
+
+    def AND(*vs):
+        if any(v is False for v in vs):
+            return False
+        return None if any(v is None for v in vs) else True
+
+    def OR(*vs):
+        if any(v is True for v in vs):
+            return True
+        return None if any(v is None for v in vs) else False
+
+    clauses = []
+    link = row.get("link")
+    arx = ilike(link, "arxiv.org")
+    if f["sources"]:
+        cases = []
+        if "arXiv" in f["sources"]:
+            cases.append(arx)
+        if "Stacks Project" in f["sources"]:
+            cases.append(NOT(arx))
+        if cases:
+            clauses.append(OR(*cases))
+    if f["authors"]:
+        a = row.get("authors")
+        clauses.append(None if a is None else bool(set(a) & set(f["authors"])))
+    if f["tags"]:
+        c = row.get("primary_category")
+        clauses.append(None if c is None else (c in f["tags"]))
+    if f["year_range"]:
+        y = row.get("year")
+        between = None if y is None else (f["year_range"][0] <= y <= f["year_range"][1])
+        clauses.append(OR(AND(arx, between), NOT(arx)))
+    if f["journal_status"] == "Journal Article":
+        clauses.append(AND(arx, row.get("journal_ref") is not None))
+    elif f["journal_status"] == "Preprint Only":
+        clauses.append(AND(arx, row.get("journal_ref") is None))
+    pf = f.get("paper_filter", {"ids": set(), "titles": set()})
+    pfc = []
+    if pf.get("ids"):
+        pfc.append(OR(*[ilike(link, i) for i in pf["ids"]]))
+    if pf.get("titles"):
+        pfc.append(OR(*[ilike(row.get("title"), t) for t in pf["titles"]]))
+    if pfc:
+        clauses.append(OR(*pfc))
+    if f["types"]:
+        name = row.get("type_name")
+        clauses.append(OR(*[ilike(None if name is None else name.lower(), t) for t in f["types"]]))
+    lo, hi = f["citation_range"]
+    cit = row.get("citations")
+    between = None if cit is None else (lo <= cit <= hi)
+    if f["include_unknown_citations"]:
+        clauses.append(OR(between, cit is None))
+    else:
+        clauses.append(AND(cit is not None, between))
+    return all(c is True for c in clauses)

@@ -40,3 +40,46 @@ def filter_states(top_k=10):
         "selective": dict(base, types=["corollary"], tags=["math.AP"], authors=["D. Lemma"], citation_range=(200, 299)),
         "nothing": dict(base, sources=["ProofWiki"], tags=["math.XX"]),
     }
+
+
+def make_sql_rows(n, seed=9):
+    """Joined (paper, theorem) rows as the production schema holds them, NULLs included."""
+    rng = np.random.default_rng(seed)
+    cats = ["math.AG", "math.NT", "math.PR", None]
+    names = ["Theorem", "Lemma", "Main Theorem", "Corollary", "proposition", None]
+    rows = []
+    for i in range(n):
+        kind = int(rng.integers(0, 10))
+        link = None if kind == 0 else (f"https://arxiv.org/abs/{2000 + i % 25}.{i:05d}" if kind < 7
+                                       else f"https://stacks.math.columbia.edu/tag/{i:04X}")
+        rows.append({
+            "link": link,
+            "authors": None if i % 11 == 0 else [AUTHORS[j] for j in rng.choice(5, size=int(rng.integers(1, 3)), replace=False)],
+            "primary_category": cats[int(rng.integers(0, 4))],
+            "year": None if i % 13 == 0 else int(rng.integers(1995, 2026)),
+            "journal_ref": None if rng.random() < 0.6 else "J. Test Math. 1 (2020)",
+            "title": None if i % 17 == 0 else f"On the {['cohomology', 'Zeta function', 'random walk'][i % 3]} of things {i}",
+            "type_name": names[int(rng.integers(0, 6))],
+            "citations": None if i % 5 == 0 else int(rng.integers(0, 200)),
+        })
+    return rows
+
+
+def sql_filter_states(top_k=10):
+    base = {"sources": ["arXiv", "Stacks Project"], "authors": [], "tags": [], "year_range": None, "journal_status": "All",
+            "paper_filter": {"ids": set(), "titles": set()}, "types": [], "citation_range": (0, 10**9),
+            "include_unknown_citations": True, "citation_weight": 0.0, "top_k": top_k}
+    return {
+        "open": dict(base),
+        "arxiv_only": dict(base, sources=["arXiv"]),
+        "stacks_only": dict(base, sources=["Stacks Project"]),
+        "authors_tags": dict(base, authors=["E. Noether"], tags=["math.AG", "math.PR"]),
+        "years": dict(base, year_range=(2010, 2015)),
+        "journal": dict(base, journal_status="Journal Article"),
+        "preprint_known_citations": dict(base, journal_status="Preprint Only", include_unknown_citations=False,
+                                         citation_range=(10, 150)),
+        "paper_filter": dict(base, paper_filter={"ids": {"2003."}, "titles": {"zeta FUNCTION"}}),
+        "types": dict(base, types=["theorem", "lemma"]),
+        "everything": dict(base, sources=["arXiv"], authors=["A. Author", "C. Prover"], tags=["math.NT"], year_range=(2000, 2024),
+                           types=["theorem"], citation_range=(5, 190), include_unknown_citations=False),
+    }

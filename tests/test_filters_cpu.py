@@ -3,9 +3,9 @@
 import numpy as np
 import pytest
 
-from filters_common import filter_states, make_theorems
+from filters_common import filter_states, make_sql_rows, make_theorems, sql_filter_states
 from oracle import oracle
-from theoremsearch_amd.filters import filter_mask
+from theoremsearch_amd.filters import filter_mask, sql_filter_mask
 
 
 @pytest.mark.parametrize("state", list(filter_states()))
@@ -36,3 +36,19 @@ def test_states_cover_empty_full_and_selective():
     assert not filter_mask(data, s["nothing"]).any()
     sel = filter_mask(data, s["selective"]).mean()
     assert 0 < sel < 0.01
+
+
+@pytest.mark.parametrize("state", list(sql_filter_states()))
+def test_sql_where_mask_agrees_with_the_clause_by_clause_restatement(state):
+    """filters.sql_filter_mask (what the scan kernel consumes as a bitmask) against oracle.sql_where, the WHERE clause
+    of streamlit_app.py:175-243 restated with explicit NULL logic - rows with NULL links, authors, years, titles,
+    type names and citation counts included."""
+    rows = make_sql_rows(4000)
+    f = sql_filter_states()[state]
+    mask = sql_filter_mask(rows, f)
+    want = np.array([oracle.sql_where(r, f) for r in rows])
+    assert np.array_equal(mask, want)
+    if state == "open":
+        assert 0.85 < mask.mean() < 0.95          # the rows with a NULL link match neither source clause
+    else:
+        assert 0 < mask.sum() < len(rows)

@@ -283,3 +283,32 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     cpu = doc["cpu_baseline"]
     assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
     assert doc["recall_at_10"] == 1.0
+
+
+def test_pgvector_search_with_a_where_mask():
+    """ORDER BY <#> LIMIT k behind a WHERE clause: pgvector.search(mask=sql_filter_mask(...)) returns what the oracle's
+    pgvector scan returns over exactly the rows the clause keeps - plain and citation-weighted."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from filters_common import make_sql_rows, sql_filter_states
+    import theoremsearch_amd as ts
+    from theoremsearch_amd import filters as flt
+    from theoremsearch_amd import pgvector
+    n, d = 5000, 768
+    q, e = oracle.golden_inputs(n, 1, d, 29, "ip")
+    rows = make_sql_rows(n)
+    cit = [r["citations"] for r in rows]
+    with ts.TheoremIndex.from_embeddings(e, metric="ip") as ix:
+        for name in ("arxiv_only", "preprint_known_citations", "everything"):
+            f = sql_filter_states(top_k=7)[name]
+            mask = flt.sql_filter_mask(rows, f)
+            keep = np.flatnonzero(mask)
+            got = pgvector.search(ix, q[0], 7, mask=mask)
+            want_i, want_sim = oracle.pgvector_search(q[0], e[keep], 7)
+            assert [g["row"] for g in got] == [int(keep[i]) for i in want_i], name
+            assert np.allclose([g["similarity"] for g in got], want_sim, atol=1e-5)
+            got_w = pgvector.search(ix, q[0], 5, citation_weight=0.05, citations=cit, mask=mask)
+            pool_i, pool_sim = oracle.pgvector_search(q[0], e[keep], oracle.pool_size(5))
+            ri, rs, rw = oracle.citation_weighted_rerank(keep[pool_i], pool_sim, [cit[int(keep[i])] for i in pool_i], 0.05, 5)
+            assert [g["row"] for g in got_w] == [int(i) for i in ri], name
+            assert np.allclose([g["score"] for g in got_w], rw, atol=1e-5)

@@ -68,3 +68,62 @@ def search_filtered(index, query_emb, theorems_data: Sequence[Mapping], filters:
             break
         out.append({"info": theorems_data[int(i)], "similarity": float(s)})
     return out
+
+
+# ---- the in-database form: WHERE clauses of the production app ---------------------------------------------------------
+def _ilike(text, needle: str) -> bool:
+    """``text ILIKE '%needle%'`` for a non-NULL text (case-insensitive substring)."""
+    return needle.lower() in text.lower()
+
+
+def _sql_row_passes(row: Mapping, f: Mapping) -> bool:
+    """One joined row (paper p, theorem t) against the WHERE clauses streamlit_app.py:175-243 assembles.  SQL's
+    three-valued logic is kept: a comparison with NULL is not true, so the row is dropped - e.g. a paper without a
+    link matches neither ``ILIKE '%arxiv.org%'`` nor ``NOT ILIKE '%arxiv.org%'``."""
+    link = row.get("link")
+    is_arxiv = None if link is None else _ilike(link, "arxiv.org")
+    if f.get("sources"):
+        ok = ("arXiv" in f["sources"] and is_arxiv is True) or ("Stacks Project" in f["sources"] and is_arxiv is False)
+        if (("arXiv" in f["sources"]) or ("Stacks Project" in f["sources"])) and not ok:
+            return False
+    if f.get("authors"):
+        authors = row.get("authors")
+        if authors is None or not set(authors) & set(f["authors"]):           # p.authors && %s
+            return False
+    if f.get("tags"):
+        if row.get("primary_category") is None or row["primary_category"] not in f["tags"]:
+            return False
+    if f.get("year_range"):
+        y0, y1 = f["year_range"]
+        year = row.get("year")                                                  # EXTRACT(YEAR FROM p.last_updated)
+        arxiv_in_range = is_arxiv is True and year is not None and y0 <= year <= y1
+        if not (arxiv_in_range or is_arxiv is False):
+            return False
+    status = f.get("journal_status", "All")
+    if status == "Journal Article" and not (is_arxiv is True and row.get("journal_ref") is not None):
+        return False
+    if status == "Preprint Only" and not (is_arxiv is True and row.get("journal_ref") is None):
+        return False
+    pf = f.get("paper_filter") or {}
+    ids, titles = pf.get("ids") or (), pf.get("titles") or ()
+    if ids or titles:
+        by_id = link is not None and any(_ilike(link, i) for i in ids)
+        by_title = row.get("title") is not None and any(_ilike(row["title"], t) for t in titles)
+        if not (by_id or by_title):
+            return False
+    if f.get("types"):
+        name = row.get("type_name")
+        if name is None or not any(_ilike(name.lower(), t) for t in f["types"]):   # lower(t.name) ILIKE ANY
+            return False
+    lo, hi = f["citation_range"]
+    cit = row.get("citations")
+    if cit is None:
+        return bool(f.get("include_unknown_citations"))
+    return lo <= cit <= hi
+
+
+def sql_filter_mask(rows: Sequence[Mapping], filters: Mapping) -> np.ndarray:
+    """bool[N] for the joined rows behind the embedding table (keys: link, authors, primary_category, year,
+    journal_ref, title, type_name, citations), in index order: the rows the production app's WHERE clause keeps.
+    Feed it to ``pgvector.search(..., mask=...)``: ORDER BY <#> LIMIT k over exactly those rows."""
+    return np.fromiter((_sql_row_passes(r, filters) for r in rows), dtype=bool, count=len(rows))

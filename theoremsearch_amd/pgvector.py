@@ -56,17 +56,18 @@ def pool_size(top_k: int) -> int:
 
 
 def search(index: TheoremIndex, query_vec, top_k: int, citation_weight: float = 0.0,
-           citations: Optional[Sequence[Optional[int]]] = None):
-    """Returns a list of dicts ``{"row", "similarity", "score"}`` ordered like the SQL result."""
+           citations: Optional[Sequence[Optional[int]]] = None, mask=None):
+    """Returns a list of dicts ``{"row", "similarity", "score"}`` ordered like the SQL result.  ``mask`` (bool per row,
+    e.g. `filters.sql_filter_mask`) plays the WHERE clause: only those rows are ranked."""
     q = np.asarray(query_vec, dtype=np.float32).reshape(1, -1)
     if citation_weight == 0.0:
-        scores, idx = index.search(q, int(top_k))
+        scores, idx = index.search(q, int(top_k), mask=mask)
         return [{"row": int(i), "similarity": 1.0 + float(s), "score": 1.0 + float(s)}
                 for s, i in zip(scores[0], idx[0]) if i >= 0]
     if citations is None:
         raise ValueError("citation-weighted search needs the per-row citation counts")
     pool = min(pool_size(top_k), 256)
-    scores, idx = index.search(q, pool)
+    scores, idx = index.search(q, pool, mask=mask)
     rows = []
     for s, i in zip(scores[0], idx[0]):
         if i < 0:
