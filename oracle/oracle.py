@@ -230,6 +230,9 @@ def check_topk_against_truth(truth_scores: np.ndarray, got_idx: np.ndarray,
                 assert set(got_run) <= members, (
                     f"query {b} ranks {pos}..{pos + take}: {got_run} not within tie run {sorted(members)}")
             pos = end
+        if kk == 0:          # nothing to rank (empty corpus): the answer is all padding
+            assert np.all(gi[b] == -1), f"query {b}: padding must be -1"
+            continue
         true_set = set(ext[:kk].tolist())
         kth = sv[kk - 1]
         for j in got.tolist():

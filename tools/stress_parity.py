@@ -1,0 +1,74 @@
+"""Randomised parity sweep on the GPU box: many (n, d, dtype, metric, nq, k, algo, mask) combinations against the
+oracle's fp64 truth, for a fixed time budget.  Prints a line per case (so a stall is visible) and arms
+faulthandler so that a hung call dumps the Python stack and exits.
+
+    python tools/stress_parity.py --seconds 240 --seed 1
+"""
+import argparse
+import faulthandler
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import theoremsearch_amd as ts  # noqa: E402
+from oracle import oracle  # noqa: E402  (checker)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=240)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    t_end = time.time() + args.seconds
+    case = 0
+    while time.time() < t_end:
+        case += 1
+        d = int(rng.choice([768, 768, 768, 1024, 1024, 384, 40]))
+        dtype = str(rng.choice(["bf16", "bf16", "f32"]))
+        metric = str(rng.choice(["cos", "ip"]))
+        n = int(rng.choice([1, 33, 1000, 16384, 16385, 40000, 70001, 150000, 300000]))
+        if d == 1024:
+            n = min(n, 150000)
+        nq = int(rng.choice([1, 2, 4, 5, 31, 32, 33, 64, 100, 128, 129, 160, 200, 256, 257, 300]))
+        k = int(rng.choice([1, 5, 10, 10, 10, 50, 64, 65, 200, 256]))
+        mfma_ok = dtype == "bf16" and d in (768, 1024)
+        algo = str(rng.choice(["auto", "scan", "mfma"])) if mfma_ok else str(rng.choice(["auto", "scan"]))
+        if algo == "scan" and nq > 64:
+            nq = int(rng.choice([1, 4, 7, 33]))          # the scan serves 4 queries per pass: keep the sweep moving
+        use_mask = algo != "mfma" and rng.random() < 0.2 and nq <= 8
+        seed = int(rng.integers(0, 2**31))
+        faulthandler.dump_traceback_later(120, exit=True)
+        t0 = time.time()
+        q, c = oracle.golden_inputs(n, nq, d, seed, metric)
+        if rng.random() < 0.15 and n > 100:              # duplicates: exact ties
+            c[rng.integers(0, n, 20)] = c[0]
+        mask = (rng.random(n) < 0.3) if use_mask else None
+        with ts.TheoremIndex.from_embeddings(c, dtype=dtype, metric=metric) as ix:
+            if mask is not None:
+                scores, idx = ix.search(q, k, mask=mask)
+            else:
+                scores, idx = ix.search(q, k, algo=algo)
+        rows = np.flatnonzero(mask) if mask is not None else np.arange(n)
+        qp, cp = oracle.prepared_inputs(q, c[rows], metric, dtype)
+        truth = oracle.scores_fp64(qp, cp)
+        m = min(k, rows.size)
+        local = np.full_like(idx, -1)
+        valid = idx >= 0
+        local[valid] = np.searchsorted(rows, idx[valid])
+        assert (idx[:, m:] == -1).all() and (idx[:, :m] >= 0).all(), "padding"
+        assert (rows[local[:, :m]] == idx[:, :m]).all(), "ids outside the allowed rows"
+        stats = oracle.check_topk_against_truth(truth, local, scores, k, gap=1e-6, score_tol=1e-5)
+        assert stats["recall"] == 1.0, stats
+        faulthandler.cancel_dump_traceback_later()
+        print(f"case {case}: n={n} d={d} {dtype} {metric} nq={nq} k={k} algo={algo} mask={use_mask} ok "
+              f"({time.time() - t0:.1f}s)", flush=True)
+    print(f"stress: {case} cases passed", flush=True)
+
+
+if __name__ == "__main__":
+    main()
