@@ -22,6 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--big", action="store_true", help="bf16 x 768 corpora of 1M-2.5M rows through the MFMA path (threshold estimates at scale)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     t_end = time.time() + args.seconds
@@ -36,17 +37,28 @@ def main():
             n = min(n, 150000)
         nq = int(rng.choice([1, 2, 4, 5, 31, 32, 33, 64, 100, 128, 129, 160, 200, 256, 257, 300]))
         k = int(rng.choice([1, 5, 10, 10, 10, 50, 64, 65, 200, 256]))
+        if args.big:
+            d, dtype = 768, "bf16"
+            n = int(rng.choice([1_000_000, 1_700_001, 2_500_000]))
+            nq = int(rng.choice([5, 16, 33, 130]))
+            k = int(rng.choice([1, 10, 10, 50, 256]))
         mfma_ok = dtype == "bf16" and d in (768, 1024)
         algo = str(rng.choice(["auto", "scan", "mfma"])) if mfma_ok else str(rng.choice(["auto", "scan"]))
+        if args.big:
+            algo = "mfma"
         if algo == "scan" and nq > 64:
             nq = int(rng.choice([1, 4, 7, 33]))          # the scan serves 4 queries per pass: keep the sweep moving
         use_mask = algo != "mfma" and rng.random() < 0.2 and nq <= 8
         seed = int(rng.integers(0, 2**31))
-        faulthandler.dump_traceback_later(120, exit=True)
+        faulthandler.dump_traceback_later(300 if args.big else 120, exit=True)
         t0 = time.time()
         q, c = oracle.golden_inputs(n, nq, d, seed, metric)
         if rng.random() < 0.15 and n > 100:              # duplicates: exact ties
             c[rng.integers(0, n, 20)] = c[0]
+        if args.big and rng.random() < 0.5:              # a cluster near the queries: heavy upper tail
+            u = q.mean(axis=0)
+            members = rng.choice(n, n // 25, replace=False)
+            c[members] += (rng.random(members.size).astype(np.float32) * np.float32(4.0))[:, None] * u
         mask = (rng.random(n) < 0.3) if use_mask else None
         with ts.TheoremIndex.from_embeddings(c, dtype=dtype, metric=metric) as ix:
             if mask is not None:
