@@ -771,6 +771,7 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         l.final_level = full_pass;
         l.z_tail = full_pass ? 0.0f : z_tail;
         l.tail_p = full_pass ? 0.0f : tail_p;
+        l.tail_z = (float)normal_tail_z(std::min(0.25, 32.0 / sample_rows));
         l.min_fill = (z_tail > 0.0f) ? (int)std::min<int64_t>(k, ix->n) : 0;
         l.out_scores = out_scores;
         l.out_idx = out_idx;
