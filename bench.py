@@ -256,6 +256,15 @@ def main():
                 "kernel_ms": round(kern_ms, 4), "launches_per_step": launches_per_step,
                 "algorithmic_bytes_per_launch": alg_bytes}
 
+    # ---- how the estimated thresholds did (one extra search outside the timed region) ---------------
+    search_stats = None
+    if bf16 and nq > 4 and args.algo in ("auto", "mfma") and not mask_ptr and encoder is None:
+        _, _, st_ = ix.search(q_host, K, algo=args.algo, return_stats=True)
+        search_stats = {"levels": st_["levels"], "fallback_queries": st_["fallback_queries"],
+                        "candidates_per_query": round(st_["candidates"] / float(nq), 1)}
+        log(rank, f"threshold levels {st_['levels']}, candidates per query {search_stats['candidates_per_query']}, "
+                  f"queries re-run exactly {st_['fallback_queries']}")
+
     # ---- recall@10 against the oracle (fp64 scores of the same bf16/fp32 values) -------------------
     last = (step_no[0] - 1) & 1
     if use_dist:
@@ -342,6 +351,7 @@ def main():
                        **({"mask_frac": args.mask_frac} if args.mask_frac > 0 else {}),
                        "parallelism": f"corpus row-sharded x{world}" + ((", gloo rehearsal on one GPU" if args.share_gpu else ", RCCL all-gather of per-shard top-k") if use_dist else "")},
             "recall_at_10": recall,
+            "search_stats": search_stats,
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

@@ -1179,6 +1179,15 @@ extern "C" int ts_index_profile_enable(ts_index* ix, int enable) {
     std::lock_guard<std::mutex> lock(ix->mu);
     ix->profiling = enable != 0;
     ix->ev_used = 0;
+    if (enable) {
+        // events are created here, not inside the loop that is being measured
+        HIP_TRY(hipSetDevice(ix->device));
+        while (ix->ev_pool.size() < 512) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) break;
+            ix->ev_pool.push_back(e);
+        }
+    }
     return TS_OK;
 }
 
