@@ -204,7 +204,18 @@ def _gpu_rank(rank, world, port, ret):
         scores, idx = searcher.search(q, 10)
         truth = oracle.scores_fp64(*oracle.prepared_inputs(q, c, "ip", "bf16"))
         stats = oracle.check_topk_against_truth(truth, idx, scores, 10)
-        ret[rank] = stats["recall"]
+        # rank of a document over the sharded corpus = its position in the whole ranking
+        rows = np.array([int(idx[0, 0]), int(idx[1, 9]), 3, len(c) - 1, len(c) // 2, len(c) // 2 - 1] + [7] * 6)
+        got_ranks = searcher.rank_of(q, rows)
+        want_ranks = oracle.rank_of(truth, rows)
+        close = np.array([np.sum(np.abs(truth[i] - truth[i, r]) <= 1e-6) - 1 for i, r in enumerate(rows)])
+        ranks_ok = bool(np.all(np.abs(got_ranks - want_ranks) <= close)) and got_ranks[0] == 0 and got_ranks[1] == 9
+        # metadata filter over the whole corpus, applied slice by slice
+        mask = np.random.default_rng(5).random(len(c)) < 0.3
+        ms, mi = searcher.search(q, 10, mask=mask)
+        keep = np.flatnonzero(mask)
+        mstats = oracle.check_topk_against_truth(truth[:, keep], np.searchsorted(keep, mi), ms, 10)
+        ret[rank] = stats["recall"] if (ranks_ok and mask[mi].all() and mstats["recall"] == 1.0) else -1.0
     finally:
         dist.destroy_process_group()
 

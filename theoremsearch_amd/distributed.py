@@ -55,9 +55,15 @@ class ShardedSearcher:
         obj.index = ix
         return obj
 
-    def search(self, queries: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:
+    def search(self, queries: np.ndarray, k: int, mask: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
+        """``mask``: bool per row of the WHOLE corpus (a metadata filter); every rank applies its slice of it."""
         import torch
-        scores, idx = self.local_search(queries, k)
+        if mask is not None:
+            ix = self.index
+            lo = ix.row_offset
+            scores, idx = ix.search(queries, k, mask=np.asarray(mask, dtype=bool)[lo:lo + ix.n])
+        else:
+            scores, idx = self.local_search(queries, k)
         if self.world == 1:
             return scores, idx
         nq = scores.shape[0]
