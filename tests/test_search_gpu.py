@@ -75,7 +75,8 @@ def test_index_rows_match_oracle_preparation(ts):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("n,d,nq,k", [(1, 8, 1, 1), (5, 8, 3, 10), (31, 40, 2, 5), (257, 768, 5, 256),
-                                      (1000, 1024, 9, 7), (4097, 100, 4, 64), (600, 768, 300, 3)])
+                                      (1000, 1024, 9, 7), (4097, 100, 4, 64), (600, 768, 300, 3),
+                                      (3001, 384, 6, 10), (2003, 384, 5, 200), (2500, 512, 7, 70), (900, 500, 3, 5)])
 def test_ragged_shapes(ts, dtype, n, d, nq, k):
     rng = np.random.default_rng(n * 7 + d)
     c = rng.standard_normal((n, d), dtype=np.float32)
@@ -398,7 +399,8 @@ def test_showcase_filters_return_topk_where_the_reference_pool_runs_dry(ts):
     assert saw_dry
 
 
-@pytest.mark.parametrize("dtype,d,n", [("f32", 768, 20011), ("bf16", 768, 20011), ("bf16", 1024, 5003), ("f32", 384, 3001)])
+@pytest.mark.parametrize("dtype,d,n", [("f32", 768, 20011), ("bf16", 768, 20011), ("bf16", 1024, 5003), ("f32", 384, 3001),
+                                       ("bf16", 384, 3001), ("f32", 512, 2001), ("bf16", 512, 2001), ("f32", 100, 999)])
 def test_rank_of_matches_position_in_the_full_ranking(ts, dtype, d, n):
     """ts_rank_of = position of the row in the full ranking of the fp64 truth, wherever the truth separates the
     target from its neighbours by more than GAP; consistent with ts_search (rank r <=> idx[r] == row)."""

@@ -481,6 +481,11 @@ static int launch_scan(const ts_index* ix, ScanArgs a, int qb_pref, hipStream_t 
     if (!force_generic && ix->dtype == TS_F32 && ix->ld == 1024) { launch_scan_spec<0, 4, 64, EMIT>(qb_pref, kr, grid, st, a); return qb_pref; }
     if (!force_generic && ix->dtype == TS_BF16 && ix->ld == 768) { launch_scan_spec<1, 3, 32, EMIT>(qb_pref, kr, grid, st, a); return qb_pref; }
     if (!force_generic && ix->dtype == TS_BF16 && ix->ld == 1024) { launch_scan_spec<1, 2, 64, EMIT>(qb_pref, kr, grid, st, a); return qb_pref; }
+    // the other common embedding widths (MiniLM-class 384, 512): same kernel, narrower lane groups
+    if (!force_generic && ix->dtype == TS_F32 && ix->ld == 384) { launch_scan_spec<0, 3, 32, EMIT>(qb_pref, kr, grid, st, a); return qb_pref; }
+    if (!force_generic && ix->dtype == TS_BF16 && ix->ld == 384) { launch_scan_spec<1, 3, 16, EMIT>(qb_pref, kr, grid, st, a); return qb_pref; }
+    if (!force_generic && ix->dtype == TS_F32 && ix->ld == 512) { launch_scan_spec<0, 2, 64, EMIT>(qb_pref, kr, grid, st, a); return qb_pref; }
+    if (!force_generic && ix->dtype == TS_BF16 && ix->ld == 512) { launch_scan_spec<1, 2, 32, EMIT>(qb_pref, kr, grid, st, a); return qb_pref; }
     if (ix->dtype == TS_F32) launch_scan_generic<0, EMIT>(kr, grid, st, a);
     else launch_scan_generic<1, EMIT>(kr, grid, st, a);
     return 1;
@@ -546,7 +551,7 @@ static int scan_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
     a.row_mask = ix->active_mask;
     // k > 64 keeps 4 keys per lane and query: on bf16 x 768 four queries at once need all 256 VGPRs, one wave per SIMD
     // (measured 0.18 of the HBM rate against 0.8 for one query per pass); the other shapes keep two waves
-    const bool wide_k_one_wave = k > 64 && ix->dtype == TS_BF16 && ix->ld == 768;
+    const bool wide_k_one_wave = k > 64 && ix->dtype == TS_BF16 && (ix->ld == 768 || ix->ld == 384);
     const int qb = ((nq >= 2 || qcount) && !wide_k_one_wave) ? 4 : 1;
     hipEvent_t stop = qcount ? nullptr : prof_begin(ix, st, ix->n);  // the MFMA path's fall-back pass is not bracketed
     launch_scan<false>(ix, a, qb, st, grid);
@@ -919,6 +924,10 @@ static void launch_rank(const ts_index* ix, const RankArgs& a, hipStream_t st, i
     if (!force_generic && ix->dtype == TS_F32 && ix->ld == 1024) return launch_rank_spec<0, 4, 64>(qb, grid, st, a);
     if (!force_generic && ix->dtype == TS_BF16 && ix->ld == 768) return launch_rank_spec<1, 3, 32>(qb, grid, st, a);
     if (!force_generic && ix->dtype == TS_BF16 && ix->ld == 1024) return launch_rank_spec<1, 2, 64>(qb, grid, st, a);
+    if (!force_generic && ix->dtype == TS_F32 && ix->ld == 384) return launch_rank_spec<0, 3, 32>(qb, grid, st, a);
+    if (!force_generic && ix->dtype == TS_BF16 && ix->ld == 384) return launch_rank_spec<1, 3, 16>(qb, grid, st, a);
+    if (!force_generic && ix->dtype == TS_F32 && ix->ld == 512) return launch_rank_spec<0, 2, 64>(qb, grid, st, a);
+    if (!force_generic && ix->dtype == TS_BF16 && ix->ld == 512) return launch_rank_spec<1, 2, 32>(qb, grid, st, a);
     const size_t lds = (size_t)a.ld * 4;
     if (ix->dtype == TS_F32) {
         hipFuncSetAttribute((const void*)rank_generic_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
