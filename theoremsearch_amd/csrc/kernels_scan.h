@@ -182,14 +182,14 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanArgs a) {
     }
 }
 
-// Generic: any ld (multiple of 64 elements), one query per pass, query staged in LDS.
-template <int DT, int KR, bool EMIT>
+// Generic: any ld (multiple of 64 elements), QB queries per pass staged in LDS (QB = 1 or 4).
+template <int DT, int KR, bool EMIT, int QB>
 __global__ void __launch_bounds__(256) scan_generic_kernel(ScanArgs a) {
     constexpr int VEC = Elem<DT>::VEC;
     constexpr int RW = kScanRB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* lds_keys = (u64*)smem;            // 1024 keys
-    float* lds_q = (float*)(smem + 8192);  // ld floats
+    float* lds_q = (float*)(smem + 8192);  // QB x ld floats
     const int lane = threadIdx.x & 63;
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t W = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -198,44 +198,65 @@ __global__ void __launch_bounds__(256) scan_generic_kernel(ScanArgs a) {
     const int64_t ld16 = a.ld / VEC;
     const int count = a.qcount ? *a.qcount : a.nq;
 
-    for (int g0 = 0; g0 < count; ++g0) {
-        const int qid = a.qlist ? a.qlist[g0] : g0;
+    for (int g0 = 0; g0 < count; g0 += QB) {
+        int qid[QB];
         __syncthreads();
-        for (int i = threadIdx.x; i < a.ld; i += blockDim.x) lds_q[i] = a.qbuf[(int64_t)qid * a.ld + i];
+#pragma unroll
+        for (int q = 0; q < QB; ++q) {
+            const int slot = (g0 + q < count) ? (g0 + q) : g0;
+            qid[q] = a.qlist ? a.qlist[slot] : slot;
+            for (int i = threadIdx.x; i < a.ld; i += blockDim.x) lds_q[(int64_t)q * a.ld + i] = a.qbuf[(int64_t)qid[q] * a.ld + i];
+        }
         __syncthreads();
-        WaveTopK<KR> tk;
-        tk.init();
+        WaveTopK<KR> tk[QB];
+#pragma unroll
+        for (int q = 0; q < QB; ++q) tk[q].init();
         for (int64_t blk = gw; blk < nblocks; blk += W) {
             const int64_t row0 = blk * RW;
-            float acc[kScanRB] = {0.f, 0.f, 0.f, 0.f};
+            float acc[QB][kScanRB];
+#pragma unroll
+            for (int q = 0; q < QB; ++q)
+#pragma unroll
+                for (int r = 0; r < kScanRB; ++r) acc[q][r] = 0.f;
             for (int64_t c = lane; c < ld16; c += 64) {
-                float qreg[VEC];
+                uint4 v[kScanRB];
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) qreg[e] = lds_q[c * VEC + e];
+                for (int r = 0; r < kScanRB; ++r) v[r] = stream_load(base + (row0 + r) * ld16 + c);
 #pragma unroll
-                for (int r = 0; r < kScanRB; ++r) {
-                    const uint4 v = stream_load(base + (row0 + r) * ld16 + c);
-                    acc[r] = chunk_dot<DT>(v, qreg, acc[r]);
+                for (int q = 0; q < QB; ++q) {
+                    float qreg[VEC];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) qreg[e] = lds_q[(int64_t)q * a.ld + c * VEC + e];
+#pragma unroll
+                    for (int r = 0; r < kScanRB; ++r) acc[q][r] = chunk_dot<DT>(v[r], qreg, acc[q][r]);
                 }
             }
-            const float s = reduce4<64>(acc[0], acc[1], acc[2], acc[3], lane);
             const int64_t row = row0 + rho<64>(lane);
             const bool rep = (lane & 15) == 0;
-            if (EMIT) {
-                if (rep && row < a.n) a.scores[(int64_t)qid * a.n + row] = s;
-            } else {
-                const bool allowed = !a.row_mask || (rep && row < a.n && ((a.row_mask[row >> 5] >> (row & 31)) & 1u));
-                const u64 key = (rep && row < a.n && s == s && allowed) ? make_key(s, (u32)row) : 0ull;
-                u64 m = __ballot(key > tk.thr);
-                while (m) {
-                    const int src = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const u64 K = shfl_u64(key, src);
-                    if (K > tk.thr) tk.insert(K, a.k, lane);
+            const bool allowed = !a.row_mask || (rep && row < a.n && ((a.row_mask[row >> 5] >> (row & 31)) & 1u));
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                const float s = reduce4<64>(acc[q][0], acc[q][1], acc[q][2], acc[q][3], lane);
+                if (EMIT) {
+                    if (rep && row < a.n && g0 + q < count) a.scores[(int64_t)qid[q] * a.n + row] = s;
+                } else {
+                    const u64 key = (rep && row < a.n && s == s && allowed) ? make_key(s, (u32)row) : 0ull;
+                    u64 m = __ballot(key > tk[q].thr);
+                    while (m) {
+                        const int src = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const u64 K = shfl_u64(key, src);
+                        if (K > tk[q].thr) tk[q].insert(K, a.k, lane);
+                    }
                 }
             }
         }
-        if (!EMIT) wg_merge_store<KR>(tk, a.k, lds_keys, a.partial + ((int64_t)g0 * gridDim.x + blockIdx.x) * a.k);
+        if (!EMIT) {
+#pragma unroll
+            for (int q = 0; q < QB; ++q)
+                if (g0 + q < count)  // uniform over the workgroup
+                    wg_merge_store<KR>(tk[q], a.k, lds_keys, a.partial + ((int64_t)(g0 + q) * gridDim.x + blockIdx.x) * a.k);
+        }
     }
 }
 

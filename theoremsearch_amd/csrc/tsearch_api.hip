@@ -459,16 +459,18 @@ static void launch_scan_spec(int qb, int kr, int grid, hipStream_t st, const Sca
 }
 
 template <int DT, bool EMIT>
-static void launch_scan_generic(int kr, int grid, hipStream_t st, const ScanArgs& a) {
-    const size_t lds = 8192 + (size_t)a.ld * 4;
-    if (EMIT || kr == 1) {
-        auto kern = scan_generic_kernel<DT, 1, EMIT>;
+static void launch_scan_generic(int qb, int kr, int grid, hipStream_t st, const ScanArgs& a) {
+    const size_t lds = 8192 + (size_t)a.ld * 4 * (qb == 4 ? 4 : 1);
+    auto go = [&](auto kern) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         kern<<<grid, 256, lds, st>>>(a);
+    };
+    if (qb == 4) {
+        if (EMIT || kr == 1) go(scan_generic_kernel<DT, 1, EMIT, 4>);
+        else go(scan_generic_kernel<DT, 4, EMIT, 1>);   // k > 64: four lists of 4 keys per lane do not fit; one query per pass
     } else {
-        auto kern = scan_generic_kernel<DT, 4, EMIT>;
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        kern<<<grid, 256, lds, st>>>(a);
+        if (EMIT || kr == 1) go(scan_generic_kernel<DT, 1, EMIT, 1>);
+        else go(scan_generic_kernel<DT, 4, EMIT, 1>);
     }
 }
 
@@ -486,9 +488,11 @@ static int launch_scan(const ts_index* ix, ScanArgs a, int qb_pref, hipStream_t 
     if (!force_generic && ix->dtype == TS_BF16 && ix->ld == 384) { launch_scan_spec<1, 3, 16, EMIT>(qb_pref, kr, grid, st, a); return qb_pref; }
     if (!force_generic && ix->dtype == TS_F32 && ix->ld == 512) { launch_scan_spec<0, 2, 64, EMIT>(qb_pref, kr, grid, st, a); return qb_pref; }
     if (!force_generic && ix->dtype == TS_BF16 && ix->ld == 512) { launch_scan_spec<1, 2, 32, EMIT>(qb_pref, kr, grid, st, a); return qb_pref; }
-    if (ix->dtype == TS_F32) launch_scan_generic<0, EMIT>(kr, grid, st, a);
-    else launch_scan_generic<1, EMIT>(kr, grid, st, a);
-    return 1;
+    // any other width: queries staged in LDS, 4 per pass while they fit (ld <= 8192) and k <= 64
+    const int qb = (qb_pref == 4 && a.ld <= 8192 && (EMIT || kr == 1)) ? 4 : 1;
+    if (ix->dtype == TS_F32) launch_scan_generic<0, EMIT>(qb, kr, grid, st, a);
+    else launch_scan_generic<1, EMIT>(qb, kr, grid, st, a);
+    return qb;
 }
 
 // Reduce [slots][m] partial keys to the final k per query: select rounds of 4096-key segments.
