@@ -126,6 +126,14 @@ int ts_search_ex(ts_index *ix, const void *queries, int q_dtype, int q_on_device
 int ts_parse_pgvector_text(const char *text, int64_t len, int32_t d, float *out, int64_t max_rows, int64_t *rows_parsed,
                            int64_t *consumed);
 
+/* A second HANDLE on the rows of `src` (no copy): its own stream, scratch buffers and lock, so that two searches of the
+ * same corpus can be in flight on two streams - the small kernels at the head of one search (query preparation, the
+ * threshold sample and its select) then overlap the tail of the previous one (final select, re-run check, merge).
+ * What a serving loop over independent query batches wants; the reference has no counterpart (one process, one query
+ * at a time, streamlit_app.py:165-173).  Read-only; must be destroyed before `src`; set_row_offset / subsets of `src`
+ * made later are not seen by the view. */
+int ts_index_view(ts_index *src, ts_index **out);
+
 /* A second index holding copies of the given rows of `src` (global ids, strictly ascending, host memory); searches
  * of it return the ORIGINAL global ids, in the same canonical order.  The filtered search for query batches and for
  * filters that stay fixed over many searches (a sidebar state, app_showcase_model.py:96-129; the WHERE clause of

@@ -323,3 +323,32 @@ def test_pgvector_search_with_a_where_mask():
             ri, rs, rw = oracle.citation_weighted_rerank(keep[pool_i], pool_sim, [cit[int(keep[i])] for i in pool_i], 0.05, 5)
             assert [g["row"] for g in got_w] == [int(i) for i in ri], name
             assert np.allclose([g["score"] for g in got_w], rw, atol=1e-5)
+
+
+def test_view_handles_search_the_same_rows_concurrently():
+    """ts_index_view: a second handle on the same rows (own stream, scratch, lock); two threads, one per handle, get
+    the answers of the owning handle; a view is read-only."""
+    import threading
+    import theoremsearch_amd as ts
+    n, d = 50000, 768
+    q, c = oracle.golden_inputs(n, 48, d, 37, "cos")
+    with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="cos", row_offset=77) as ix:
+        want = ix.search(q, 10)
+        with ix.view() as v:
+            assert (v.n, v.d, v.row_offset) == (ix.n, ix.d, 77)
+            bad = []
+
+            def worker(h):
+                for _ in range(20):
+                    s, i = h.search(q, 10)
+                    if not (np.array_equal(i, want[1]) and np.array_equal(s, want[0])):
+                        bad.append(1)
+
+            threads = [threading.Thread(target=worker, args=(h,)) for h in (ix, v)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            assert not bad
+            with pytest.raises(ts.TSearchError):
+                v.upload(c[:1], 0)

@@ -58,6 +58,7 @@ _SIGNATURES = {
                                C.c_int, C.c_void_p, C.c_int, C.POINTER(SearchStats)]),
     "ts_parse_pgvector_text": (C.c_int, [C.c_char_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64),
                                          C.POINTER(C.c_int64)]),
+    "ts_index_view": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "ts_index_subset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),
     "ts_search_filtered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

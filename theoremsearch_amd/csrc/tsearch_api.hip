@@ -81,6 +81,7 @@ struct ts_index {
     float* res_scores = nullptr; int64_t* res_idx = nullptr; size_t res_cap = 0;  // device result buffers (entries)
     u32* mask_dev = nullptr;    size_t mask_bytes = 0;       // filtered search: device copy of a host bitmask
     int64_t* id_map = nullptr;                               // subset index: local row -> global id
+    bool borrowed = false;                                   // a view: rows / id_map belong to another handle
     void* rank_buf = nullptr;   size_t rank_bytes = 0;       // ts_rank_of: targets | counts | target scores, one query block
     const u32* active_mask = nullptr;                        // bitmask of the search in progress (under `mu`)
     bool attr_done = false;
@@ -210,10 +211,41 @@ extern "C" int ts_index_create(int device, int64_t n, int32_t d, int dtype, int 
     return TS_OK;
 }
 
+extern "C" int ts_index_view(ts_index* src, ts_index** out) {
+    if (!out) return fail(TS_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!src) return fail(TS_ERR_INVALID, "index is NULL");
+    HIP_TRY(hipSetDevice(src->device));
+    ts_index* ix = new (std::nothrow) ts_index();
+    if (!ix) return fail(TS_ERR_NOMEM, "host allocation failed");
+    ix->device = src->device;
+    ix->n = src->n;
+    ix->n_pad = src->n_pad;
+    ix->d = src->d;
+    ix->ld = src->ld;
+    ix->dtype = src->dtype;
+    ix->metric = src->metric;
+    ix->row_offset = src->row_offset;
+    ix->cu_count = src->cu_count;
+    ix->rows = src->rows;
+    ix->id_map = src->id_map;
+    ix->borrowed = true;
+    if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ix;
+        return fail(TS_ERR_HIP, "stream creation failed");
+    }
+    *out = ix;
+    return TS_OK;
+}
+
 extern "C" int ts_index_destroy(ts_index* ix) {
     if (!ix) return TS_OK;
     hipSetDevice(ix->device);
     if (ix->stream) hipStreamSynchronize(ix->stream);
+    if (ix->borrowed) {
+        ix->rows = nullptr;
+        ix->id_map = nullptr;
+    }
     void* ptrs[] = {ix->rows,  ix->stage,   ix->qstore,   ix->qf32,     ix->cand,       ix->count,  ix->thr, ix->priv, ix->pcount, ix->mask_dev, ix->rank_buf, ix->id_map,
                     ix->fb_list, ix->fb_count, ix->stat, ix->partial, ix->partial2, ix->res_scores, ix->res_idx};
     for (void* p : ptrs)
@@ -313,6 +345,7 @@ static int check_rows(const ts_index* ix, const void* p, int src_dtype, int64_t 
     if (!ix || !p) return fail(TS_ERR_INVALID, "NULL argument");
     if (src_dtype != TS_F32 && src_dtype != TS_BF16) return fail(TS_ERR_INVALID, "src_dtype %d", src_dtype);
     if (ix->id_map) return fail(TS_ERR_UNSUPPORTED, "a subset index is read-only");
+    if (ix->borrowed) return fail(TS_ERR_UNSUPPORTED, "a view is read-only: upload through the handle that owns the rows");
     if (row0 < 0 || nrows < 0 || row0 + nrows > ix->n)
         return fail(TS_ERR_INVALID, "rows [%lld, %lld) outside the index of %lld rows", (long long)row0,
                     (long long)(row0 + nrows), (long long)ix->n);

@@ -68,6 +68,17 @@ class TheoremIndex:
         ix.upload(rows, 0)
         return ix
 
+    def view(self) -> "TheoremIndex":
+        """A second handle on the same rows (no copy) with its own stream and scratch: searches through the two handles
+        can be in flight at once on two streams (serving loops over independent batches).  Read-only; close it before
+        the index it views."""
+        v = object.__new__(TheoremIndex)
+        v._lib, v._h = self._lib, C.c_void_p()
+        v.n, v.d, v.dtype, v.metric, v.device, v.row_offset = self.n, self.d, self.dtype, self.metric, self.device, self.row_offset
+        v._parent = self                      # keeps the owner of the rows alive
+        _ffi.check(self._lib.ts_index_view(self._h, C.byref(v._h)))
+        return v
+
     def subset(self, rows_or_mask) -> "TheoremIndex":
         """A new index over a subset of this one's rows (bool mask of length n, or ascending global row ids).
         Its searches return this index's ids: the filtered search for query batches / long-lived filters."""
