@@ -647,3 +647,21 @@ def sql_where(row, f) -> bool:
     else:
         clauses.append(AND(cit is not None, between))
     return all(c is True for c in clauses)
+
+
+def cpu_reference_topk(q: np.ndarray, c: np.ndarray, k: int, threads: Optional[int] = None):
+    """The reference's own CPU formulation, as its scripts run it on the host: ``util.cos_sim`` = L2-normalise both sides
+    and one fp32 matmul (sentence_transformers: ``torch.mm(F.normalize(a), F.normalize(b).T)``), then
+    ``np.argsort(-S, axis=1)[:, :k]`` (compare_embeddings.py:61,105).  torch on the CPU, ``threads`` host threads
+    (default: all).  This is what bench.py times as ``cpu_baseline`` (kind "port"); returns (indices, seconds)."""
+    import time
+
+    import torch
+    import torch.nn.functional as F
+    if threads:
+        torch.set_num_threads(int(threads))
+    a, b = torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32)), torch.from_numpy(np.ascontiguousarray(c, dtype=np.float32))
+    t0 = time.perf_counter()
+    S = torch.mm(F.normalize(a, p=2, dim=1), F.normalize(b, p=2, dim=1).T).numpy()
+    top = np.argsort(-S, axis=1)[:, :k]
+    return top, time.perf_counter() - t0
