@@ -23,7 +23,7 @@ def ts():
 
 
 def algos_for(dtype, d):
-    return ["scan", "mfma"] if (dtype == "bf16" and d in (768, 1024)) else ["scan"]
+    return ["scan", "mfma"] if (dtype == "bf16" and d in (384, 512, 768, 1024)) else ["scan"]
 
 
 def check(q, c, metric, dtype, k, scores, idx):
@@ -198,6 +198,21 @@ def test_estimated_threshold_is_verified_not_trusted(ts, kind):
         scores, idx, st = ix.search(q, 10, algo="mfma", return_stats=True)
         assert st["algo"] == 2
         check(q, c, "ip", "bf16", 10, scores, idx)
+
+
+@pytest.mark.parametrize("d", [384, 512])
+def test_mfma_narrow_widths(ts, d):
+    """d = 384 / 512 (MiniLM-class models) on the MFMA path: one and two query groups per wave, partial last tile,
+    more queries than one launch holds, large k."""
+    q, c = oracle.golden_inputs(70_013, 300, d, 90 + d, "cos")
+    with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="cos") as ix:
+        for nq, k in ((5, 10), (128, 10), (129, 3), (256, 50), (300, 256)):
+            s, i, st = ix.search(q[:nq], k, algo="mfma", return_stats=True)
+            assert st["algo"] == 2
+            check(q[:nq], c, "cos", "bf16", k, s, i)
+        sa, ia = ix.search(q[:40], 10)              # auto picks the MFMA path for a batch
+        ss, is_ = ix.search(q[:40], 10, algo="scan")
+        assert np.mean(ia == is_) > 0.999
 
 
 def test_clustered_corpus_is_served_without_reruns(ts):

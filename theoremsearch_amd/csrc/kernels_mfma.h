@@ -53,6 +53,9 @@ constexpr int kMfmaPrivCap = 32;   // entries of a lane-private candidate list
 template <int D> struct MfmaGeom;
 template <> struct MfmaGeom<768> { static constexpr int kUnitK = 384, kSlots = 6; };
 template <> struct MfmaGeom<1024> { static constexpr int kUnitK = 256, kSlots = 8; };
+// the narrower common widths: same unit image (blocks of 64 columns), two units per tile, two query groups per wave
+template <> struct MfmaGeom<512> { static constexpr int kUnitK = 256, kSlots = 8; };
+template <> struct MfmaGeom<384> { static constexpr int kUnitK = 192, kSlots = 8; };
 template <int D> struct MfmaDims {
     static constexpr int kKSteps = D / 16;
     static constexpr int kUnitK = MfmaGeom<D>::kUnitK;
@@ -65,7 +68,6 @@ template <int D> struct MfmaDims {
     static constexpr int kPieceEvery = kUnitSteps / kPieces;     // one piece every so many k-steps
     static constexpr int kAhead = 4;                             // A fragments (k-steps) in flight
 };
-constexpr int mfma_lds_bytes(int d) { return d == 768 ? MfmaDims<768>::kLds : MfmaDims<1024>::kLds; }
 constexpr int mfma_queries_per_launch(int d, int groups) { return 128 * groups; }
 
 struct MfmaArgs {
@@ -198,7 +200,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma_topk_kernel(MfmaArgs a) 
     constexpr int kKSteps = dims::kKSteps, kUnitSteps = dims::kUnitSteps, kUnits = dims::kUnits;
     constexpr int kUnitBytes = dims::kUnitBytes, kSlots = dims::kSlots, kPieces = dims::kPieces;
     constexpr int kAhead = dims::kAhead, kUnitK = dims::kUnitK;
-    static_assert(GROUPS == 1 || (GROUPS == 2 && D == 768), "two query groups per wave only fit at d = 768");
+    static_assert(GROUPS == 1 || (GROUPS == 2 && D <= 768), "two query groups per wave only fit up to d = 768");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -225,7 +227,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma_topk_kernel(MfmaArgs a) 
 
     // group A fragments of k-steps < kAV live in VGPRs, the rest in AGPRs (d = 1024: 256 registers of
     // one group do not fit the 256 architectural VGPRs next to everything else); group B all in AGPRs
-    constexpr int kAV = (D == 768) ? kKSteps : kKSteps / 2;
+    constexpr int kAV = (D <= 768) ? kKSteps : kKSteps / 2;
     bf16x8 qa[kAV], qa_hi[kKSteps > kAV ? kKSteps - kAV : 1], qb[GROUPS == 2 ? kKSteps : 1];
     {
         const bf16x8* pa = (const bf16x8*)(a.q + (int64_t)qid_a * D + 8 * h);

@@ -427,6 +427,8 @@ __global__ void init_thr_kernel(float* thr, int nq, int* fb_count, unsigned long
     }
 }
 
+static inline bool mfma_dim(int d) { return d == 384 || d == 512 || d == 768 || d == 1024; }
+
 static int ensure_search_scratch(ts_index* ix, int k) {
     size_t z = 0;
     if (!ix->qstore) {
@@ -454,7 +456,7 @@ static int ensure_search_scratch(ts_index* ix, int k) {
         TS_TRY(ensure(&p, &z, 16));
         ix->stat = (unsigned long long*)p;
     }
-    if (!ix->cand && ix->dtype == TS_BF16 && (ix->d == 768 || ix->d == 1024)) {
+    if (!ix->cand && ix->dtype == TS_BF16 && mfma_dim(ix->d)) {
         void* p = nullptr;
         z = 0;
         TS_TRY(ensure(&p, &z, (size_t)kQBlock * kCandCap * 8));
@@ -784,6 +786,8 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         hipEvent_t stop = full_pass ? prof_begin(ix, st, ix->n) : nullptr;  // only the full pass is bracketed
         int rc;
         if (ix->d == 1024) rc = launch_mfma<1024, 1>(full_pass, variant, grid, st, a);
+        else if (ix->d == 512) rc = (groups == 1) ? launch_mfma<512, 1>(full_pass, variant, grid, st, a) : launch_mfma<512, 2>(full_pass, variant, grid, st, a);
+        else if (ix->d == 384) rc = (groups == 1) ? launch_mfma<384, 1>(full_pass, variant, grid, st, a) : launch_mfma<384, 2>(full_pass, variant, grid, st, a);
         else if (groups == 1) rc = launch_mfma<768, 1>(full_pass, variant, grid, st, a);
         else rc = launch_mfma<768, 2>(full_pass, variant, grid, st, a);
         prof_end(stop, st);
@@ -842,9 +846,9 @@ static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_
     if (nq < 0) return fail(TS_ERR_INVALID, "nq = %d", nq);
     if (k < 1 || k > TS_MAX_K) return fail(TS_ERR_INVALID, "k = %d outside [1, %d]", k, TS_MAX_K);
     if (algo < TS_ALGO_AUTO || algo > TS_ALGO_MFMA) return fail(TS_ERR_INVALID, "algo %d", algo);
-    const bool mfma_ok = ix->dtype == TS_BF16 && (ix->d == 768 || ix->d == 1024) && ix->n >= 1;
+    const bool mfma_ok = ix->dtype == TS_BF16 && mfma_dim(ix->d) && ix->n >= 1;
     if (algo == TS_ALGO_MFMA && !mfma_ok)
-        return fail(TS_ERR_UNSUPPORTED, "the MFMA path needs a bf16 index with d = 768 or 1024");
+        return fail(TS_ERR_UNSUPPORTED, "the MFMA path needs a bf16 index with d = 384, 512, 768 or 1024");
     if (nq == 0) return TS_OK;
     std::lock_guard<std::mutex> lock(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));

@@ -29,7 +29,7 @@ def main():
     case = 0
     while time.time() < t_end:
         case += 1
-        d = int(rng.choice([768, 768, 768, 1024, 1024, 384, 40]))
+        d = int(rng.choice([768, 768, 768, 1024, 1024, 384, 384, 512, 512, 40]))
         dtype = str(rng.choice(["bf16", "bf16", "f32"]))
         metric = str(rng.choice(["cos", "ip"]))
         n = int(rng.choice([1, 33, 1000, 16384, 16385, 40000, 70001, 150000, 300000]))
@@ -42,7 +42,7 @@ def main():
             n = int(rng.choice([1_000_000, 1_700_001, 2_500_000]))
             nq = int(rng.choice([5, 16, 33, 130]))
             k = int(rng.choice([1, 10, 10, 50, 256]))
-        mfma_ok = dtype == "bf16" and d in (768, 1024)
+        mfma_ok = dtype == "bf16" and d in (384, 512, 768, 1024)
         algo = str(rng.choice(["auto", "scan", "mfma"])) if mfma_ok else str(rng.choice(["auto", "scan"]))
         if args.big:
             algo = "mfma"
