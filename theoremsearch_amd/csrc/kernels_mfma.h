@@ -1,4 +1,4 @@
-// Batched search, bf16, d = 768 or 1024: query x corpus contraction on the matrix cores with the top-k
+// Batched search, bf16, d = 768 or 1024 (and the narrower 384 / 512): query x corpus contraction on the matrix cores with the top-k
 // selection fused behind it.  The [nq x N] score matrix is never written.
 //
 // Replaces util.cos_sim(q_emb, s_emb) + np.argsort(-sim_matrix, axis=1) of the batched call
