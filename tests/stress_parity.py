@@ -2,7 +2,7 @@
 oracle's fp64 truth, for a fixed time budget.  Prints a line per case (so a stall is visible) and arms
 faulthandler so that a hung call dumps the Python stack and exits.
 
-    python tools/stress_parity.py --seconds 240 --seed 1
+    python tests/stress_parity.py --seconds 240 --seed 1
 """
 import argparse
 import faulthandler
