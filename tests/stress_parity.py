@@ -48,7 +48,7 @@ def main():
             algo = "mfma"
         if algo == "scan" and nq > 64:
             nq = int(rng.choice([1, 4, 7, 33]))          # the scan serves 4 queries per pass: keep the sweep moving
-        use_mask = algo != "mfma" and rng.random() < 0.2 and nq <= 8
+        use_mask = algo != "mfma" and rng.random() < 0.25 and (nq <= 8 or (mfma_ok and n >= 16384))
         seed = int(rng.integers(0, 2**31))
         faulthandler.dump_traceback_later(300 if args.big else 120, exit=True)
         t0 = time.time()
@@ -59,7 +59,7 @@ def main():
             u = q.mean(axis=0)
             members = rng.choice(n, n // 25, replace=False)
             c[members] += (rng.random(members.size).astype(np.float32) * np.float32(4.0))[:, None] * u
-        mask = (rng.random(n) < 0.3) if use_mask else None
+        mask = (rng.random(n) < float(rng.choice([0.05, 0.3, 0.8]))) if use_mask else None
         with ts.TheoremIndex.from_embeddings(c, dtype=dtype, metric=metric) as ix:
             if mask is not None:
                 scores, idx = ix.search(q, k, mask=mask)

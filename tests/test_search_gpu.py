@@ -347,6 +347,32 @@ def test_filtered_search_equals_search_of_the_allowed_rows(ts, dtype):
         check(q, c, "cos", dtype, k, s0, i0)
 
 
+@pytest.mark.parametrize("d", [768, 1024])
+def test_filtered_batches_run_on_the_mfma_path(ts, d):
+    """A batch behind a host mask that keeps >= 10 % of the rows goes through the MFMA kernel (bit tested in its append
+    path, threshold estimates made for the allowed rows); sparser masks through the scan.  Either way: the k best
+    ALLOWED rows, exactly."""
+    n, nq, k = 60_013, 40, 10
+    q, c = oracle.golden_inputs(n, nq, d, 91, "cos")
+    rng = np.random.default_rng(6)
+    with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="cos") as ix:
+        for frac in (0.9, 0.5, 0.15, 0.05, 0.0002):
+            mask = rng.random(n) < frac
+            mask[-1] = True
+            allowed = np.flatnonzero(mask)
+            scores, idx = ix.search(q, k, mask=mask)
+            m = min(k, allowed.size)
+            assert (idx[:, m:] == -1).all() and mask[idx[:, :m]].all()
+            qp, cp = oracle.prepared_inputs(q, c[allowed], "cos", "bf16")
+            truth = oracle.scores_fp64(qp, cp)
+            local = np.full_like(idx, -1)
+            local[:, :m] = np.searchsorted(allowed, idx[:, :m])
+            stats = oracle.check_topk_against_truth(truth, local, scores, k, gap=GAP, score_tol=SCORE_TOL)
+            assert stats["recall"] == 1.0
+        s_un, i_un = ix.search(q, k)                 # the next unfiltered batch is unaffected
+        check(q, c, "cos", "bf16", k, s_un, i_un)
+
+
 def test_subset_index_returns_the_ids_of_the_parent(ts):
     """ts_index_subset: a batch search of the copy = the filtered scan of the parent = the oracle over the allowed
     rows, with the parent's global ids (row_offset included); MFMA path and scan path of the copy."""

@@ -83,6 +83,7 @@ struct MfmaArgs {
     u64* cand;                     // [256][cap] shared spill lists
     u32* count;                    // [256]
     int cap;
+    const u32* row_mask;           // optional filter: bit (row & 31) of word row >> 5 set = the row may be returned
     int ahead;                     // units kept in flight by the DMA ring (1 .. kSlots - 1)
     int nq;                        // real queries of this launch: waves / groups holding only padding skip the matrix work
     unsigned long long* dbg;       // VARIANT 3 only: per-wave cycle sums
@@ -169,7 +170,8 @@ __device__ __forceinline__ void mfma_append(const f32x16& acc, float thr, int qi
         const int64_t row = row_base + (g & 3) + 8 * (g >> 2);
         const bool hit = (s >= thr) && (FULL || row < a.n);
         if (__any(hit)) {
-            if (hit) {
+            // metadata filter: tested only for scores that pass the threshold (a handful per query and pass)
+            if (hit && (!a.row_mask || ((a.row_mask[row >> 5] >> (row & 31)) & 1u))) {
                 const u64 key = make_key(s, (u32)row);
                 if (cnt < (u32)kMfmaPrivCap) {
                     mine[cnt] = key;

@@ -84,6 +84,7 @@ struct ts_index {
     bool borrowed = false;                                   // a view: rows / id_map belong to another handle
     void* rank_buf = nullptr;   size_t rank_bytes = 0;       // ts_rank_of: targets | counts | target scores, one query block
     const u32* active_mask = nullptr;                        // bitmask of the search in progress (under `mu`)
+    int64_t active_allowed = 0;                              // rows that bitmask allows (host masks: counted; else n)
     bool attr_done = false;
     // optional event brackets around the dominant kernel (ts_index_profile_*)
     bool profiling = false;
@@ -748,8 +749,10 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
     // under-filled query costs an exact scan pass), few enough that the append path (~0.27 us per candidate and
     // query, whatever N) stays cheap: 10M rows measured 3.91 / 3.94 / 4.02 ms per search at 128 / 256 / 512
     const int stat_cands = std::min(2048, std::max(env_int("TS_MFMA_STAT_CANDS", 128), 16 * kk));
+    // rows the candidates are drawn from: all of them, or the rows a filter allows (the sample sees only those too)
+    const int64_t pop = ix->active_mask ? ix->active_allowed : ix->n;
     const float z_tail = (statistical && lv.size() == 2)
-                             ? (float)normal_tail_z(std::min(0.25, (double)stat_cands / (double)std::max<int64_t>(ix->n, 1)))
+                             ? (float)normal_tail_z(std::min(0.25, (double)stat_cands / (double)std::max<int64_t>(pop, 1)))
                              : 0.0f;
     // Second estimate (exponential tail fit of the sample's order statistics, kernels_select.h), for score distributions
     // with heavier tails than a Gaussian.  Only where it is needed: when the guaranteed bound alone (the kk-th best of
@@ -758,7 +761,7 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
     const double sample_rows = (double)std::max<int64_t>(1, lv[0].ntiles * kTileRows);
     const bool bound_swamps = (double)kk * (double)ix->n / sample_rows > 0.5 * kCandCap;
     const float tail_p = (z_tail > 0.0f && bound_swamps && env_int("TS_MFMA_TAIL_FIT", 1))
-                             ? (float)std::min(0.25, (double)std::max(2048, 8 * kk) / (double)std::max<int64_t>(ix->n, 1))
+                             ? (float)std::min(0.25, (double)std::max(2048, 8 * kk) / (double)std::max<int64_t>(pop, 1))
                              : 0.0f;
     static unsigned long long* g_dbg = nullptr;  // diagnostics (TS_MFMA_VARIANT=3): per-wave cycle sums
     for (size_t i = 0; i < lv.size(); ++i) {
@@ -772,6 +775,7 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         a.q = (const unsigned short*)ix->qstore;
         a.thr = ix->thr;
         a.nq = env_int("TS_MFMA_NO_IDLE", 0) ? 256 : nq;
+        a.row_mask = ix->active_mask;
         a.ahead = env_int("TS_MFMA_AHEAD", 0);
         a.priv = ix->priv;
         a.pcount = ix->pcount;
@@ -818,7 +822,7 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         l.z_tail = full_pass ? 0.0f : z_tail;
         l.tail_p = full_pass ? 0.0f : tail_p;
         l.tail_z = (float)normal_tail_z(std::min(0.25, 32.0 / sample_rows));
-        l.min_fill = (z_tail > 0.0f) ? (int)std::min<int64_t>(k, ix->n) : 0;
+        l.min_fill = (z_tail > 0.0f) ? (int)std::min<int64_t>(k, pop) : 0;
         l.out_scores = out_scores;
         l.out_idx = out_idx;
         l.k_user = k;
@@ -867,7 +871,21 @@ static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_
             HIP_TRY(hipMemcpyAsync(ix->mask_dev, row_mask, words * 4, hipMemcpyHostToDevice, st));
             ix->active_mask = ix->mask_dev;
         }
-        algo = TS_ALGO_SCAN;  // the filter is applied by the scan kernel
+        // Batches behind a host mask that keeps at least a tenth of the rows run the MFMA path: the bit is tested in its
+        // append path and the threshold estimates are made for the allowed rows (the sample sees only those).  Sparser
+        // masks leave the sample too few allowed rows to estimate from; device masks would need a count + sync first:
+        // both go through the scan kernel, 4 queries per pass (or through a subset index).
+        bool dense_host_mask = false;
+        if (!mask_on_device && mfma_dim(ix->d) && ix->dtype == TS_BF16 && nq > env_int("TS_SCAN_MAX_QUERIES", 4) &&
+            ix->n >= env_int("TS_MFMA_MIN_ROWS", 16384) && algo != TS_ALGO_SCAN) {
+            int64_t allowed = 0;
+            for (size_t w = 0; w < words; ++w) allowed += __builtin_popcount(row_mask[w]);
+            const int64_t tail_bits = (int64_t)words * 32 - ix->n;   // bits past the last row do not count
+            if (tail_bits > 0 && words > 0) allowed -= __builtin_popcount(row_mask[words - 1] >> (32 - tail_bits));
+            ix->active_allowed = allowed;
+            dense_host_mask = allowed * 10 >= ix->n;
+        }
+        algo = dense_host_mask ? TS_ALGO_MFMA : TS_ALGO_SCAN;
     }
     int use = algo;
     // The scan serves 4 queries per pass at the HBM rate; the MFMA path serves up to 256 per pass but its pass is
@@ -948,7 +966,7 @@ extern "C" int ts_search_filtered(ts_index* ix, const void* queries, int q_dtype
                                   const uint32_t* row_mask, int mask_on_device, float* out_scores, int64_t* out_idx,
                                   int out_on_device, void* stream) {
     if (!row_mask) return fail(TS_ERR_INVALID, "row_mask is NULL");
-    return search_impl(ix, queries, q_dtype, q_on_device, nq, k, out_scores, out_idx, out_on_device, stream, TS_ALGO_SCAN,
+    return search_impl(ix, queries, q_dtype, q_on_device, nq, k, out_scores, out_idx, out_on_device, stream, TS_ALGO_AUTO,
                        nullptr, row_mask, mask_on_device);
 }
 
