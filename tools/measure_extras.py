@@ -67,6 +67,9 @@ def main():
         if dtype == "bf16":
             # filtered batch search: copy the allowed rows once, then unfiltered batch-256 searches of the copy
             q256 = synthetic.synth_queries(2, 256)
+            mask50 = rng.random(n) < 0.5
+            res["search_b256_mask50pct_mfma"] = timed(ix, lambda: ix.search(q256, 10, mask=mask50))
+            res["search_b256_unfiltered"] = timed(ix, lambda: ix.search(q256, 10))
             t0 = time.perf_counter()
             sub = ix.subset(mask)
             t_build = time.perf_counter() - t0
