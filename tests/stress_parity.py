@@ -45,10 +45,10 @@ def main():
         mfma_ok = dtype == "bf16" and d in (384, 512, 768, 1024)
         algo = str(rng.choice(["auto", "scan", "mfma"])) if mfma_ok else str(rng.choice(["auto", "scan"]))
         if args.big:
-            algo = "mfma"
+            algo = "auto" if rng.random() < 0.4 else "mfma"     # "auto" may carry a dense host mask (masked MFMA pass)
         if algo == "scan" and nq > 64:
             nq = int(rng.choice([1, 4, 7, 33]))          # the scan serves 4 queries per pass: keep the sweep moving
-        use_mask = algo != "mfma" and rng.random() < 0.25 and (nq <= 8 or (mfma_ok and n >= 16384))
+        use_mask = algo != "mfma" and rng.random() < (0.7 if args.big else 0.25) and (nq <= 8 or (mfma_ok and n >= 16384))
         seed = int(rng.integers(0, 2**31))
         faulthandler.dump_traceback_later(300 if args.big else 120, exit=True)
         t0 = time.time()
