@@ -19,7 +19,11 @@
  *     (score = -inf, index = -1).
  *   - a stream argument is a hipStream_t passed as void* (NULL = the index's own stream).  With
  *     host output buffers the call returns after the results have landed; with device buffers
- *     it returns after enqueueing the work on that stream.
+ *     it returns after enqueueing the work on that stream.  The index's own stream is a blocking
+ *     stream: it is ordered with the legacy null stream, so NULL is also the right value for work
+ *     that lives on the default stream of the caller (torch.cuda.current_stream().cuda_stream is 0
+ *     there).  A call that arrives on a different stream than the previous call on the same handle
+ *     is ordered behind that call by the library (the handle's scratch buffers are shared).
  *   - one handle may be used from several threads (the Streamlit apps share one model and one
  *     library across session threads, streamlit_app.py:52); calls on one handle are serialised
  *     inside, different handles are independent.
@@ -88,8 +92,16 @@ int ts_index_destroy(ts_index *ix);
 int ts_index_set_row_offset(ts_index *ix, int64_t row_offset);
 /* The index's own HIP stream (hipStream_t as void*): what stream = NULL means in the calls below. */
 int ts_index_stream(const ts_index *ix, void **stream);
+/* Waits until everything this handle has enqueued (on its own stream and on the stream of its last call) is done. */
+int ts_index_synchronize(ts_index *ix);
 int ts_index_info(const ts_index *ix, int64_t *n, int32_t *d, int32_t *dtype, int32_t *metric,
                   int64_t *ld_elems, int64_t *row_offset, void **device_rows);
+
+/* Tuning / diagnostic options of one handle (the TS_* knobs of DESIGN.md section 8, e.g. "TS_MFMA_FIRST_ROWS").  Their
+ * initial values are read from the environment once, when the handle is created; afterwards only these calls change
+ * them (the search path never calls getenv).  reset = back to the built-in default.  The reference has no counterpart. */
+int ts_index_set_option(ts_index *ix, const char *name, int32_t value);
+int ts_index_reset_option(ts_index *ix, const char *name);
 
 /* Rows [row0, row0 + nrows) from host memory (src_dtype TS_F32 or TS_BF16, dense [nrows x d]).
  * Replaces building the corpus tensor (app_create_embeddings.py:81-89) and the per-row INSERT /
@@ -99,6 +111,16 @@ int ts_index_upload(ts_index *ix, const void *host_rows, int src_dtype, int64_t 
  * goes straight into the index without a host hop. */
 int ts_index_upload_device(ts_index *ix, const void *dev_rows, int src_dtype, int64_t src_ld,
                            int64_t row0, int64_t nrows, void *stream);
+/* Growth ("incremental append mirroring the upsert-by-slogan_id semantics",
+ * ec2/generate_embeddings/__main__.py:85-99 - a slogan_id that is not in the table yet is INSERTed).  ts_index_reserve
+ * makes room for `capacity_rows` rows without changing n; ts_index_append* add nrows rows behind the last one (growing
+ * the allocation 1.5x when it is full: one device-to-device move of the rows) and return the global id of the first
+ * new row.  Not on views / subset indexes, and refused (TS_ERR_UNSUPPORTED) while views of the index are alive.
+ * Views and subsets made earlier do not see the new rows. */
+int ts_index_reserve(ts_index *ix, int64_t capacity_rows);
+int ts_index_append(ts_index *ix, const void *host_rows, int src_dtype, int64_t nrows, int64_t *first_row);
+int ts_index_append_device(ts_index *ix, const void *dev_rows, int src_dtype, int64_t src_ld, int64_t nrows,
+                           void *stream, int64_t *first_row);
 /* Stored rows back to the host in the storage dtype, dense [nrows x d] (what the kernels multiply). */
 int ts_index_download(ts_index *ix, void *host_rows, int64_t row0, int64_t nrows);
 
@@ -152,6 +174,12 @@ int ts_search_filtered(ts_index *ix, const void *queries, int q_dtype, int q_on_
                        const uint32_t *row_mask, int mask_on_device, float *out_scores, int64_t *out_idx,
                        int out_on_device, void *stream);
 
+/* The same with an algorithm hint (TS_ALGO_SCAN is honoured; TS_ALGO_MFMA is refused with TS_ERR_UNSUPPORTED when the mask is
+ * too sparse or lives on the device; TS_ALGO_AUTO decides by the mask's density) and the per-call counters. */
+int ts_search_filtered_ex(ts_index *ix, const void *queries, int q_dtype, int q_on_device, int32_t nq, int32_t k,
+                          const uint32_t *row_mask, int mask_on_device, float *out_scores, int64_t *out_idx,
+                          int out_on_device, void *stream, int algo, ts_search_stats *stats);
+
 /* Rank of one given row per query in the canonical order of that query's scores over the whole index (0 = best):
  * the number of rows whose (score, -row) beats the target's.  One streaming pass that counts; replaces ranking the
  * full [nq x N] matrix and looking the relevant document up - np.argsort(-sim_matrix) followed by the position of
@@ -187,6 +215,44 @@ int ts_merge_topk(int device, const float *scores, const int64_t *idx, int32_t n
 int ts_merge_topk_packed(int device, const void *packed, int64_t part_stride_bytes, int64_t idx_offset_bytes,
                          int32_t nparts, int32_t nq, int32_t k_in, int32_t k_out, float *out_scores,
                          int64_t *out_idx, void *stream);
+
+/* ---- row-sharded search over RCCL (BASELINE.json configs[3]) -------------------------------
+ * The corpus row-shards over the GPUs of one node: GPU g holds rows [g N / G, (g+1) N / G) in its own ts_index whose
+ * row_offset makes the ids global; every GPU searches its shard for the (replicated) query batch; ONE ncclAllGather
+ * over xGMI exchanges the packed per-shard top-k (12 * nq * k bytes per rank) and a merge kernel reduces the G * k
+ * candidates per query.  The exchange lives in this library (RCCL bound by dlopen at first use; TS_RCCL_LIB names the
+ * file when the process has not loaded one yet): no torch.distributed, no MPI on the search path.
+ *
+ * ts_comm_*: one member per PROCESS (one process per GPU, the torch.distributed.run model).  Rank 0 calls
+ * ts_comm_unique_id and hands the 128 bytes to the other ranks by whatever channel the launcher has (a file, a TCP
+ * store); every rank then calls ts_comm_create (collective).  ts_comm_search enqueues on `stream` the local search of
+ * `shard`, the all-gather and the merge; every rank receives the global answer (device or host buffers as in
+ * ts_search).  ts_comm_allgather is the bare collective on device buffers (recv holds world * bytes). */
+typedef struct ts_comm ts_comm;
+#define TS_COMM_ID_BYTES 128
+int ts_comm_unique_id(void *id_out, int32_t id_bytes);
+int ts_comm_create(int device, int32_t world, int32_t rank, const void *id, int32_t id_bytes, ts_comm **out);
+int ts_comm_destroy(ts_comm *c);
+int ts_comm_info(const ts_comm *c, int32_t *world, int32_t *rank, int32_t *device);
+int ts_comm_allgather(ts_comm *c, const void *send_dev, void *recv_dev, int64_t bytes, void *stream);
+int ts_comm_search(ts_comm *c, ts_index *shard, const void *queries, int q_dtype, int q_on_device, int32_t nq, int32_t k,
+                   float *out_scores, int64_t *out_idx, int out_on_device, void *stream);
+
+/* ts_shards_*: ONE process drives all the GPUs (ncclCommInitAll, one stream per device) - what a serving process such
+ * as the Streamlit app would hold instead of one ts_index.  devices = NULL means 0 .. ngpu-1; a device id may repeat
+ * (several shards on one GPU, for rehearsing the path on a one-GPU box: the exchange then uses device copies, RCCL
+ * refuses two ranks on one GPU).  ts_shards_upload routes global rows to their shards; ts_shards_shard lends the
+ * ts_index of shard g (rows [*lo, *hi)) for device uploads / options / profiling; ts_shards_search takes host queries
+ * and returns host results. */
+typedef struct ts_shards ts_shards;
+int ts_shards_create(int32_t ngpu, const int32_t *devices, int64_t n_total, int32_t d, int dtype, int metric,
+                     ts_shards **out);
+int ts_shards_destroy(ts_shards *s);
+int ts_shards_info(const ts_shards *s, int32_t *ngpu, int64_t *n_total, int32_t *uses_rccl);
+int ts_shards_shard(ts_shards *s, int32_t g, ts_index **ix, int64_t *lo, int64_t *hi);
+int ts_shards_upload(ts_shards *s, const void *host_rows, int src_dtype, int64_t row0, int64_t nrows);
+int ts_shards_search(ts_shards *s, const void *queries, int q_dtype, int32_t nq, int32_t k, float *out_scores,
+                     int64_t *out_idx);
 
 /* ---- encoder epilogue ------------------------------------------------
  * Pooling + optional L2 normalisation + cast of a transformer's last hidden state, fused in one kernel that

@@ -222,7 +222,6 @@ def test_clustered_corpus_is_served_without_reruns(ts):
     exponential tail fit of the sample's order statistics holds the candidate count near its target instead.
     Scaled down to a test by a small sample (TS_MFMA_FIRST_ROWS) and k = 50: with the fit no re-runs, without it
     all queries overflow; the answers are exact and identical either way."""
-    import os
     rng = np.random.default_rng(71)
     n, d, nq, k = 300_000, 768, 16, 50
     c = rng.standard_normal((n, d), dtype=np.float32) * np.float32(1 / np.sqrt(d))
@@ -231,22 +230,17 @@ def test_clustered_corpus_is_served_without_reruns(ts):
     members = rng.choice(n, n // 20, replace=False)
     c[members] += (0.5 + 0.1 * rng.standard_normal(members.size)).astype(np.float32)[:, None] * u
     q = u + rng.standard_normal((nq, d)).astype(np.float32) * np.float32(0.2 / np.sqrt(d))
-    os.environ["TS_MFMA_FIRST_ROWS"] = "2048"
-    try:
-        with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as ix:
-            scores, idx, st = ix.search(q, k, algo="mfma", return_stats=True)
-            check(q, c, "ip", "bf16", k, scores, idx)
-            assert st["fallback_queries"] == 0
-            assert k * nq <= st["candidates"] < nq * 4096
-            os.environ["TS_MFMA_TAIL_FIT"] = "0"
-            try:
-                s0, i0, st0 = ix.search(q, k, algo="mfma", return_stats=True)
-            finally:
-                del os.environ["TS_MFMA_TAIL_FIT"]
-            check(q, c, "ip", "bf16", k, s0, i0)                # exact either way (through the re-run)
-            assert st0["fallback_queries"] > 0 and st0["candidates"] > 3 * st["candidates"], (st, st0)
-    finally:
-        del os.environ["TS_MFMA_FIRST_ROWS"]
+    with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as ix:
+        ix.set_option("TS_MFMA_FIRST_ROWS", 2048)
+        scores, idx, st = ix.search(q, k, algo="mfma", return_stats=True)
+        check(q, c, "ip", "bf16", k, scores, idx)
+        assert st["fallback_queries"] == 0
+        assert k * nq <= st["candidates"] < nq * 4096
+        ix.set_option("TS_MFMA_TAIL_FIT", 0)
+        s0, i0, st0 = ix.search(q, k, algo="mfma", return_stats=True)
+        ix.set_option("TS_MFMA_TAIL_FIT", None)
+        check(q, c, "ip", "bf16", k, s0, i0)                # exact either way (through the re-run)
+        assert st0["fallback_queries"] > 0 and st0["candidates"] > 3 * st["candidates"], (st, st0)
 
 
 def test_candidate_overflow_falls_back_exactly(ts):

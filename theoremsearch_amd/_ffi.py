@@ -45,12 +45,19 @@ _SIGNATURES = {
     "ts_index_create": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "ts_index_destroy": (C.c_int, [C.c_void_p]),
     "ts_index_set_row_offset": (C.c_int, [C.c_void_p, C.c_int64]),
+    "ts_index_synchronize": (C.c_int, [C.c_void_p]),
     "ts_index_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "ts_index_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                 C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                 C.POINTER(C.c_void_p)]),
+    "ts_index_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
+    "ts_index_reset_option": (C.c_int, [C.c_void_p, C.c_char_p]),
     "ts_index_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64]),
     "ts_index_upload_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+    "ts_index_reserve": (C.c_int, [C.c_void_p, C.c_int64]),
+    "ts_index_append": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_int64)]),
+    "ts_index_append_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
+                                         C.POINTER(C.c_int64)]),
     "ts_index_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
     "ts_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                             C.c_int, C.c_void_p]),
@@ -62,6 +69,8 @@ _SIGNATURES = {
     "ts_index_subset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),
     "ts_search_filtered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "ts_search_filtered_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(SearchStats)]),
     "ts_rank_of": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p]),
     "ts_count_above": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -71,6 +80,19 @@ _SIGNATURES = {
                                 C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ts_merge_topk_packed": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ts_comm_unique_id": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ts_comm_create": (C.c_int, [C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
+    "ts_comm_destroy": (C.c_int, [C.c_void_p]),
+    "ts_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "ts_comm_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "ts_comm_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_int32, C.c_void_p,
+                                 C.c_void_p, C.c_int, C.c_void_p]),
+    "ts_shards_create": (C.c_int, [C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "ts_shards_destroy": (C.c_int, [C.c_void_p]),
+    "ts_shards_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "ts_shards_shard": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "ts_shards_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64]),
+    "ts_shards_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "ts_pool_normalize": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int, C.c_int,
                                     C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     "ts_index_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),

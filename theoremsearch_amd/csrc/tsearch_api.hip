@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cctype>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -50,10 +51,30 @@ static int fail(int code, const char* fmt, ...) {
         if (rc_ != TS_OK) return rc_; \
     } while (0)
 
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
+// Tuning / diagnostic knobs.  Read from the environment ONCE per handle (ts_index_create / ts_index_view /
+// ts_index_subset), changed afterwards only through ts_index_set_option: no getenv on the search path.
+enum Knob {
+    K_MFMA_MIN_RANK, K_MFMA_VARIANT, K_MFMA_GROUPS, K_MFMA_GRID, K_MFMA_STAT, K_MFMA_STAT_CANDS, K_MFMA_TAIL_FIT,
+    K_MFMA_NO_IDLE, K_MFMA_AHEAD, K_MFMA_TARGET_CANDS, K_MFMA_FIRST_ROWS, K_MFMA_TARGET_SPARSE, K_MFMA_RUN,
+    K_MFMA_MIN_ROWS, K_MFMA_SHAPE, K_MFMA_F32, K_SCAN_GENERIC, K_SCAN_MAX_QUERIES, K_COUNT
+};
+static const char* const kKnobNames[K_COUNT] = {
+    "TS_MFMA_MIN_RANK", "TS_MFMA_VARIANT", "TS_MFMA_GROUPS", "TS_MFMA_GRID", "TS_MFMA_STAT", "TS_MFMA_STAT_CANDS",
+    "TS_MFMA_TAIL_FIT", "TS_MFMA_NO_IDLE", "TS_MFMA_AHEAD", "TS_MFMA_TARGET_CANDS", "TS_MFMA_FIRST_ROWS",
+    "TS_MFMA_TARGET_SPARSE", "TS_MFMA_RUN", "TS_MFMA_MIN_ROWS", "TS_MFMA_SHAPE", "TS_MFMA_F32", "TS_SCAN_GENERIC",
+    "TS_SCAN_MAX_QUERIES"};
+struct Knobs {
+    int v[K_COUNT];
+    bool set[K_COUNT];
+    Knobs() {
+        for (int i = 0; i < K_COUNT; ++i) {
+            const char* e = getenv(kKnobNames[i]);
+            set[i] = e && *e;
+            v[i] = set[i] ? atoi(e) : 0;
+        }
+    }
+    int get(Knob k, int dflt) const { return set[k] ? v[k] : dflt; }
+};
 
 // ---------------------------------------------------------------------------------------------
 // handles
@@ -82,10 +103,16 @@ struct ts_index {
     u32* mask_dev = nullptr;    size_t mask_bytes = 0;       // filtered search: device copy of a host bitmask
     int64_t* id_map = nullptr;                               // subset index: local row -> global id
     bool borrowed = false;                                   // a view: rows / id_map belong to another handle
+    ts_index* parent = nullptr;                              // a view: the handle that owns the rows
+    std::atomic<int> nviews{0};                              // live views of this handle (it cannot grow meanwhile)
     void* rank_buf = nullptr;   size_t rank_bytes = 0;       // ts_rank_of: targets | counts | target scores, one query block
     const u32* active_mask = nullptr;                        // bitmask of the search in progress (under `mu`)
     int64_t active_allowed = 0;                              // rows that bitmask allows (host masks: counted; else n)
     bool attr_done = false;
+    Knobs knobs;                                             // env at creation, then ts_index_set_option
+    hipStream_t last_stream = nullptr;                       // stream of the previous call that used the scratch buffers
+    hipEvent_t order_ev = nullptr;                           // orders a call on another stream behind it
+    unsigned long long* dbg = nullptr;                       // TS_MFMA_VARIANT=3: per-wave cycle sums
     // optional event brackets around the dominant kernel (ts_index_profile_*)
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;   // pairs: [2i] start, [2i+1] stop
@@ -130,6 +157,31 @@ static hipEvent_t prof_begin(ts_index* ix, hipStream_t st, int64_t rows) {
 static void prof_end(hipEvent_t stop, hipStream_t st) {
     if (stop) hipEventRecord(stop, st);
 }
+
+// Stream of this call (NULL = the index's own).  The per-handle scratch buffers are shared by all calls: when the
+// previous call was enqueued on ANOTHER stream, this one is ordered behind it (event record + wait), so that a
+// second call never overwrites scratch the first one still reads.  Called under ix->mu.
+// The index's own stream is a BLOCKING stream: it orders with the legacy null stream, which is what a torch
+// default stream's handle (0 = NULL here) means - encoder kernels before an upload / search, torch ops after it.
+static int enter_stream(ts_index* ix, void* stream, hipStream_t* out) {
+    hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
+    if (ix->last_stream && ix->last_stream != st) {
+        if (!ix->order_ev) HIP_TRY(hipEventCreateWithFlags(&ix->order_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ix->order_ev, ix->last_stream));
+        HIP_TRY(hipStreamWaitEvent(st, ix->order_ev, 0));
+    }
+    ix->last_stream = st;
+    *out = st;
+    return TS_OK;
+}
+
+// Device buffer freed on every return path.
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <class T> T* as() const { return (T*)p; }
+};
 
 // ---------------------------------------------------------------------------------------------
 // library / device
@@ -200,7 +252,7 @@ extern "C" int ts_index_create(int device, int64_t n, int32_t d, int dtype, int 
         delete ix;
         return fail(TS_ERR_NOMEM, "hipMalloc of %zu bytes for the index failed: %s", bytes, hipGetErrorString(e));
     }
-    e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
+    e = hipStreamCreateWithFlags(&ix->stream, hipStreamDefault);
     if (e == hipSuccess) e = hipMemsetAsync(ix->rows, 0, bytes, ix->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
     if (e != hipSuccess) {
@@ -231,10 +283,12 @@ extern "C" int ts_index_view(ts_index* src, ts_index** out) {
     ix->rows = src->rows;
     ix->id_map = src->id_map;
     ix->borrowed = true;
-    if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&ix->stream, hipStreamDefault) != hipSuccess) {
         delete ix;
         return fail(TS_ERR_HIP, "stream creation failed");
     }
+    ix->parent = src;
+    src->nviews.fetch_add(1);
     *out = ix;
     return TS_OK;
 }
@@ -246,12 +300,14 @@ extern "C" int ts_index_destroy(ts_index* ix) {
     if (ix->borrowed) {
         ix->rows = nullptr;
         ix->id_map = nullptr;
+        if (ix->parent) ix->parent->nviews.fetch_sub(1);
     }
     void* ptrs[] = {ix->rows,  ix->stage,   ix->qstore,   ix->qf32,     ix->cand,       ix->count,  ix->thr, ix->priv, ix->pcount, ix->mask_dev, ix->rank_buf, ix->id_map,
-                    ix->fb_list, ix->fb_count, ix->stat, ix->partial, ix->partial2, ix->res_scores, ix->res_idx};
+                    ix->fb_list, ix->fb_count, ix->stat, ix->partial, ix->partial2, ix->res_scores, ix->res_idx, ix->dbg};
     for (void* p : ptrs)
         if (p) hipFree(p);
     for (hipEvent_t e : ix->ev_pool) hipEventDestroy(e);
+    if (ix->order_ev) hipEventDestroy(ix->order_ev);
     if (ix->stream) hipStreamDestroy(ix->stream);
     delete ix;
     return TS_OK;
@@ -261,6 +317,29 @@ extern "C" int ts_index_set_row_offset(ts_index* ix, int64_t off) {
     if (!ix || off < 0) return fail(TS_ERR_INVALID, "bad argument");
     ix->row_offset = off;
     return TS_OK;
+}
+
+extern "C" int ts_index_set_option(ts_index* ix, const char* name, int32_t value) {
+    if (!ix || !name) return fail(TS_ERR_INVALID, "NULL argument");
+    for (int i = 0; i < K_COUNT; ++i)
+        if (!strcmp(name, kKnobNames[i])) {
+            std::lock_guard<std::mutex> lock(ix->mu);
+            ix->knobs.v[i] = value;
+            ix->knobs.set[i] = true;
+            return TS_OK;
+        }
+    return fail(TS_ERR_INVALID, "unknown option '%s'", name);
+}
+
+extern "C" int ts_index_reset_option(ts_index* ix, const char* name) {
+    if (!ix || !name) return fail(TS_ERR_INVALID, "NULL argument");
+    for (int i = 0; i < K_COUNT; ++i)
+        if (!strcmp(name, kKnobNames[i])) {
+            std::lock_guard<std::mutex> lock(ix->mu);
+            ix->knobs.set[i] = false;
+            return TS_OK;
+        }
+    return fail(TS_ERR_INVALID, "unknown option '%s'", name);
 }
 
 extern "C" int ts_index_subset(ts_index* src, const int64_t* rows, int64_t nrows, ts_index** out) {
@@ -295,6 +374,15 @@ extern "C" int ts_index_subset(ts_index* src, const int64_t* rows, int64_t nrows
         return fail(TS_ERR_HIP, "subset copy failed: %s", hipGetErrorString(e));
     }
     *out = ix;
+    return TS_OK;
+}
+
+extern "C" int ts_index_synchronize(ts_index* ix) {
+    if (!ix) return fail(TS_ERR_INVALID, "index is NULL");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    if (ix->last_stream && ix->last_stream != ix->stream) HIP_TRY(hipStreamSynchronize(ix->last_stream));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
     return TS_OK;
 }
 
@@ -342,40 +430,43 @@ static int prep_dispatch(int src_dtype, int dst_dtype, bool normalize, const voi
     return TS_OK;
 }
 
-static int check_rows(const ts_index* ix, const void* p, int src_dtype, int64_t row0, int64_t nrows) {
+static int check_rows(const ts_index* ix, const void* p, int src_dtype, int64_t row0, int64_t nrows, bool write) {
     if (!ix || !p) return fail(TS_ERR_INVALID, "NULL argument");
     if (src_dtype != TS_F32 && src_dtype != TS_BF16) return fail(TS_ERR_INVALID, "src_dtype %d", src_dtype);
-    if (ix->id_map) return fail(TS_ERR_UNSUPPORTED, "a subset index is read-only");
-    if (ix->borrowed) return fail(TS_ERR_UNSUPPORTED, "a view is read-only: upload through the handle that owns the rows");
+    if (write && ix->id_map) return fail(TS_ERR_UNSUPPORTED, "a subset index is read-only");
+    if (write && ix->borrowed) return fail(TS_ERR_UNSUPPORTED, "a view is read-only: upload through the handle that owns the rows");
     if (row0 < 0 || nrows < 0 || row0 + nrows > ix->n)
         return fail(TS_ERR_INVALID, "rows [%lld, %lld) outside the index of %lld rows", (long long)row0,
                     (long long)(row0 + nrows), (long long)ix->n);
     return TS_OK;
 }
 
-extern "C" int ts_index_upload_device(ts_index* ix, const void* dev_rows, int src_dtype, int64_t src_ld, int64_t row0,
-                                      int64_t nrows, void* stream) {
-    TS_TRY(check_rows(ix, dev_rows, src_dtype, row0, nrows));
+// Uploads: the *_locked forms run under ix->mu (the public entry points and the append calls take it).
+static int upload_device_locked(ts_index* ix, const void* dev_rows, int src_dtype, int64_t src_ld, int64_t row0, int64_t nrows,
+                                void* stream) {
+    TS_TRY(check_rows(ix, dev_rows, src_dtype, row0, nrows, true));
     if (src_ld < ix->d) return fail(TS_ERR_INVALID, "src_ld %lld < d %d", (long long)src_ld, ix->d);
     if (nrows == 0) return TS_OK;
-    std::lock_guard<std::mutex> lock(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));
-    hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
+    hipStream_t st;
+    TS_TRY(enter_stream(ix, stream, &st));
     char* dst = (char*)ix->rows + (size_t)row0 * ix->ld * ix->elem();
     return prep_dispatch(src_dtype, ix->dtype, ix->metric == TS_METRIC_COS, dev_rows, src_ld, dst, nullptr, ix->ld, ix->d,
                          nrows, nrows, st);
 }
 
-extern "C" int ts_index_upload(ts_index* ix, const void* host_rows, int src_dtype, int64_t row0, int64_t nrows) {
-    TS_TRY(check_rows(ix, host_rows, src_dtype, row0, nrows));
+static int upload_host_locked(ts_index* ix, const void* host_rows, int src_dtype, int64_t row0, int64_t nrows) {
+    TS_TRY(check_rows(ix, host_rows, src_dtype, row0, nrows, true));
     if (nrows == 0) return TS_OK;
-    std::lock_guard<std::mutex> lock(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));
     const size_t src_elem = src_dtype == TS_BF16 ? 2 : 4;
     const size_t src_row = (size_t)ix->d * src_elem;
+    hipStream_t own;
+    TS_TRY(enter_stream(ix, nullptr, &own));   // rows / the stage buffer may still feed a call enqueued on a caller's stream
     if (src_dtype == ix->dtype && ix->metric == TS_METRIC_IP && ix->ld == ix->d) {
         // stored as given: straight copy into place
-        HIP_TRY(hipMemcpy((char*)ix->rows + (size_t)row0 * src_row, host_rows, (size_t)nrows * src_row, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpyAsync((char*)ix->rows + (size_t)row0 * src_row, host_rows, (size_t)nrows * src_row, hipMemcpyHostToDevice, own));
+        HIP_TRY(hipStreamSynchronize(own));
         return TS_OK;
     }
     TS_TRY(ensure(&ix->stage, &ix->stage_bytes, kStageBytes));
@@ -383,22 +474,108 @@ extern "C" int ts_index_upload(ts_index* ix, const void* host_rows, int src_dtyp
     for (int64_t r = 0; r < nrows; r += rows_per) {
         const int64_t cnt = std::min(rows_per, nrows - r);
         HIP_TRY(hipMemcpyAsync(ix->stage, (const char*)host_rows + (size_t)r * src_row, (size_t)cnt * src_row,
-                               hipMemcpyHostToDevice, ix->stream));
+                               hipMemcpyHostToDevice, own));
         char* dst = (char*)ix->rows + (size_t)(row0 + r) * ix->ld * ix->elem();
         TS_TRY(prep_dispatch(src_dtype, ix->dtype, ix->metric == TS_METRIC_COS, ix->stage, ix->d, dst, nullptr, ix->ld,
-                             ix->d, cnt, cnt, ix->stream));
-        HIP_TRY(hipStreamSynchronize(ix->stream));  // the stage buffer is reused by the next chunk
+                             ix->d, cnt, cnt, own));
+        HIP_TRY(hipStreamSynchronize(own));  // the stage buffer is reused by the next chunk
     }
     return TS_OK;
 }
 
-extern "C" int ts_index_download(ts_index* ix, void* host_rows, int64_t row0, int64_t nrows) {
-    TS_TRY(check_rows(ix, host_rows, ix ? ix->dtype : 0, row0, nrows));
-    if (nrows == 0) return TS_OK;
+extern "C" int ts_index_upload_device(ts_index* ix, const void* dev_rows, int src_dtype, int64_t src_ld, int64_t row0,
+                                      int64_t nrows, void* stream) {
+    if (!ix) return fail(TS_ERR_INVALID, "index is NULL");
     std::lock_guard<std::mutex> lock(ix->mu);
+    return upload_device_locked(ix, dev_rows, src_dtype, src_ld, row0, nrows, stream);
+}
+
+extern "C" int ts_index_upload(ts_index* ix, const void* host_rows, int src_dtype, int64_t row0, int64_t nrows) {
+    if (!ix) return fail(TS_ERR_INVALID, "index is NULL");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    return upload_host_locked(ix, host_rows, src_dtype, row0, nrows);
+}
+
+// ---- growth: reserve / append ------------------------------------------------------
+// The allocation holds n_pad rows (a multiple of 256, zero beyond n); appending past it moves the rows to a larger
+// allocation (1.5x, at least what is asked).  Refused while views of the index exist (they hold the old pointer).
+static int grow_locked(ts_index* ix, int64_t want_rows) {
+    if (want_rows > 0xFFFFFFF0ll) return fail(TS_ERR_INVALID, "capacity %lld out of range", (long long)want_rows);
+    const int64_t new_pad = std::max<int64_t>(kRowPad, (want_rows + kRowPad - 1) / kRowPad * kRowPad);
+    if (new_pad <= ix->n_pad) return TS_OK;
+    if (ix->borrowed || ix->id_map) return fail(TS_ERR_UNSUPPORTED, "a view / subset index cannot grow");
+    if (ix->nviews.load() > 0) return fail(TS_ERR_UNSUPPORTED, "the index has %d live views: destroy them before growing it", ix->nviews.load());
+    HIP_TRY(hipSetDevice(ix->device));
+    const size_t row_bytes = (size_t)ix->ld * ix->elem();
+    const size_t old_bytes = (size_t)ix->n_pad * row_bytes, new_bytes = (size_t)new_pad * row_bytes;
+    void* fresh = nullptr;
+    hipError_t e = hipMalloc(&fresh, new_bytes);
+    if (e != hipSuccess) return fail(TS_ERR_NOMEM, "hipMalloc of %zu bytes for the grown index failed: %s", new_bytes, hipGetErrorString(e));
+    hipStream_t own;
+    int rc = enter_stream(ix, nullptr, &own);
+    if (rc == TS_OK) {
+        e = hipMemcpyAsync(fresh, ix->rows, old_bytes, hipMemcpyDeviceToDevice, own);
+        if (e == hipSuccess) e = hipMemsetAsync((char*)fresh + old_bytes, 0, new_bytes - old_bytes, own);
+        if (e == hipSuccess) e = hipStreamSynchronize(own);
+        if (e != hipSuccess) rc = fail(TS_ERR_HIP, "moving the rows failed: %s", hipGetErrorString(e));
+    }
+    if (rc != TS_OK) {
+        hipFree(fresh);
+        return rc;
+    }
+    hipFree(ix->rows);
+    ix->rows = fresh;
+    ix->n_pad = new_pad;
+    return TS_OK;
+}
+
+extern "C" int ts_index_reserve(ts_index* ix, int64_t capacity_rows) {
+    if (!ix || capacity_rows < 0) return fail(TS_ERR_INVALID, "bad argument");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    return grow_locked(ix, capacity_rows);
+}
+
+static int append_locked(ts_index* ix, int64_t nrows, int64_t* first_row) {
+    if (nrows < 0) return fail(TS_ERR_INVALID, "nrows = %lld", (long long)nrows);
+    if (ix->borrowed || ix->id_map) return fail(TS_ERR_UNSUPPORTED, "a view / subset index is read-only");
+    if (ix->n + nrows > ix->n_pad) TS_TRY(grow_locked(ix, std::max(ix->n + nrows, ix->n_pad + ix->n_pad / 2)));
+    if (first_row) *first_row = ix->n + ix->row_offset;
+    return TS_OK;
+}
+
+extern "C" int ts_index_append(ts_index* ix, const void* host_rows, int src_dtype, int64_t nrows, int64_t* first_row) {
+    if (!ix || (!host_rows && nrows > 0)) return fail(TS_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    TS_TRY(append_locked(ix, nrows, first_row));
+    const int64_t old_n = ix->n;
+    ix->n += nrows;
+    const int rc = nrows ? upload_host_locked(ix, host_rows, src_dtype, old_n, nrows) : TS_OK;
+    if (rc != TS_OK) ix->n = old_n;
+    return rc;
+}
+
+extern "C" int ts_index_append_device(ts_index* ix, const void* dev_rows, int src_dtype, int64_t src_ld, int64_t nrows,
+                                      void* stream, int64_t* first_row) {
+    if (!ix || (!dev_rows && nrows > 0)) return fail(TS_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    TS_TRY(append_locked(ix, nrows, first_row));
+    const int64_t old_n = ix->n;
+    ix->n += nrows;
+    const int rc = nrows ? upload_device_locked(ix, dev_rows, src_dtype, src_ld, old_n, nrows, stream) : TS_OK;
+    if (rc != TS_OK) ix->n = old_n;
+    return rc;
+}
+
+extern "C" int ts_index_download(ts_index* ix, void* host_rows, int64_t row0, int64_t nrows) {
+    if (!ix) return fail(TS_ERR_INVALID, "index is NULL");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    TS_TRY(check_rows(ix, host_rows, ix->dtype, row0, nrows, false));
+    if (nrows == 0) return TS_OK;
     HIP_TRY(hipSetDevice(ix->device));
     const size_t row_bytes = (size_t)ix->d * ix->elem();
     TS_TRY(ensure(&ix->stage, &ix->stage_bytes, kStageBytes));
+    hipStream_t own;
+    TS_TRY(enter_stream(ix, nullptr, &own));
     const int64_t rows_per = std::max<int64_t>(1, (int64_t)(kStageBytes / row_bytes));
     for (int64_t r = 0; r < nrows; r += rows_per) {
         const int64_t cnt = std::min(rows_per, nrows - r);
@@ -514,7 +691,7 @@ static void launch_scan_generic(int qb, int kr, int grid, hipStream_t st, const 
 template <bool EMIT>
 static int launch_scan(const ts_index* ix, ScanArgs a, int qb_pref, hipStream_t st, int grid) {
     const int kr = (a.k <= 64) ? 1 : 4;
-    const bool force_generic = env_int("TS_SCAN_GENERIC", 0) != 0;
+    const bool force_generic = ix->knobs.get(K_SCAN_GENERIC, 0) != 0;
     if (!force_generic && ix->dtype == TS_F32 && ix->ld == 768) { launch_scan_spec<0, 3, 64, EMIT>(qb_pref, kr, grid, st, a); return qb_pref; }
     if (!force_generic && ix->dtype == TS_F32 && ix->ld == 1024) { launch_scan_spec<0, 4, 64, EMIT>(qb_pref, kr, grid, st, a); return qb_pref; }
     if (!force_generic && ix->dtype == TS_BF16 && ix->ld == 768) { launch_scan_spec<1, 3, 32, EMIT>(qb_pref, kr, grid, st, a); return qb_pref; }
@@ -630,18 +807,18 @@ static double normal_tail_z(double p) {
            (((((b[0] * r + b[1]) * r + b[2]) * r + b[3]) * r + b[4]) * r + 1.0);
 }
 
-static int mfma_target_cands(int64_t n, int kk) {
+static int mfma_target_cands(const Knobs& kn, int64_t n, int kk) {
     // Cost model fitted on 10M / 1.25M x 768, batch 256: a sample row costs ~0.4 ns, a candidate of the next
     // level ~0.27 us per query (the append path is ~1 us of wave time).  Minimising kk * N * c_row / F + c_cand * F
     // gives F ~ 512 * sqrt(N / 1e7) candidates per query for the full pass.
     int target = (int)(512.0 * std::sqrt(std::max<double>((double)n, 1.0) / 1e7));
     target = std::max(target, 8 * kk);  // large k: keep the level ratio >= 8, or the sparse levels cost as much as the pass
-    return std::min(2048, std::max(64, env_int("TS_MFMA_TARGET_CANDS", target)));
+    return std::min(2048, std::max(64, kn.get(K_MFMA_TARGET_CANDS, target)));
 }
 
-static std::vector<Level> plan_levels(int64_t n, int kk, bool statistical) {
+static std::vector<Level> plan_levels(const Knobs& kn, int64_t n, int kk, bool statistical) {
     const int64_t T = (n + kTileRows - 1) / kTileRows;
-    const int target = mfma_target_cands(n, kk);
+    const int target = mfma_target_cands(kn, n, kk);
     auto pow2_ratio = [&](int cands) { int64_t r = 2; while (r * 2 * kk <= cands) r *= 2; return r; };
     const int64_t r_last = pow2_ratio(target);
     // The sparsest level runs unthresholded: every score becomes a candidate, so it may hold at most
@@ -649,15 +826,15 @@ static std::vector<Level> plan_levels(int64_t n, int kk, bool statistical) {
     // sample size: 8192 rows for large corpora; below 4M rows half of that estimates the threshold as well (the
     // guaranteed bound k * N / sample stays small) and its pass + select are 13 us shorter - 2 % of a 1.25M-row shard
     const int first_default = (statistical && n < 4000000) ? kLevelSortMax / 2 : kLevelSortMax;
-    const int64_t first_rows = std::min<int64_t>(kLevelSortMax, (int64_t)env_int("TS_MFMA_FIRST_ROWS", first_default));
-    const int64_t r_cap = std::max<int64_t>(2, pow2_ratio(env_int("TS_MFMA_TARGET_SPARSE", 1280)));
+    const int64_t first_rows = std::min<int64_t>(kLevelSortMax, (int64_t)kn.get(K_MFMA_FIRST_ROWS, first_default));
+    const int64_t r_cap = std::max<int64_t>(2, pow2_ratio(kn.get(K_MFMA_TARGET_SPARSE, 1280)));
     std::vector<Level> lv;
     int64_t stride = 1;
     for (;;) {
         const int64_t nt = (T + stride - 1) / stride;
         // sampling in runs of consecutive tiles (shared DRAM pages / TLB entries) measured no different from
         // single tiles; kept as a knob
-        const int run = (stride > 1 && nt >= 8 * 256) ? env_int("TS_MFMA_RUN", 1) : 1;
+        const int run = (stride > 1 && nt >= 8 * 256) ? kn.get(K_MFMA_RUN, 1) : 1;
         lv.push_back({stride, nt, run});
         if (nt * kTileRows <= first_rows) break;  // every score of this level fits: it can run unthresholded
         if (statistical) {
@@ -715,21 +892,21 @@ static int launch_mfma(bool full_pass, int variant, int grid, hipStream_t st, co
 // (256 queries; one group = half the matrix work when the batch is <= 128), d = 1024 one (128 queries).
 static int mfma_block_queries(const ts_index* ix, int nq) {
     if (ix->d == 1024) return 128;
-    return nq <= 128 && env_int("TS_MFMA_GROUPS", 0) != 2 ? 128 : 256;
+    return nq <= 128 && ix->knobs.get(K_MFMA_GROUPS, 0) != 2 ? 128 : 256;
 }
 
 static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* out_idx, hipStream_t st, ts_search_stats* stats) {
     // threshold rank: the k-th best of a sample is already a valid lower bound of the final k-th best; private
     // lists + spill absorb the run-to-run spread of the candidate count, so no safety margin in the rank
-    const int kk = std::max(k, env_int("TS_MFMA_MIN_RANK", 1));
-    const int variant = env_int("TS_MFMA_VARIANT", 0);
+    const int kk = std::max(k, ix->knobs.get(K_MFMA_MIN_RANK, 1));
+    const int variant = ix->knobs.get(K_MFMA_VARIANT, 0);
     const int groups = mfma_block_queries(ix, nq) / 128;
     if (!ix->attr_done) {
         HIP_TRY(hipFuncSetAttribute((const void*)level_select_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelLds));
         HIP_TRY(hipFuncSetAttribute((const void*)level_select_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelLds));
         ix->attr_done = true;
     }
-    const int grid = std::max(1, std::min(env_int("TS_MFMA_GRID", ix->cu_count), 2048));
+    const int grid = std::max(1, std::min(ix->knobs.get(K_MFMA_GRID, ix->cu_count), 2048));
     const int nwriters = 2 * grid;
     if (ix->priv_writers != nwriters) {
         if (ix->priv) HIP_TRY(hipFree(ix->priv));
@@ -743,12 +920,12 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
     // Threshold of the full pass: by default extrapolated from ONE unthresholded sample (Gaussian tail of the
     // sample's scores, verified afterwards by the candidate count); TS_MFMA_STAT=0 selects the chain of
     // guaranteed lower bounds (more sample rows to scan, no re-runs ever).
-    const bool statistical = env_int("TS_MFMA_STAT", 1) != 0;
-    const std::vector<Level> lv = plan_levels(ix->n, kk, statistical);
+    const bool statistical = ix->knobs.get(K_MFMA_STAT, 1) != 0;
+    const std::vector<Level> lv = plan_levels(ix->knobs, ix->n, kk, statistical);
     // expected candidates per query of the full pass under the estimate: 16x the k that must come back (an
     // under-filled query costs an exact scan pass), few enough that the append path (~0.27 us per candidate and
     // query, whatever N) stays cheap: 10M rows measured 3.91 / 3.94 / 4.02 ms per search at 128 / 256 / 512
-    const int stat_cands = std::min(2048, std::max(env_int("TS_MFMA_STAT_CANDS", 128), 16 * kk));
+    const int stat_cands = std::min(2048, std::max(ix->knobs.get(K_MFMA_STAT_CANDS, 128), 16 * kk));
     // rows the candidates are drawn from: all of them, or the rows a filter allows (the sample sees only those too)
     const int64_t pop = ix->active_mask ? ix->active_allowed : ix->n;
     const float z_tail = (statistical && lv.size() == 2)
@@ -760,10 +937,9 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
     // max(2048, 8 kk) expected candidates, a quarter of the buffer.
     const double sample_rows = (double)std::max<int64_t>(1, lv[0].ntiles * kTileRows);
     const bool bound_swamps = (double)kk * (double)ix->n / sample_rows > 0.5 * kCandCap;
-    const float tail_p = (z_tail > 0.0f && bound_swamps && env_int("TS_MFMA_TAIL_FIT", 1))
+    const float tail_p = (z_tail > 0.0f && bound_swamps && ix->knobs.get(K_MFMA_TAIL_FIT, 1))
                              ? (float)std::min(0.25, (double)std::max(2048, 8 * kk) / (double)std::max<int64_t>(pop, 1))
                              : 0.0f;
-    static unsigned long long* g_dbg = nullptr;  // diagnostics (TS_MFMA_VARIANT=3): per-wave cycle sums
     for (size_t i = 0; i < lv.size(); ++i) {
         const bool full_pass = (i + 1 == lv.size());
         MfmaArgs a;
@@ -774,9 +950,9 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         a.run = lv[i].run;
         a.q = (const unsigned short*)ix->qstore;
         a.thr = ix->thr;
-        a.nq = env_int("TS_MFMA_NO_IDLE", 0) ? 256 : nq;
+        a.nq = ix->knobs.get(K_MFMA_NO_IDLE, 0) ? 256 : nq;
         a.row_mask = ix->active_mask;
-        a.ahead = env_int("TS_MFMA_AHEAD", 0);
+        a.ahead = ix->knobs.get(K_MFMA_AHEAD, 0);
         a.priv = ix->priv;
         a.pcount = ix->pcount;
         a.cand = ix->cand;
@@ -784,8 +960,8 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         a.cap = kCandCap;
         a.dbg = nullptr;
         if (variant >= 3) {
-            if (!g_dbg) HIP_TRY(hipMalloc((void**)&g_dbg, 2048 * 4 * 4 * 8));
-            a.dbg = g_dbg;
+            if (!ix->dbg) HIP_TRY(hipMalloc((void**)&ix->dbg, 2048 * 4 * 4 * 8));
+            a.dbg = ix->dbg;
         }
         hipEvent_t stop = full_pass ? prof_begin(ix, st, ix->n) : nullptr;  // only the full pass is bracketed
         int rc;
@@ -856,7 +1032,8 @@ static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_
     if (nq == 0) return TS_OK;
     std::lock_guard<std::mutex> lock(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));
-    hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
+    hipStream_t st;
+    TS_TRY(enter_stream(ix, stream, &st));
     TS_TRY(ensure_search_scratch(ix, k));
     struct MaskScope {  // the bitmask is a property of this call only
         ts_index* ix;
@@ -876,8 +1053,8 @@ static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_
         // masks leave the sample too few allowed rows to estimate from; device masks would need a count + sync first:
         // both go through the scan kernel, 4 queries per pass (or through a subset index).
         bool dense_host_mask = false;
-        if (!mask_on_device && mfma_dim(ix->d) && ix->dtype == TS_BF16 && nq > env_int("TS_SCAN_MAX_QUERIES", 4) &&
-            ix->n >= env_int("TS_MFMA_MIN_ROWS", 16384) && algo != TS_ALGO_SCAN) {
+        if (!mask_on_device && mfma_dim(ix->d) && ix->dtype == TS_BF16 && nq > ix->knobs.get(K_SCAN_MAX_QUERIES, 4) &&
+            ix->n >= ix->knobs.get(K_MFMA_MIN_ROWS, 16384) && algo != TS_ALGO_SCAN) {
             int64_t allowed = 0;
             for (size_t w = 0; w < words; ++w) allowed += __builtin_popcount(row_mask[w]);
             const int64_t tail_bits = (int64_t)words * 32 - ix->n;   // bits past the last row do not count
@@ -885,13 +1062,15 @@ static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_
             ix->active_allowed = allowed;
             dense_host_mask = allowed * 10 >= ix->n;
         }
+        if (algo == TS_ALGO_MFMA && !dense_host_mask)
+            return fail(TS_ERR_UNSUPPORTED, "the MFMA path serves host masks that keep at least a tenth of the rows, for more than 4 queries");
         algo = dense_host_mask ? TS_ALGO_MFMA : TS_ALGO_SCAN;
     }
     int use = algo;
     // The scan serves 4 queries per pass at the HBM rate; the MFMA path serves up to 256 per pass but its pass is
     // ~1.7x longer (matrix + HBM load drops the clock): a handful of queries is faster through the scan.
     if (use == TS_ALGO_AUTO)
-        use = (mfma_ok && ix->n >= env_int("TS_MFMA_MIN_ROWS", 16384) && nq > (k > 64 ? 1 : env_int("TS_SCAN_MAX_QUERIES", 4))) ? TS_ALGO_MFMA
+        use = (mfma_ok && ix->n >= ix->knobs.get(K_MFMA_MIN_ROWS, 16384) && nq > (k > 64 ? 1 : ix->knobs.get(K_SCAN_MAX_QUERIES, 4))) ? TS_ALGO_MFMA
                                                                                                           : TS_ALGO_SCAN;
     if (stats) stats->algo = use;
 
@@ -970,6 +1149,14 @@ extern "C" int ts_search_filtered(ts_index* ix, const void* queries, int q_dtype
                        nullptr, row_mask, mask_on_device);
 }
 
+extern "C" int ts_search_filtered_ex(ts_index* ix, const void* queries, int q_dtype, int q_on_device, int32_t nq, int32_t k,
+                                     const uint32_t* row_mask, int mask_on_device, float* out_scores, int64_t* out_idx,
+                                     int out_on_device, void* stream, int algo, ts_search_stats* stats) {
+    if (!row_mask) return fail(TS_ERR_INVALID, "row_mask is NULL");
+    return search_impl(ix, queries, q_dtype, q_on_device, nq, k, out_scores, out_idx, out_on_device, stream, algo, stats,
+                       row_mask, mask_on_device);
+}
+
 template <int DT, int CH, int G>
 static void launch_rank_spec(int qb, int grid, hipStream_t st, const RankArgs& a) {
     if (qb == 4) rank_kernel<DT, CH, G, 4><<<grid, 256, 0, st>>>(a);
@@ -978,7 +1165,7 @@ static void launch_rank_spec(int qb, int grid, hipStream_t st, const RankArgs& a
 
 static void launch_rank(const ts_index* ix, const RankArgs& a, hipStream_t st, int grid) {
     const int qb = a.nq >= 2 ? 4 : 1;
-    const bool force_generic = env_int("TS_SCAN_GENERIC", 0) != 0;
+    const bool force_generic = ix->knobs.get(K_SCAN_GENERIC, 0) != 0;
     if (!force_generic && ix->dtype == TS_F32 && ix->ld == 768) return launch_rank_spec<0, 3, 64>(qb, grid, st, a);
     if (!force_generic && ix->dtype == TS_F32 && ix->ld == 1024) return launch_rank_spec<0, 4, 64>(qb, grid, st, a);
     if (!force_generic && ix->dtype == TS_BF16 && ix->ld == 768) return launch_rank_spec<1, 3, 32>(qb, grid, st, a);
@@ -1012,15 +1199,22 @@ extern "C" int ts_parse_pgvector_text(const char* text, int64_t len, int32_t d, 
         int col = 0;
         bool closed = false;
         while (p < len) {
-            while (p < len && (text[p] == ' ' || text[p] == ',')) ++p;
+            while (p < len && (isspace((unsigned char)text[p]) || text[p] == ',')) ++p;
             if (p < len && text[p] == ']') { closed = true; ++p; break; }
             int t = 0;
-            while (p < len && text[p] != ',' && text[p] != ']' && text[p] != ' ' && t < 63) tok[t++] = text[p++];
+            while (p < len && text[p] != ',' && text[p] != ']' && !isspace((unsigned char)text[p]) && t < 63) tok[t++] = text[p++];
             if (p >= len) break;  // value cut off by the end of the buffer: the caller resumes at `consumed`
             tok[t] = 0;
+            if (t == 63 && text[p] != ',' && text[p] != ']' && !isspace((unsigned char)text[p]))
+                return fail(TS_ERR_INVALID, "row %lld: numeric literal longer than 63 characters", (long long)rows);
+            // vector_in takes decimal literals only: strtof would also accept nan / inf / hex floats
+            for (int c = 0; c < t; ++c)
+                if (!(isdigit((unsigned char)tok[c]) || tok[c] == '+' || tok[c] == '-' || tok[c] == '.' || tok[c] == 'e' || tok[c] == 'E'))
+                    return fail(TS_ERR_INVALID, "row %lld: cannot parse '%s'", (long long)rows, tok);
             char* end = nullptr;
             const float v = strtof(tok, &end);  // what pgvector's vector_in does: one correctly rounded fp32 conversion
             if (end == tok || *end != 0) return fail(TS_ERR_INVALID, "row %lld: cannot parse '%s'", (long long)rows, tok);
+            if (!std::isfinite(v)) return fail(TS_ERR_INVALID, "row %lld: '%s' is not a finite float", (long long)rows, tok);
             if (col >= d) return fail(TS_ERR_INVALID, "row %lld has more than %d values", (long long)rows, d);
             out[rows * d + col++] = v;
         }
@@ -1053,7 +1247,8 @@ static int rank_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_de
     if (ix->id_map) return fail(TS_ERR_UNSUPPORTED, "rank / count on a subset index");
     std::lock_guard<std::mutex> lock(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));
-    hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
+    hipStream_t st;
+    TS_TRY(enter_stream(ix, stream, &st));
     TS_TRY(ensure_search_scratch(ix, 1));
     constexpr size_t kPer = 8 + 8 + 4;
     TS_TRY(ensure(&ix->rank_buf, &ix->rank_bytes, (size_t)kQBlock * kPer));
@@ -1140,10 +1335,22 @@ extern "C" int ts_scores(ts_index* ix, const void* queries, int q_dtype, int q_o
     if (nq == 0 || ix->n == 0) return TS_OK;
     std::lock_guard<std::mutex> lock(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));
-    hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
+    hipStream_t st;
+    TS_TRY(enter_stream(ix, stream, &st));
     TS_TRY(ensure_search_scratch(ix, 1));
     float* dout = out;
-    if (!out_on_device) HIP_TRY(hipMalloc((void**)&dout, (size_t)nq * ix->n * 4));
+    DevBuf tmp;
+    if (!out_on_device) {
+        // the score matrix is for the evaluation script's small shapes: refuse what cannot fit beside the index
+        const size_t want = (size_t)nq * (size_t)ix->n * 4;
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        if (want > free_b / 2)
+            return fail(TS_ERR_NOMEM, "score matrix of %d x %lld floats (%zu bytes) does not fit: use ts_search / ts_rank_of",
+                        nq, (long long)ix->n, want);
+        HIP_TRY(tmp.alloc(want));
+        dout = tmp.as<float>();
+    }
     const size_t q_elem = q_dtype == TS_BF16 ? 2 : 4;
     if (!q_on_device) TS_TRY(ensure(&ix->stage, &ix->stage_bytes, kStageBytes));
     int rc = TS_OK;
@@ -1151,7 +1358,10 @@ extern "C" int ts_scores(ts_index* ix, const void* queries, int q_dtype, int q_o
         const int nb = std::min(kQBlock, nq - q0);
         const void* qsrc = (const char*)queries + (size_t)q0 * ix->d * q_elem;
         if (!q_on_device) {
-            hipMemcpyAsync(ix->stage, qsrc, (size_t)nb * ix->d * q_elem, hipMemcpyHostToDevice, st);
+            if (hipMemcpyAsync(ix->stage, qsrc, (size_t)nb * ix->d * q_elem, hipMemcpyHostToDevice, st) != hipSuccess) {
+                rc = fail(TS_ERR_HIP, "copy of the queries failed");
+                break;
+            }
             qsrc = ix->stage;
         }
         rc = prep_dispatch(q_dtype, ix->dtype, ix->metric == TS_METRIC_COS, qsrc, ix->d, ix->qstore, ix->qf32, ix->ld, ix->d, nb,
@@ -1173,7 +1383,6 @@ extern "C" int ts_scores(ts_index* ix, const void* queries, int q_dtype, int q_o
         if (rc == TS_OK && hipMemcpyAsync(out, dout, (size_t)nq * ix->n * 4, hipMemcpyDeviceToHost, st) != hipSuccess)
             rc = fail(TS_ERR_HIP, "copy of the score matrix failed");
         if (hipStreamSynchronize(st) != hipSuccess && rc == TS_OK) rc = fail(TS_ERR_HIP, "stream synchronize failed");
-        hipFree(dout);
     }
     return rc;
 }
@@ -1199,12 +1408,13 @@ extern "C" int ts_merge_topk(int device, const float* scores, const int64_t* idx
         HIP_TRY(hipGetLastError());
         return TS_OK;
     }
-    float *ds = nullptr, *dos = nullptr;
-    int64_t *di = nullptr, *doi = nullptr;
-    HIP_TRY(hipMalloc((void**)&ds, nin * 4));
-    HIP_TRY(hipMalloc((void**)&di, nin * 8));
-    HIP_TRY(hipMalloc((void**)&dos, nout * 4));
-    HIP_TRY(hipMalloc((void**)&doi, nout * 8));
+    // one temporary block (freed on every return path): ids in | ids out | scores in | scores out
+    DevBuf tmp;
+    HIP_TRY(tmp.alloc(nin * 12 + nout * 12));
+    int64_t* di = tmp.as<int64_t>();
+    int64_t* doi = di + nin;
+    float* ds = (float*)(doi + nout);
+    float* dos = ds + nin;
     HIP_TRY(hipMemcpyAsync(ds, scores, nin * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(di, idx, nin * 8, hipMemcpyHostToDevice, st));
     a.scores = ds; a.idx = di; a.out_scores = dos; a.out_idx = doi;
@@ -1213,7 +1423,6 @@ extern "C" int ts_merge_topk(int device, const float* scores, const int64_t* idx
     HIP_TRY(hipMemcpyAsync(out_scores, dos, nout * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(out_idx, doi, nout * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    hipFree(ds); hipFree(di); hipFree(dos); hipFree(doi);
     return TS_OK;
 }
 
@@ -1348,3 +1557,5 @@ extern "C" int ts_timer_destroy(ts_timer* t) {
     delete t;
     return TS_OK;
 }
+
+#include "shards.inc"

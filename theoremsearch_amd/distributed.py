@@ -1,18 +1,29 @@
-"""Row-sharded search over the GPUs of one node: one process per GPU, ``torch.distributed``
-(backend "nccl" = RCCL over xGMI), SURVEY.md section 8e.
+"""Row-sharded search over the GPUs of one node (BASELINE.json configs[3]).
 
-Rank r holds rows ``[r N / G, (r+1) N / G)`` of the corpus in its own :class:`TheoremIndex` whose
-``row_offset`` makes the returned ids global.  A search is: every rank runs the single-GPU kernels
-on its shard for the (replicated) query batch, one all-gather exchanges the per-shard top-k
-(``nq * k * 12`` bytes per rank), and every rank merges the ``G * k`` candidates per query with the
-device merge kernel.  The exchange is latency-bound (20 KB per rank at nq = 256, k = 10); there is no
-other collective on the path.
+Rank r holds rows ``[r N / G, (r+1) N / G)`` of the corpus in its own :class:`TheoremIndex` whose ``row_offset``
+makes the returned ids global.  A search is: every rank runs the single-GPU kernels on its shard for the
+(replicated) query batch, ONE all-gather exchanges the packed per-shard top-k (``12 * nq * k`` bytes per rank,
+latency-bound), and every rank merges the ``G * k`` candidates per query with the device merge kernel.  There is
+no other collective on the path.
 
-``local_search`` / ``merge`` can be injected so that the partition + exchange logic is testable with
-the gloo backend on CPU ranks (tests/test_distributed_cpu.py); the defaults are the HIP kernels.
+Two process models, one packed result layout (scores ``[nq x k]`` f32 at offset 0, ids ``[nq x k]`` i64 at
+``packed_idx_off``):
+
+* :class:`ShardedSearcher` - one PROCESS per GPU (``torch.distributed.run``).  The collective is either
+  ``exchange="native"``: ``ncclAllGather`` inside libtsearch (``ts_comm_*``: RCCL over xGMI; ``torch.distributed``
+  only carries the 128-byte unique id once, at start-up), or ``exchange="torch"``:
+  ``dist.all_gather_into_tensor`` on the same packed block - device tensors with the nccl backend, host tensors
+  with gloo (CPU tests, and rehearsals of several ranks on one GPU).  Device path: queries, per-shard results,
+  gathered blocks and merged results all stay in HBM (`search_device`); the exchange + merge of batch i run on a
+  side stream and overlap the search of batch i + 1.
+* :class:`Shards` - ONE process drives all the GPUs (``ts_shards_*``: ``ncclCommInitAll``, one stream per device).
+
+``local_search`` / ``merge`` can be injected so that the partition + exchange logic runs on CPU ranks with the gloo
+backend (tests/test_distributed_cpu.py); the defaults are the HIP kernels.
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Callable, Optional, Tuple
 
 import numpy as np
@@ -23,26 +34,63 @@ def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
     return n * rank // world, n * (rank + 1) // world
 
 
-class ShardedSearcher:
-    """Search over a row-sharded corpus; works with host arrays (numpy in, numpy out)."""
+def packed_idx_off(nq: int, k: int) -> int:
+    return (nq * k * 4 + 7) // 8 * 8
 
-    def __init__(self, local_search: Callable[[np.ndarray, int], Tuple[np.ndarray, np.ndarray]],
+
+def packed_bytes(nq: int, k: int) -> int:
+    return packed_idx_off(nq, k) + nq * k * 8
+
+
+def pack_results(scores: np.ndarray, idx: np.ndarray) -> np.ndarray:
+    nq, k = scores.shape
+    blk = np.zeros(packed_bytes(nq, k), dtype=np.uint8)
+    blk[: nq * k * 4] = np.ascontiguousarray(scores, dtype=np.float32).view(np.uint8).reshape(-1)
+    off = packed_idx_off(nq, k)
+    blk[off: off + nq * k * 8] = np.ascontiguousarray(idx, dtype=np.int64).view(np.uint8).reshape(-1)
+    return blk
+
+
+def unpack_results(blocks: np.ndarray, nparts: int, nq: int, k: int) -> Tuple[np.ndarray, np.ndarray]:
+    """``[nparts * blk]`` bytes -> scores ``[nparts x nq x k]`` f32, ids ``[nparts x nq x k]`` i64."""
+    blk, off = packed_bytes(nq, k), packed_idx_off(nq, k)
+    b = np.ascontiguousarray(blocks, dtype=np.uint8).reshape(nparts, blk)
+    scores = np.stack([b[p, : nq * k * 4].copy().view(np.float32).reshape(nq, k) for p in range(nparts)])
+    idx = np.stack([b[p, off: off + nq * k * 8].copy().view(np.int64).reshape(nq, k) for p in range(nparts)])
+    return scores, idx
+
+
+class ShardedSearcher:
+    """Search over a row-sharded corpus, one process per shard."""
+
+    def __init__(self, local_search: Optional[Callable[[np.ndarray, int], Tuple[np.ndarray, np.ndarray]]] = None,
                  merge: Optional[Callable[[np.ndarray, np.ndarray, int], Tuple[np.ndarray, np.ndarray]]] = None,
-                 group=None):
+                 group=None, index=None, exchange: str = "auto"):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.local_search = local_search
-        if merge is None:
-            from .index import merge_topk
-            merge = merge_topk
-        self.merge = merge
+        self.index = index
+        self.local_search = local_search or ((lambda q, k: index.search(q, k)) if index is not None else None)
+        self._merge_host = merge
+        self._comm = C.c_void_p()
+        self._bufs = {}
+        self._step = 0
+        backend = dist.get_backend(group) if dist.is_initialized() else None
+        if exchange == "auto":
+            exchange = "native" if (index is not None and backend == "nccl") else "torch"
+        if exchange not in ("native", "torch"):
+            raise ValueError(f"exchange must be 'auto', 'native' or 'torch', got {exchange!r}")
+        self.exchange = exchange
+        self.backend = backend
+        if exchange == "native" and self.world > 1:
+            self._init_native_comm()
 
+    # -- construction ---------------------------------------------------------------------------------------------
     @classmethod
     def from_local_rows(cls, local_rows, total_rows: int, dtype: str = "bf16", metric: str = "cos", device: int = 0,
-                        group=None) -> "ShardedSearcher":
+                        group=None, exchange: str = "auto") -> "ShardedSearcher":
         """Build this rank's shard index from its slice of the corpus (rows ``shard_bounds(...)``)."""
         import torch.distributed as dist
         from .index import TheoremIndex
@@ -51,15 +99,113 @@ class ShardedSearcher:
         lo, hi = shard_bounds(total_rows, world, rank)
         ix = TheoremIndex.from_embeddings(local_rows, dtype=dtype, metric=metric, device=device, row_offset=lo)
         assert ix.n == hi - lo, f"rank {rank} expected {hi - lo} rows, got {ix.n}"
-        obj = cls(lambda q, k: ix.search(q, k), group=group)
-        obj.index = ix
-        return obj
+        return cls(group=group, index=ix, exchange=exchange)
 
+    def _init_native_comm(self) -> None:
+        """ts_comm_create on every rank; torch.distributed only carries the unique id (start-up, not the search path)."""
+        from . import _ffi
+        lib = _ffi.load()
+        ident = [None]
+        if self.rank == 0:
+            buf = C.create_string_buffer(128)
+            _ffi.check(lib.ts_comm_unique_id(buf, 128))
+            ident[0] = bytes(buf.raw)
+        self.dist.broadcast_object_list(ident, src=self.dist.get_global_rank(self.group, 0) if self.group else 0,
+                                        group=self.group)
+        _ffi.check(lib.ts_comm_create(self.index.device, self.world, self.rank, ident[0], 128, C.byref(self._comm)))
+
+    def close(self) -> None:
+        if self._comm.value:
+            from . import _ffi
+            _ffi.load().ts_comm_destroy(self._comm)
+            self._comm = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- the device pipeline (what bench.py times) -----------------------------------------------------------------
+    def _device_buffers(self, nq: int, k: int):
+        import torch
+        key = (nq, k)
+        b = self._bufs.get(key)
+        if b is None:
+            dev = torch.device("cuda", self.index.device)
+            blk = packed_bytes(nq, k)
+            b = {
+                "mine": [torch.empty(blk, dtype=torch.uint8, device=dev) for _ in range(2)],
+                "all": [torch.empty(self.world * blk, dtype=torch.uint8, device=dev) for _ in range(2)],
+                "fin_s": [torch.empty((nq, k), dtype=torch.float32, device=dev) for _ in range(2)],
+                "fin_i": [torch.empty((nq, k), dtype=torch.int64, device=dev) for _ in range(2)],
+                "searched": [torch.cuda.Event() for _ in range(2)],
+                "done": [torch.cuda.Event() for _ in range(2)],
+                "used": [False, False],
+                "side": torch.cuda.Stream(device=dev),
+            }
+            self._bufs[key] = b
+        return b
+
+    def search_device(self, q_ptr: int, q_dtype: str, nq: int, k: int, stream=None, algo: str = "auto", mask_ptr: int = 0,
+                      overlap: bool = True):
+        """Enqueue one sharded search of ``nq`` device-resident queries: local search on ``stream`` (a
+        ``torch.cuda.Stream``; default: the current one), then the exchange + merge on a side stream, so that they
+        overlap the next call's search (``overlap=False``: everything on ``stream``).  Returns
+        ``(scores, idx, done)``: merged global results as device tensors ``[nq x k]`` (double-buffered: valid until
+        the second-next call) and the ``torch.cuda.Event`` that marks them complete."""
+        import torch
+        from . import _ffi
+        lib = _ffi.load()
+        main = stream or torch.cuda.current_stream(self.index.device)
+        b = self._device_buffers(nq, k)
+        p = self._step & 1
+        self._step += 1
+        if b["used"][p]:
+            main.wait_event(b["done"][p])              # the exchange of the call before last has consumed mine[p]
+        blk, off = packed_bytes(nq, k), packed_idx_off(nq, k)
+        base = b["mine"][p].data_ptr()
+        self.index.search_device(q_ptr, q_dtype, nq, k, base, base + off, main.cuda_stream, algo=algo, mask_ptr=mask_ptr)
+        side = b["side"] if overlap else main
+        if overlap:
+            b["searched"][p].record(main)
+            side.wait_event(b["searched"][p])
+        if self.world == 1:
+            src = b["mine"][p]
+        else:
+            src = b["all"][p]
+            if self.exchange == "native":
+                _ffi.check(lib.ts_comm_allgather(self._comm, C.c_void_p(base), C.c_void_p(src.data_ptr()), blk,
+                                                 C.c_void_p(side.cuda_stream)))
+            else:
+                with torch.cuda.stream(side):
+                    if self.backend == "nccl":
+                        self.dist.all_gather_into_tensor(src, b["mine"][p], group=self.group)
+                    else:                                     # gloo moves host memory: rehearsal of N ranks on one GPU
+                        side.synchronize()
+                        host = torch.empty(src.shape, dtype=src.dtype)
+                        self.dist.all_gather_into_tensor(host, b["mine"][p].cpu(), group=self.group)
+                        src.copy_(host)
+        _ffi.check(lib.ts_merge_topk_packed(self.index.device, C.c_void_p(src.data_ptr()), blk, off, self.world, nq, k, k,
+                                            C.c_void_p(b["fin_s"][p].data_ptr()), C.c_void_p(b["fin_i"][p].data_ptr()),
+                                            C.c_void_p(side.cuda_stream)))
+        b["done"][p].record(side)
+        b["used"][p] = True
+        return b["fin_s"][p], b["fin_i"][p], b["done"][p]
+
+    # -- host arrays in, host arrays out -----------------------------------------------------------------------------
     def search(self, queries: np.ndarray, k: int, mask: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
         """``mask``: bool per row of the WHOLE corpus (a metadata filter); every rank applies its slice of it."""
         import torch
+        ix = self.index
+        if ix is not None and mask is None and self._merge_host is None:
+            # the device pipeline end to end
+            q = np.ascontiguousarray(np.asarray(queries, dtype=np.float32).reshape(-1, ix.d))
+            qd = torch.from_numpy(q).to(torch.device("cuda", ix.device))
+            s, i, done = self.search_device(qd.data_ptr(), "f32", q.shape[0], int(k), overlap=False)
+            done.synchronize()
+            return s.cpu().numpy(), i.cpu().numpy()
         if mask is not None:
-            ix = self.index
             lo = ix.row_offset
             scores, idx = ix.search(queries, k, mask=np.asarray(mask, dtype=bool)[lo:lo + ix.n])
         else:
@@ -67,18 +213,18 @@ class ShardedSearcher:
         if self.world == 1:
             return scores, idx
         nq = scores.shape[0]
-        dev = "cuda" if self.dist.get_backend(self.group) == "nccl" else "cpu"
-        # one exchange: scores and ids packed into a single int64 payload (score bits in the low word)
-        payload = np.empty((nq, k, 2), dtype=np.int64)
-        payload[..., 0] = scores.astype(np.float32).view(np.int32).astype(np.int64)
-        payload[..., 1] = idx
-        mine = torch.from_numpy(payload).to(dev)
-        gathered = torch.empty((self.world * nq, k, 2), dtype=torch.int64, device=dev)  # rank-major concatenation
-        self.dist.all_gather_into_tensor(gathered, mine, group=self.group)
-        g = gathered.cpu().numpy().reshape(self.world, nq, k, 2)
-        all_scores = g[..., 0].astype(np.int32).view(np.float32)
-        all_idx = np.ascontiguousarray(g[..., 1])
-        return self.merge(np.ascontiguousarray(all_scores), all_idx, k)
+        mine = torch.from_numpy(pack_results(scores, idx))
+        on_gpu = self.backend == "nccl"
+        if on_gpu:
+            mine = mine.to(torch.device("cuda", ix.device))
+        gathered = torch.empty(self.world * mine.numel(), dtype=torch.uint8, device=mine.device)
+        self.dist.all_gather_into_tensor(gathered, mine, group=self.group)     # ONE exchange, rank-major
+        all_scores, all_idx = unpack_results(gathered.cpu().numpy(), self.world, nq, k)
+        merge = self._merge_host
+        if merge is None:
+            from .index import merge_topk
+            merge = lambda s_, i_, k_: merge_topk(s_, i_, k_, device=ix.device if ix is not None else 0)
+        return merge(all_scores, all_idx, k)
 
     def rank_of(self, queries: np.ndarray, rows, local_rank_of=None, local_count_above=None) -> np.ndarray:
         """Rank of global row ``rows[i]`` for query ``i`` over the WHOLE sharded corpus (0 = best; -1 = no such row):
@@ -109,3 +255,67 @@ class ShardedSearcher:
         out = total.cpu().numpy()
         out[~known] = -1
         return out
+
+
+class Shards:
+    """One process, all GPUs of the node: ``ts_shards_*`` (``ncclCommInitAll``, one stream per device, the exchange
+    inside libtsearch).  ``devices=None`` uses devices ``0 .. ngpu-1``; repeating a device id puts several shards on one
+    GPU (rehearsal on a one-GPU box; the exchange then uses device copies)."""
+
+    def __init__(self, n_total: int, d: int, ngpu: int, dtype: str = "bf16", metric: str = "ip", devices=None):
+        from . import _ffi
+        from .index import _DTYPES, _METRICS
+        self._lib = _ffi.load()
+        self._h = C.c_void_p()
+        self.n_total, self.d, self.ngpu = int(n_total), int(d), int(ngpu)
+        dev = None
+        if devices is not None:
+            dev = (C.c_int32 * ngpu)(*[int(x) for x in devices])
+        _ffi.check(self._lib.ts_shards_create(ngpu, dev, self.n_total, self.d, _DTYPES[dtype], _METRICS[metric],
+                                              C.byref(self._h)))
+        rc = C.c_int32(0)
+        _ffi.check(self._lib.ts_shards_info(self._h, None, None, C.byref(rc)))
+        self.uses_rccl = bool(rc.value)
+
+    def upload(self, rows, row0: int = 0) -> None:
+        from . import _ffi
+        from .index import _host_rows
+        rows = _host_rows(rows)
+        if rows.shape[1] != self.d:
+            raise ValueError(f"rows have d={rows.shape[1]}, corpus has d={self.d}")
+        _ffi.check(self._lib.ts_shards_upload(self._h, _ffi.as_ptr(rows), _ffi.np_dtype_code(rows), int(row0), rows.shape[0]))
+
+    def bounds(self, g: int) -> Tuple[int, int]:
+        from . import _ffi
+        lo, hi = C.c_int64(0), C.c_int64(0)
+        _ffi.check(self._lib.ts_shards_shard(self._h, int(g), None, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def search(self, queries, k: int) -> Tuple[np.ndarray, np.ndarray]:
+        from . import _ffi
+        from .index import _host_rows
+        q = _host_rows(queries)
+        if q.shape[1] != self.d:
+            raise ValueError(f"queries have d={q.shape[1]}, corpus has d={self.d}")
+        scores = np.empty((q.shape[0], int(k)), dtype=np.float32)
+        idx = np.empty((q.shape[0], int(k)), dtype=np.int64)
+        _ffi.check(self._lib.ts_shards_search(self._h, _ffi.as_ptr(q), _ffi.np_dtype_code(q), q.shape[0], int(k),
+                                              _ffi.as_ptr(scores), _ffi.as_ptr(idx)))
+        return scores, idx
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.ts_shards_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

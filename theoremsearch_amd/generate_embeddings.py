@@ -32,23 +32,33 @@ def embed_texts(embedder, texts_to_embed: list[str], batch_size: int = 16):
     return embeddings.tolist()
 
 
-def embed_into_index(embedder: SentenceEncoder, index: TheoremIndex, texts: list[str], row0: int,
-                     batch_size: int = 16) -> None:
+def embed_into_index(embedder: SentenceEncoder, index: TheoremIndex, texts: list[str], row0,
+                     batch_size: int = 16):
     """Encode ``texts`` and store them as index rows ``[row0, row0 + len(texts))`` (upsert-by-position,
-    the HBM counterpart of ``ON CONFLICT (slogan_id) DO UPDATE``, __main__.py:85-99).  On a GPU the
-    encoder output goes device-to-device through ``ts_index_upload_device``."""
+    the HBM counterpart of ``ON CONFLICT (slogan_id) DO UPDATE``, __main__.py:85-99); ``row0=None`` appends them
+    behind the last row (the INSERT half of the upsert) and returns the id of the first new row.  On a GPU the
+    encoder output goes device-to-device through ``ts_index_upload_device`` / ``ts_index_append_device`` on the
+    stream the encoder ran on (a default-stream handle of 0 means the index's own stream, which is ordered with
+    the legacy default stream; any other stream is used as is), and the call returns after the rows have landed."""
     emb = embedder.encode_device(texts, batch_size=batch_size, normalize_embeddings=True)
+    first = row0
     if emb.is_cuda:
         import torch
-        stream = torch.cuda.current_stream().cuda_stream
-        index.upload_device(emb.data_ptr(), "f32", emb.stride(0), row0, emb.shape[0], stream)
-        torch.cuda.current_stream().synchronize()
+        stream = torch.cuda.current_stream(emb.device).cuda_stream
+        if row0 is None:
+            first = index.append_device(emb.data_ptr(), "f32", emb.stride(0), emb.shape[0], stream)
+        else:
+            index.upload_device(emb.data_ptr(), "f32", emb.stride(0), row0, emb.shape[0], stream)
+        index.synchronize()          # `emb` is released when this function returns: the upload must have read it
+    elif row0 is None:
+        first = index.append(emb.numpy())
     else:
         index.upload(emb.numpy(), row0)
+    return first
 
 
 def generate_embeddings(pages, embedder_alias: str, index: TheoremIndex, slot_of=None, batch_size: int = 16,
-                        overwrite: bool = False, embedder=None) -> int:
+                        overwrite: bool = False, embedder=None, slots: dict | None = None) -> int:
     """The loop of ``ec2/generate_embeddings/__main__.py:10-105`` with the RDS calls factored out.
 
     The reference pages ``{"slogan_id", "slogan"}`` rows out of Postgres with keyset pagination
@@ -58,9 +68,31 @@ def generate_embeddings(pages, embedder_alias: str, index: TheoremIndex, slot_of
     Here ``pages`` is any iterable of such pages (the database cursor stays the caller's business),
     the destination is the HBM index, and ``slot_of(slogan_id) -> row`` is the upsert key (default:
     the slogan id is the row).  Rows are written device-to-device.  Returns the number of rows embedded.
+
+    ``slots`` (a dict ``slogan_id -> row``, kept by the caller across runs) switches to the growing form: a
+    slogan_id it knows is an UPDATE of its row (skipped unless ``overwrite``), one it does not know is an INSERT -
+    its embedding is appended behind the last row (``ts_index_append_device``) and recorded in ``slots``; the index
+    needs no rebuild when new slogans arrive.
     """
     if embedder is None:
         embedder = get_embedder(embedder_alias)
+    if slots is not None:
+        n_done = 0
+        for page in pages:
+            fresh = [r for r in page if r["slogan_id"] not in slots]
+            if fresh:
+                first = embed_into_index(embedder, index, [r["slogan"] for r in fresh], None, batch_size=batch_size)
+                for j, r in enumerate(fresh):
+                    slots[r["slogan_id"]] = first + j
+                n_done += len(fresh)
+            if overwrite:
+                new_ids = {r["slogan_id"] for r in fresh}
+                for r in page:
+                    if r["slogan_id"] not in new_ids:
+                        embed_into_index(embedder, index, [r["slogan"]], slots[r["slogan_id"]] - index.row_offset,
+                                         batch_size=batch_size)
+                        n_done += 1
+        return n_done
     slot_of = slot_of or (lambda slogan_id: int(slogan_id))
     seen = getattr(index, "_filled", None)
     if seen is None:

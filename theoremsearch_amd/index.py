@@ -106,9 +106,41 @@ class TheoremIndex:
         _ffi.check(self._lib.ts_index_upload_device(self._h, C.c_void_p(dev_ptr), _DTYPES[src_dtype], int(src_ld),
                                                     int(row0), int(nrows), C.c_void_p(stream)))
 
+    def reserve(self, capacity: int) -> None:
+        """Make room for ``capacity`` rows (no change to ``n``): later `append` calls then never move the rows."""
+        _ffi.check(self._lib.ts_index_reserve(self._h, int(capacity)))
+
+    def append(self, rows) -> int:
+        """Add rows behind the last one (new ``slogan_id``s of the upsert pipeline, ec2/generate_embeddings/__main__.py:85-99);
+        returns the global id of the first new row.  The allocation grows 1.5x when it is full."""
+        rows = _host_rows(rows)
+        if rows.shape[1] != self.d:
+            raise ValueError(f"rows have d={rows.shape[1]}, index has d={self.d}")
+        first = C.c_int64(-1)
+        _ffi.check(self._lib.ts_index_append(self._h, _ffi.as_ptr(rows), _ffi.np_dtype_code(rows), rows.shape[0],
+                                             C.byref(first)))
+        self.n += rows.shape[0]
+        return first.value
+
+    def append_device(self, dev_ptr: int, src_dtype: str, src_ld: int, nrows: int, stream: int = 0) -> int:
+        """`append` for rows already in device memory (the encoder output)."""
+        first = C.c_int64(-1)
+        _ffi.check(self._lib.ts_index_append_device(self._h, C.c_void_p(dev_ptr), _DTYPES[src_dtype], int(src_ld), int(nrows),
+                                                    C.c_void_p(stream), C.byref(first)))
+        self.n += int(nrows)
+        return first.value
+
     def set_row_offset(self, offset: int) -> None:
         _ffi.check(self._lib.ts_index_set_row_offset(self._h, int(offset)))
         self.row_offset = int(offset)
+
+    def set_option(self, name: str, value: Optional[int]) -> None:
+        """Tuning / diagnostic knob of this handle (``"TS_MFMA_FIRST_ROWS"`` ...); ``None`` restores the default.
+        The knobs' initial values come from the environment when the handle is created."""
+        if value is None:
+            _ffi.check(self._lib.ts_index_reset_option(self._h, name.encode()))
+        else:
+            _ffi.check(self._lib.ts_index_set_option(self._h, name.encode(), int(value)))
 
     def download(self, row0: int = 0, nrows: Optional[int] = None) -> np.ndarray:
         """Stored rows (normalised / bf16-rounded as the kernels see them)."""
@@ -116,6 +148,10 @@ class TheoremIndex:
         out = np.empty((nrows, self.d), dtype=np.uint16 if _DTYPES[self.dtype] == TS_BF16 else np.float32)
         _ffi.check(self._lib.ts_index_download(self._h, _ffi.as_ptr(out), int(row0), int(nrows)))
         return out
+
+    def synchronize(self) -> None:
+        """Wait for everything this handle has enqueued (uploads / searches with device buffers return early)."""
+        _ffi.check(self._lib.ts_index_synchronize(self._h))
 
     @property
     def stream(self) -> int:
@@ -146,8 +182,13 @@ class TheoremIndex:
             words = np.zeros((self.n + 31) // 32 * 4, dtype=np.uint8)
             words[: bits.shape[0]] = bits
             words = words.view(np.uint32)
-            _ffi.check(self._lib.ts_search_filtered(self._h, _ffi.as_ptr(q), _ffi.np_dtype_code(q), 0, nq, k,
-                                                    _ffi.as_ptr(words), 0, _ffi.as_ptr(scores), _ffi.as_ptr(idx), 0, None))
+            stats = _ffi.SearchStats()
+            _ffi.check(self._lib.ts_search_filtered_ex(self._h, _ffi.as_ptr(q), _ffi.np_dtype_code(q), 0, nq, k,
+                                                       _ffi.as_ptr(words), 0, _ffi.as_ptr(scores), _ffi.as_ptr(idx), 0, None,
+                                                       _ALGOS[algo], C.byref(stats)))
+            if return_stats:
+                return scores, idx, {"algo": stats.algo, "levels": stats.levels,
+                                     "fallback_queries": stats.fallback_queries, "candidates": stats.candidates}
             return scores, idx
         stats = _ffi.SearchStats()
         _ffi.check(self._lib.ts_search_ex(self._h, _ffi.as_ptr(q), _ffi.np_dtype_code(q), 0, nq, k,

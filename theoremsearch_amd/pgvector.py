@@ -89,7 +89,10 @@ def search(index: TheoremIndex, query_vec, top_k: int, citation_weight: float = 
                 for s, i in zip(scores[0], idx[0]) if i >= 0]
     if citations is None:
         raise ValueError("citation-weighted search needs the per-row citation counts")
-    pool = min(pool_size(top_k), 256)
+    pool = pool_size(top_k)                      # max(50, 10 k): the reference's slider stops at k = 20 -> 200
+    if pool > _ffi.TS_MAX_K:
+        raise ValueError(f"citation pool of {pool} rows (top_k = {top_k}) exceeds the library's k limit of {_ffi.TS_MAX_K}; "
+                         "the reference's UI allows top_k <= 20 (streamlit_app.py:317)")
     scores, idx = index.search(q, pool, mask=mask)
     rows = []
     for s, i in zip(scores[0], idx[0]):
