@@ -186,6 +186,41 @@ def prepared_inputs(q, c, metric="ip", dtype="f32"):
 # parity protocol ("Hard parts", first item)
 # ----------------------------------------------------------------------------
 
+def _check_one_query(b, ext, sv, score_of, got, got_scores_row, kk, k, gap, score_tol):
+    """One query of the protocol.  ``ext`` / ``sv``: indices and fp64 scores of the best rows in canonical order (at least
+    kk + 1 of them unless the corpus is smaller); ``score_of(j)``: fp64 score of row j.  Returns (pinned, recall hits)."""
+    pinned = 0
+    assert len(set(got.tolist())) == kk, f"query {b}: duplicate indices {got}"
+    pos = 0
+    while pos < kk:
+        end = pos + 1
+        while end < len(ext) and sv[end - 1] - sv[end] <= gap:
+            end += 1
+        members = set(int(x) for x in ext[pos:end])
+        take = min(end, kk) - pos
+        got_run = [int(x) for x in got[pos:pos + take]]
+        if end - pos == 1:
+            pinned += 1
+            assert got_run[0] == ext[pos], (
+                f"query {b} rank {pos}: got {got_run[0]} want {ext[pos]} "
+                f"(fp64 scores {score_of(got_run[0])!r} vs {sv[pos]!r})")
+        else:
+            assert set(got_run) <= members, (
+                f"query {b} ranks {pos}..{pos + take}: {got_run} not within tie run {sorted(members)}")
+        pos = end
+    true_set = set(int(x) for x in ext[:kk])
+    kth = sv[kk - 1]
+    hits = 0
+    ref = np.array([score_of(int(j)) for j in got], dtype=np.float64)
+    for j, r in zip(got.tolist(), ref):
+        if j in true_set or r >= kth - gap:
+            hits += 1
+    if got_scores_row is not None:
+        gs = np.asarray(got_scores_row, dtype=np.float64)[:kk]
+        assert np.all(np.abs(gs - ref) <= score_tol), f"query {b}: scores off by {np.max(np.abs(gs - ref))}"
+    return pinned, hits
+
+
 def check_topk_against_truth(truth_scores: np.ndarray, got_idx: np.ndarray,
                              got_scores: Optional[np.ndarray], k: int,
                              gap: float = 1e-6, score_tol: float = 1e-5) -> Dict[str, float]:
@@ -207,46 +242,99 @@ def check_topk_against_truth(truth_scores: np.ndarray, got_idx: np.ndarray,
     for b in range(B):
         row = t[b].copy()
         row[np.isnan(row)] = -np.inf
-        order = np.lexsort((np.arange(N), -row))
-        ext = order[: min(N, kk + 64)]
-        sv = row[ext]
-        got = gi[b, :kk]
-        assert len(set(got.tolist())) == kk, f"query {b}: duplicate indices {got}"
-        # split the sorted prefix into runs of near-equal scores
-        pos = 0
-        while pos < kk:
-            end = pos + 1
-            while end < len(ext) and sv[end - 1] - sv[end] <= gap:
-                end += 1
-            members = set(ext[pos:end].tolist())
-            take = min(end, kk) - pos
-            got_run = got[pos:pos + take].tolist()
-            if end - pos == 1:
-                pinned_total += 1
-                assert got_run[0] == ext[pos], (
-                    f"query {b} rank {pos}: got {got_run[0]} want {ext[pos]} "
-                    f"(fp64 scores {row[got_run[0]]!r} vs {sv[pos]!r})")
-            else:
-                assert set(got_run) <= members, (
-                    f"query {b} ranks {pos}..{pos + take}: {got_run} not within tie run {sorted(members)}")
-            pos = end
         if kk == 0:          # nothing to rank (empty corpus): the answer is all padding
             assert np.all(gi[b] == -1), f"query {b}: padding must be -1"
             continue
-        true_set = set(ext[:kk].tolist())
-        kth = sv[kk - 1]
-        for j in got.tolist():
-            if j in true_set or row[j] >= kth - gap:
-                recall_hits += 1
-        if got_scores is not None:
-            gs = _as_2d(got_scores)[b, :kk]
-            ref = row[got]
-            assert np.all(np.abs(gs.astype(np.float64) - ref) <= score_tol), (
-                f"query {b}: scores off by {np.max(np.abs(gs - ref))}")
+        order = np.lexsort((np.arange(N), -row))
+        ext = order[: min(N, kk + 64)]
+        gs_row = None if got_scores is None else _as_2d(got_scores)[b]
+        p, h = _check_one_query(b, ext, row[ext], lambda j: row[j], gi[b, :kk], gs_row, kk, k, gap, score_tol)
+        pinned_total += p
+        recall_hits += h
         if kk < k:
             assert np.all(gi[b, kk:] == -1), f"query {b}: padding must be -1"
     return {"pinned": pinned_total, "positions": B * kk,
             "recall": recall_hits / float(B * kk) if B * kk else 1.0}
+
+
+class ChunkedTruth:
+    """The same protocol for corpora whose [B x N] fp64 score matrix does not fit: feed the corpus chunk by chunk
+    (`add`), each chunk's fp64 scores are reduced at once to the ``k + 64`` best rows per query plus the fp64 scores of
+    the rows the answer under test returned; `check` then applies `check_topk_against_truth`'s rules.  ``queries`` are
+    the prepared operand values (what the kernels multiply); ``got_idx`` are global row ids."""
+
+    def __init__(self, queries: np.ndarray, got_idx: np.ndarray, k: int, keep_extra: int = 64):
+        self.q64 = _as_2d(queries).astype(np.float64)
+        self.got = _as_2d(got_idx).astype(np.int64)
+        self.k = int(k)
+        self.keep = self.k + keep_extra
+        B = self.q64.shape[0]
+        self.best_s = np.full((B, 0), -np.inf)
+        self.best_i = np.zeros((B, 0), dtype=np.int64)
+        self.got_s = np.full(self.got.shape, np.nan)
+        self.n = 0
+
+    def scores_of_chunk(self, rows: np.ndarray) -> np.ndarray:
+        return self.q64 @ _as_2d(rows).astype(np.float64).T
+
+    def add(self, rows: np.ndarray, row0: int, allowed: Optional[np.ndarray] = None) -> None:
+        """``rows``: prepared values of global rows ``[row0, row0 + len(rows))``; ``allowed``: optional bool per row
+        (filtered search: disallowed rows do not exist)."""
+        self.add_scores(self.scores_of_chunk(rows), row0, allowed)
+
+    def add_scores(self, s: np.ndarray, row0: int, allowed: Optional[np.ndarray] = None) -> None:
+        s = np.array(s, dtype=np.float64)
+        s[np.isnan(s)] = -np.inf
+        if allowed is not None:
+            s[:, ~np.asarray(allowed, dtype=bool)] = -np.inf
+        B, m = s.shape
+        self.n += m if allowed is None else int(np.count_nonzero(allowed))
+        inside = (self.got >= row0) & (self.got < row0 + m)
+        bb, jj = np.nonzero(inside)
+        self.got_s[bb, jj] = s[bb, self.got[bb, jj] - row0]
+        keep = min(self.keep, m)
+        part = np.argpartition(-s, keep - 1, axis=1)[:, :keep] if keep < m else np.tile(np.arange(m), (B, 1))
+        cand_s = np.take_along_axis(s, part, axis=1)
+        cand_i = part.astype(np.int64) + row0
+        # everything tied with the chunk's keep-th value would be needed for exactness of ties across the cut; the
+        # extra 64 rows make a 65-fold near-tie at the k boundary the only case that could be missed
+        all_s = np.concatenate([self.best_s, cand_s], axis=1)
+        all_i = np.concatenate([self.best_i, cand_i], axis=1)
+        order = np.lexsort((all_i, -all_s), axis=1)[:, : self.keep]
+        self.best_s = np.take_along_axis(all_s, order, axis=1)
+        self.best_i = np.take_along_axis(all_i, order, axis=1)
+
+    def merge(self, other_best_s: np.ndarray, other_best_i: np.ndarray, other_got_s: np.ndarray, other_n: int) -> None:
+        """Fold in another accumulator's state (sharded checks: every rank accumulates its own rows)."""
+        all_s = np.concatenate([self.best_s, other_best_s], axis=1)
+        all_i = np.concatenate([self.best_i, other_best_i], axis=1)
+        order = np.lexsort((all_i, -all_s), axis=1)[:, : self.keep]
+        self.best_s = np.take_along_axis(all_s, order, axis=1)
+        self.best_i = np.take_along_axis(all_i, order, axis=1)
+        self.got_s = np.where(np.isnan(self.got_s), other_got_s, self.got_s)
+        self.n += other_n
+
+    def check(self, got_scores: Optional[np.ndarray], gap: float = 1e-6, score_tol: float = 1e-5) -> Dict[str, float]:
+        B = self.q64.shape[0]
+        kk = min(self.k, self.n)
+        pinned_total = recall_hits = 0
+        for b in range(B):
+            if kk == 0:
+                assert np.all(self.got[b] == -1), f"query {b}: padding must be -1"
+                continue
+            valid = self.best_s[b] > -np.inf
+            ext, sv = self.best_i[b][valid], self.best_s[b][valid]
+            got = self.got[b, :kk]
+            assert np.all(got >= 0), f"query {b}: padding inside the first {kk} results: {got}"
+            lookup = {int(j): float(v) for j, v in zip(got, self.got_s[b, :kk])}
+            assert not any(np.isnan(v) for v in lookup.values()), f"query {b}: returned rows outside the corpus: {got}"
+            gs_row = None if got_scores is None else _as_2d(got_scores)[b]
+            p, h = _check_one_query(b, ext, sv, lambda j: lookup[j], got, gs_row, kk, self.k, gap, score_tol)
+            pinned_total += p
+            recall_hits += h
+            if kk < self.k:
+                assert np.all(self.got[b, kk:] == -1), f"query {b}: padding must be -1"
+        return {"pinned": pinned_total, "positions": B * kk, "recall": recall_hits / float(B * kk) if B * kk else 1.0}
 
 
 def recall_at_k(truth_idx: np.ndarray, got_idx: np.ndarray) -> float:

@@ -18,6 +18,63 @@ import theoremsearch_amd as ts  # noqa: E402
 from oracle import oracle  # noqa: E402  (checker)
 
 
+def one_case(rng, big: bool, case: int = 0, watchdog: bool = True) -> str:
+    """One random combination, checked; returns its description.  Used by the time-boxed sweep below and, with a
+    fixed seed list, by tests/test_fullsize_gpu.py (collected by pytest)."""
+    d = int(rng.choice([768, 768, 768, 1024, 1024, 384, 384, 512, 512, 40]))
+    dtype = str(rng.choice(["bf16", "bf16", "f32"]))
+    metric = str(rng.choice(["cos", "ip"]))
+    n = int(rng.choice([1, 33, 1000, 16384, 16385, 40000, 70001, 150000, 300000]))
+    if d == 1024:
+        n = min(n, 150000)
+    nq = int(rng.choice([1, 2, 4, 5, 31, 32, 33, 64, 100, 128, 129, 160, 200, 256, 257, 300]))
+    k = int(rng.choice([1, 5, 10, 10, 10, 50, 64, 65, 200, 256]))
+    if big:
+        d, dtype = 768, "bf16"
+        n = int(rng.choice([1_000_000, 1_700_001, 2_500_000]))
+        nq = int(rng.choice([5, 16, 33, 130]))
+        k = int(rng.choice([1, 10, 10, 50, 256]))
+    mfma_ok = dtype == "bf16" and d in (384, 512, 768, 1024)
+    algo = str(rng.choice(["auto", "scan", "mfma"])) if mfma_ok else str(rng.choice(["auto", "scan"]))
+    if big:
+        algo = "auto" if rng.random() < 0.4 else "mfma"     # "auto" may carry a dense host mask (masked MFMA pass)
+    if algo == "scan" and nq > 64:
+        nq = int(rng.choice([1, 4, 7, 33]))          # the scan serves 4 queries per pass: keep the sweep moving
+    use_mask = algo != "mfma" and rng.random() < (0.7 if big else 0.25) and (nq <= 8 or (mfma_ok and n >= 16384))
+    seed = int(rng.integers(0, 2**31))
+    if watchdog:
+        faulthandler.dump_traceback_later(300 if big else 120, exit=True)
+    t0 = time.time()
+    q, c = oracle.golden_inputs(n, nq, d, seed, metric)
+    if rng.random() < 0.15 and n > 100:              # duplicates: exact ties
+        c[rng.integers(0, n, 20)] = c[0]
+    if big and rng.random() < 0.5:              # a cluster near the queries: heavy upper tail
+        u = q.mean(axis=0)
+        members = rng.choice(n, n // 25, replace=False)
+        c[members] += (rng.random(members.size).astype(np.float32) * np.float32(4.0))[:, None] * u
+    mask = (rng.random(n) < float(rng.choice([0.05, 0.3, 0.8]))) if use_mask else None
+    with ts.TheoremIndex.from_embeddings(c, dtype=dtype, metric=metric) as ix:
+        if mask is not None:
+            scores, idx = ix.search(q, k, mask=mask)
+        else:
+            scores, idx = ix.search(q, k, algo=algo)
+    rows = np.flatnonzero(mask) if mask is not None else np.arange(n)
+    qp, cp = oracle.prepared_inputs(q, c[rows], metric, dtype)
+    truth = oracle.scores_fp64(qp, cp)
+    m = min(k, rows.size)
+    local = np.full_like(idx, -1)
+    valid = idx >= 0
+    local[valid] = np.searchsorted(rows, idx[valid])
+    assert (idx[:, m:] == -1).all() and (idx[:, :m] >= 0).all(), "padding"
+    assert (rows[local[:, :m]] == idx[:, :m]).all(), "ids outside the allowed rows"
+    stats = oracle.check_topk_against_truth(truth, local, scores, k, gap=1e-6, score_tol=1e-5)
+    assert stats["recall"] == 1.0, stats
+    if watchdog:
+        faulthandler.cancel_dump_traceback_later()
+    return (f"case {case}: n={n} d={d} {dtype} {metric} nq={nq} k={k} algo={algo} mask={use_mask} ok "
+            f"({time.time() - t0:.1f}s)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240)
@@ -29,56 +86,7 @@ def main():
     case = 0
     while time.time() < t_end:
         case += 1
-        d = int(rng.choice([768, 768, 768, 1024, 1024, 384, 384, 512, 512, 40]))
-        dtype = str(rng.choice(["bf16", "bf16", "f32"]))
-        metric = str(rng.choice(["cos", "ip"]))
-        n = int(rng.choice([1, 33, 1000, 16384, 16385, 40000, 70001, 150000, 300000]))
-        if d == 1024:
-            n = min(n, 150000)
-        nq = int(rng.choice([1, 2, 4, 5, 31, 32, 33, 64, 100, 128, 129, 160, 200, 256, 257, 300]))
-        k = int(rng.choice([1, 5, 10, 10, 10, 50, 64, 65, 200, 256]))
-        if args.big:
-            d, dtype = 768, "bf16"
-            n = int(rng.choice([1_000_000, 1_700_001, 2_500_000]))
-            nq = int(rng.choice([5, 16, 33, 130]))
-            k = int(rng.choice([1, 10, 10, 50, 256]))
-        mfma_ok = dtype == "bf16" and d in (384, 512, 768, 1024)
-        algo = str(rng.choice(["auto", "scan", "mfma"])) if mfma_ok else str(rng.choice(["auto", "scan"]))
-        if args.big:
-            algo = "auto" if rng.random() < 0.4 else "mfma"     # "auto" may carry a dense host mask (masked MFMA pass)
-        if algo == "scan" and nq > 64:
-            nq = int(rng.choice([1, 4, 7, 33]))          # the scan serves 4 queries per pass: keep the sweep moving
-        use_mask = algo != "mfma" and rng.random() < (0.7 if args.big else 0.25) and (nq <= 8 or (mfma_ok and n >= 16384))
-        seed = int(rng.integers(0, 2**31))
-        faulthandler.dump_traceback_later(300 if args.big else 120, exit=True)
-        t0 = time.time()
-        q, c = oracle.golden_inputs(n, nq, d, seed, metric)
-        if rng.random() < 0.15 and n > 100:              # duplicates: exact ties
-            c[rng.integers(0, n, 20)] = c[0]
-        if args.big and rng.random() < 0.5:              # a cluster near the queries: heavy upper tail
-            u = q.mean(axis=0)
-            members = rng.choice(n, n // 25, replace=False)
-            c[members] += (rng.random(members.size).astype(np.float32) * np.float32(4.0))[:, None] * u
-        mask = (rng.random(n) < float(rng.choice([0.05, 0.3, 0.8]))) if use_mask else None
-        with ts.TheoremIndex.from_embeddings(c, dtype=dtype, metric=metric) as ix:
-            if mask is not None:
-                scores, idx = ix.search(q, k, mask=mask)
-            else:
-                scores, idx = ix.search(q, k, algo=algo)
-        rows = np.flatnonzero(mask) if mask is not None else np.arange(n)
-        qp, cp = oracle.prepared_inputs(q, c[rows], metric, dtype)
-        truth = oracle.scores_fp64(qp, cp)
-        m = min(k, rows.size)
-        local = np.full_like(idx, -1)
-        valid = idx >= 0
-        local[valid] = np.searchsorted(rows, idx[valid])
-        assert (idx[:, m:] == -1).all() and (idx[:, :m] >= 0).all(), "padding"
-        assert (rows[local[:, :m]] == idx[:, :m]).all(), "ids outside the allowed rows"
-        stats = oracle.check_topk_against_truth(truth, local, scores, k, gap=1e-6, score_tol=1e-5)
-        assert stats["recall"] == 1.0, stats
-        faulthandler.cancel_dump_traceback_later()
-        print(f"case {case}: n={n} d={d} {dtype} {metric} nq={nq} k={k} algo={algo} mask={use_mask} ok "
-              f"({time.time() - t0:.1f}s)", flush=True)
+        print(one_case(rng, args.big, case), flush=True)
     print(f"stress: {case} cases passed", flush=True)
 
 

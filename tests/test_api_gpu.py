@@ -1,0 +1,218 @@
+"""GPU tests of the host-side API added in round 2: index growth (reserve / append), the sharded search behind the C ABI
+(ts_shards_*, ts_comm_*), ordering of calls across streams, per-handle options.  Everything goes through libtsearch.so."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ts():
+    import theoremsearch_amd as ts
+    from theoremsearch_amd import _ffi
+    assert _ffi.device_count() > 0, "GPU tests need a HIP device"
+    return ts
+
+
+def check(q, c, metric, dtype, k, scores, idx):
+    qp, cp = oracle.prepared_inputs(q, c, metric, dtype)
+    stats = oracle.check_topk_against_truth(oracle.scores_fp64(qp, cp), idx, scores, k)
+    assert stats["recall"] == 1.0
+    return stats
+
+
+# ---- growth -----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype,metric", [("f32", "cos"), ("bf16", "ip")])
+def test_append_grows_the_index_and_searches_like_a_rebuild(ts, dtype, metric):
+    """New slogan_ids of the upsert pipeline (ec2/generate_embeddings/__main__.py:85-99: INSERT ... ON CONFLICT DO
+    UPDATE) are appended; the grown index answers bit for bit like one built from all the rows at once."""
+    q, c = oracle.golden_inputs(40_000, 9, 768, 5, metric)
+    with ts.TheoremIndex.from_embeddings(c[:1000], dtype=dtype, metric=metric) as ix:
+        assert ix.append(c[1000:1003]) == 1000            # fits the padding of the first allocation
+        assert ix.append(c[1003:20_000]) == 1003          # forces a move to a larger allocation
+        ix.reserve(40_000)
+        assert ix.append(c[20_000:]) == 20_000
+        assert ix.n == 40_000
+        scores, idx = ix.search(q, 10)
+        with ts.TheoremIndex.from_embeddings(c, dtype=dtype, metric=metric) as ref:
+            rs, ri = ref.search(q, 10)
+            assert np.array_equal(ix.download(), ref.download())
+        assert np.array_equal(idx, ri) and np.array_equal(scores, rs)
+        check(q, c, metric, dtype, 10, scores, idx)
+        # an UPDATE of an existing row is an upload at its slot
+        ix.upload(c[7:8], 30_000)
+        s2, i2 = ix.search(c[7:8], 2)
+        assert set(i2[0].tolist()) == {7, 30_000}
+
+
+def test_append_is_refused_while_views_exist_and_on_derived_indexes(ts):
+    from theoremsearch_amd import _ffi
+    q, c = oracle.golden_inputs(2000, 2, 768, 6, "ip")
+    with ts.TheoremIndex.from_embeddings(c[:300], metric="ip") as ix:
+        v = ix.view()
+        with pytest.raises(_ffi.TSearchError) as e:
+            ix.append(c[300:2000])                         # needs a move: the view holds the old rows
+        assert e.value.code == -5 and ix.n == 300
+        with pytest.raises(_ffi.TSearchError):
+            v.append(c[300:301])
+        v.close()
+        assert ix.append(c[300:2000]) == 300 and ix.n == 2000
+        sub = ix.subset(np.arange(0, 2000, 2))
+        with pytest.raises(_ffi.TSearchError):
+            sub.append(c[:1])
+        assert sub.download().shape == (1000, 768)         # reading a subset index is allowed
+        sub.close()
+
+
+def test_append_device_rows_with_row_offset(ts):
+    import torch
+    q, c = oracle.golden_inputs(5000, 3, 768, 8, "cos")
+    with ts.TheoremIndex(0, 768, dtype="bf16", metric="cos", row_offset=1_000_000) as ix:
+        dev = torch.from_numpy(c).cuda()
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            first = ix.append_device(dev.data_ptr(), "f32", 768, 5000, s.cuda_stream)
+        assert first == 1_000_000 and ix.n == 5000
+        scores, idx = ix.search(q, 5)                      # a call on another stream: ordered behind the append
+        check(q, c, "cos", "bf16", 5, scores, idx - 1_000_000)
+
+
+# ---- ordering across streams ---------------------------------------------------------------------------------------
+def test_calls_on_different_streams_share_the_scratch_safely(ts):
+    """Two searches enqueued back to back on two different streams of one handle, device outputs: the second must not
+    overwrite scratch the first still reads (per-handle scratch across streams)."""
+    import torch
+    q, c = oracle.golden_inputs(120_000, 256, 768, 9, "ip")
+    with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as ix:
+        want_s, want_i = ix.search(q, 10)
+        qa = torch.from_numpy(q).cuda()
+        qb = torch.from_numpy(q[::-1].copy()).cuda()
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        outs = [(torch.empty((256, 10), dtype=torch.float32, device="cuda"), torch.empty((256, 10), dtype=torch.int64, device="cuda"))
+                for _ in range(6)]
+        for rep in range(3):
+            ix.search_device(qa.data_ptr(), "f32", 256, 10, outs[2 * rep][0].data_ptr(), outs[2 * rep][1].data_ptr(), s1.cuda_stream)
+            ix.search_device(qb.data_ptr(), "f32", 256, 10, outs[2 * rep + 1][0].data_ptr(), outs[2 * rep + 1][1].data_ptr(), s2.cuda_stream)
+        ix.synchronize()
+        torch.cuda.synchronize()
+        for rep in range(3):
+            assert np.array_equal(outs[2 * rep][1].cpu().numpy(), want_i)
+            assert np.array_equal(outs[2 * rep + 1][1].cpu().numpy(), want_i[::-1])
+            assert np.array_equal(outs[2 * rep][0].cpu().numpy(), want_s)
+
+
+def test_upload_reads_rows_produced_on_the_default_stream(ts):
+    """embed_into_index's pattern: rows are produced by kernels on torch's default stream (handle 0) and
+    uploaded with stream = 0 = the index's own stream, which must be ordered behind them."""
+    import torch
+    n, d = 200_000, 768
+    g = torch.Generator(device="cuda").manual_seed(3)
+    base = torch.randn((n, d), generator=g, device="cuda", dtype=torch.float32)
+    with ts.TheoremIndex(n, d, dtype="f32", metric="ip") as ix:
+        for rep in range(3):
+            rows = base
+            for _ in range(20):                            # a queue of default-stream kernels the upload has to wait for
+                rows = rows * 1.0001 + 0.001
+            ix.upload_device(rows.data_ptr(), "f32", d, 0, n, torch.cuda.current_stream().cuda_stream)
+            want = rows.cpu().numpy()
+            ix.synchronize()
+            got = ix.download()
+            assert np.array_equal(got, want), f"repeat {rep}: the upload read its source before it was written"
+
+
+def test_options_are_per_handle(ts):
+    from theoremsearch_amd import _ffi
+    q, c = oracle.golden_inputs(70_000, 40, 768, 4, "ip")
+    with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as a, \
+            ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as b:
+        a.set_option("TS_MFMA_STAT", 0)                     # the chain of guaranteed bounds: more levels
+        _, _, sa = a.search(q, 10, algo="mfma", return_stats=True)
+        _, _, sb = b.search(q, 10, algo="mfma", return_stats=True)
+        assert sa["levels"] > sb["levels"] == 2
+        a.set_option("TS_MFMA_STAT", None)
+        _, _, sa = a.search(q, 10, algo="mfma", return_stats=True)
+        assert sa["levels"] == 2
+        with pytest.raises(_ffi.TSearchError):
+            a.set_option("TS_NO_SUCH_KNOB", 1)
+
+
+# ---- sharded search behind the C ABI --------------------------------------------------------------------------------
+@pytest.mark.parametrize("ngpu", [1, 3, 8])
+def test_shards_on_one_device_answer_like_the_whole_index(ts, ngpu):
+    """ts_shards_*: the corpus row-sharded over `ngpu` shards (all on device 0 here: the exchange uses device copies,
+    RCCL refuses two ranks on one GPU), routed uploads, packed per-shard results, merge: bit-identical to one index."""
+    from theoremsearch_amd.distributed import Shards
+    n, k = 90_001, 10
+    q, c = oracle.golden_inputs(n, 33, 768, 12, "ip")
+    c[70_000] = c[5]                                        # an exact tie across shards: the lower global id ranks first
+    with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as whole:
+        want_s, want_i = whole.search(q, k)
+    with Shards(n, 768, ngpu, dtype="bf16", metric="ip", devices=[0] * ngpu) as sh:
+        assert not sh.uses_rccl
+        assert sh.bounds(0)[0] == 0 and sh.bounds(ngpu - 1)[1] == n
+        for r0 in range(0, n, 25_000):                      # uploads that straddle shard boundaries
+            sh.upload(c[r0:r0 + 25_000], r0)
+        scores, idx = sh.search(q, k)
+    assert np.array_equal(idx, want_i) and np.array_equal(scores, want_s)
+    check(q, c, "ip", "bf16", k, scores, idx)
+
+
+def test_comm_of_one_rank_runs_the_rccl_exchange(ts):
+    """ts_comm_*: the RCCL communicator inside libtsearch (ncclCommInitRank, ncclAllGather) with world = 1 - all a one-GPU
+    box can run - must reproduce the plain search through search -> all-gather -> merge."""
+    from theoremsearch_amd import _ffi
+    lib = _ffi.load()
+    q, c = oracle.golden_inputs(50_000, 17, 768, 13, "cos")
+    ident = C.create_string_buffer(128)
+    _ffi.check(lib.ts_comm_unique_id(ident, 128))
+    comm = C.c_void_p()
+    _ffi.check(lib.ts_comm_create(0, 1, 0, ident, 128, C.byref(comm)))
+    try:
+        w, r, d = C.c_int32(), C.c_int32(), C.c_int32()
+        _ffi.check(lib.ts_comm_info(comm, C.byref(w), C.byref(r), C.byref(d)))
+        assert (w.value, r.value, d.value) == (1, 0, 0)
+        with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="cos", row_offset=777) as ix:
+            want_s, want_i = ix.search(q, 10)
+            scores = np.empty((17, 10), np.float32)
+            idx = np.empty((17, 10), np.int64)
+            for _ in range(3):
+                _ffi.check(lib.ts_comm_search(comm, ix.handle, _ffi.as_ptr(q), 0, 0, 17, 10, _ffi.as_ptr(scores), _ffi.as_ptr(idx), 0, None))
+                assert np.array_equal(idx, want_i) and np.array_equal(scores, want_s)
+            assert idx.min() >= 777
+    finally:
+        lib.ts_comm_destroy(comm)
+
+
+def test_sharded_searcher_device_pipeline_with_changing_queries(ts):
+    """ShardedSearcher.search_device - the loop bench.py times - with DIFFERENT queries every step (identical queries
+    would mask a result block that is read while it is rewritten): search on one stream, exchange + merge on the side
+    stream, double-buffered results."""
+    import torch
+    from theoremsearch_amd.distributed import ShardedSearcher
+    n, nq, k = 150_000, 64, 10
+    _, c = oracle.golden_inputs(n, 1, 768, 21, "ip")
+    rng = np.random.default_rng(5)
+    batches = [rng.standard_normal((nq, 768)).astype(np.float32) for _ in range(6)]
+    with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as ix:
+        want = [ix.search(b, k) for b in batches]
+        searcher = ShardedSearcher(index=ix)
+        dev = [torch.from_numpy(b).cuda() for b in batches]
+        torch.cuda.synchronize()
+        main = torch.cuda.Stream()
+        got = []
+        for step, qd in enumerate(dev):
+            s, i, done = searcher.search_device(qd.data_ptr(), "f32", nq, k, stream=main)
+            got.append((s, i, done))
+            if step >= 1:                                   # results of the previous step are still valid (double-buffered)
+                ps, pi, pdone = got[step - 1]
+                pdone.synchronize()
+                assert np.array_equal(pi.cpu().numpy(), want[step - 1][1]), f"step {step - 1}"
+                assert np.array_equal(ps.cpu().numpy(), want[step - 1][0])
+        got[-1][2].synchronize()
+        assert np.array_equal(got[-1][1].cpu().numpy(), want[-1][1])
+        searcher.close()

@@ -1,0 +1,145 @@
+"""Parity at BASELINE.json's FULL sizes, every query through the oracle's protocol (pinned ranks exact, near-tie runs as
+sets, scores within 1e-5 of the fp64 truth of the same operands):
+
+  configs[2]  10M x 768 bf16, 256 queries, top-10, algo = auto  (the level plan, estimated thresholds and tail-fit gate
+              of the MFMA path exactly as bench.py runs them; no query may need the exact re-run)
+  configs[1]  1M x 768 fp32, one query, top-10                 (the streaming scan)
+
+plus a fixed-seed slice of the randomised sweep of tests/stress_parity.py, small and --big (1M-2.5M rows, clusters,
+masks, k up to 256).  The fp64 truth is accumulated chunk by chunk on the host (oracle.ChunkedTruth) from the same
+generator bench.py uses (synthetic.synth_chunk); nothing here reads /root/reference.
+
+Matches the batched form of the reference's evaluation, util.cos_sim(q, s) + np.argsort(-S) per query
+(compare_embeddings.py:61,105), at the shapes the north-star names.
+"""
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from oracle import oracle
+
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+pytestmark = pytest.mark.gpu
+
+K = 10
+D = 768
+
+
+@pytest.fixture(scope="module")
+def ts():
+    import theoremsearch_amd as ts
+    from theoremsearch_amd import _ffi
+    assert _ffi.device_count() > 0, "GPU tests need a HIP device"
+    return ts
+
+
+def _threads():
+    return max(1, min(16, len(os.sched_getaffinity(0))))
+
+
+def build_index(ts, rows_total, dtype):
+    """Corpus of bench.py (chunks of synthetic.synth_chunk, stored as given: metric ip on unit rows)."""
+    import synthetic
+    bf16 = dtype == "bf16"
+    ch = synthetic.CHUNK_ROWS
+    ix = ts.TheoremIndex(rows_total, D, dtype=dtype, metric="ip")
+    chunks = list(range((rows_total + ch - 1) // ch))
+
+    def make(c):
+        data = synthetic.synth_chunk(c, ch, D, bf16=bf16)
+        hi = min(rows_total, (c + 1) * ch)
+        ix.upload(data[: hi - c * ch], c * ch)
+        return c
+
+    with ThreadPoolExecutor(_threads()) as ex:
+        list(ex.map(make, chunks))
+    return ix, chunks
+
+
+def chunked_truth_check(q_host, dtype, rows_total, chunks, idx, scores, k):
+    import synthetic
+    bf16 = dtype == "bf16"
+    ch = synthetic.CHUNK_ROWS
+    qf = oracle.bf16_bits_to_f32(q_host) if bf16 else q_host
+    truth = oracle.ChunkedTruth(qf, idx, k)
+
+    def chunk_scores(c):
+        data = synthetic.synth_chunk(c, ch, D, bf16=bf16)[: min(rows_total, (c + 1) * ch) - c * ch]
+        vals = oracle.bf16_bits_to_f32(data) if bf16 else data
+        return c, truth.scores_of_chunk(vals)
+
+    with ThreadPoolExecutor(max(1, _threads() // 2)) as ex:
+        for c, s in ex.map(chunk_scores, chunks):
+            truth.add_scores(s, c * ch)
+    return truth.check(scores, gap=1e-6, score_tol=1e-5)
+
+
+@pytest.mark.timeout(1500)
+def test_config2_10m_bf16_batch256_every_query(ts):
+    import synthetic
+    rows_total, nq = 10_000_000, 256
+    t0 = time.time()
+    ix, chunks = build_index(ts, rows_total, "bf16")
+    q = synthetic.synth_queries(0, nq, D, bf16=True)
+    t1 = time.time()
+    try:
+        scores, idx, st = ix.search(q, K, algo="auto", return_stats=True)
+        assert st["algo"] == 2 and st["levels"] == 2, st           # the MFMA path with one sample level, as bench.py runs it
+        assert st["fallback_queries"] == 0, st                      # no query needed the exact re-run
+        assert st["candidates"] >= nq * K
+        # deterministic: a second search returns the same bits
+        s2, i2 = ix.search(q, K, algo="auto")
+        assert np.array_equal(idx, i2) and np.array_equal(scores, s2)
+        # and the exact scan agrees on a slice of the batch (4 queries = one pass over the corpus)
+        s3, i3 = ix.search(q[:4], K, algo="scan")
+        assert np.array_equal(i3, idx[:4])
+    finally:
+        ix.close()
+    t2 = time.time()
+    stats = chunked_truth_check(q, "bf16", rows_total, chunks, idx, scores, K)
+    print(f"[fullsize] build {t1 - t0:.0f}s, search {t2 - t1:.0f}s, truth {time.time() - t2:.0f}s, {stats}")
+    assert stats["recall"] == 1.0 and stats["positions"] == nq * K
+    assert stats["pinned"] >= 0.99 * stats["positions"]
+
+
+@pytest.mark.timeout(600)
+def test_config1_1m_f32_batch1(ts):
+    import synthetic
+    rows_total = 1_000_000
+    ix, chunks = build_index(ts, rows_total, "f32")
+    try:
+        for b in range(3):                                        # three different single queries
+            q = synthetic.synth_queries(b, 1, D, bf16=False)
+            scores, idx, st = ix.search(q, K, return_stats=True)
+            assert st["algo"] == 1
+            stats = chunked_truth_check(q, "f32", rows_total, chunks, idx, scores, K)
+            assert stats["recall"] == 1.0 and stats["pinned"] == K
+    finally:
+        ix.close()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("seed,cases", [(101, 14), (202, 14), (303, 14)])
+def test_random_sweep_fixed_seeds(ts, seed, cases):
+    """tests/stress_parity.py with fixed seeds: d in {40, 384, 512, 768, 1024}, both dtypes and metrics, 1..300 queries,
+    k up to 256, every algorithm, masks, duplicated rows."""
+    import stress_parity
+    rng = np.random.default_rng(seed)
+    for c in range(cases):
+        print(stress_parity.one_case(rng, False, c, watchdog=False))
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("seed,cases", [(11, 3), (12, 3)])
+def test_random_sweep_big_fixed_seeds(ts, seed, cases):
+    """The --big sweep with fixed seeds: bf16 x 768 corpora of 1M-2.5M rows through the MFMA path, half of them with a
+    cluster of 4 % of the rows pulled towards the queries, most behind host masks, k up to 256."""
+    import stress_parity
+    rng = np.random.default_rng(seed)
+    for c in range(cases):
+        print(stress_parity.one_case(rng, True, c, watchdog=False))

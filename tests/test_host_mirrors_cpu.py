@@ -90,7 +90,7 @@ def test_topk_helper_on_adversarial_fixtures():
 
 @pytest.fixture(scope="module")
 def tiny_encoder():
-    return SentenceEncoder(num_layers=1, device="cpu")
+    return SentenceEncoder(num_layers=1, device="cpu", allow_random_init=True)
 
 
 def test_encoder_call_surface(tiny_encoder):

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def encoder():
     from theoremsearch_amd.encoder import SentenceEncoder
-    return SentenceEncoder(num_layers=2)          # random-init BERT-base-shaped stand-in on cuda:0
+    return SentenceEncoder(num_layers=2, allow_random_init=True)          # random-init BERT-base-shaped stand-in on cuda:0
 
 
 def test_cos_sim_and_semantic_search_match_oracle():

@@ -20,15 +20,23 @@ EMBEDDERS = {
 
 
 def get_embedder(embedder_alias: str) -> SentenceEncoder:
+    """``SentenceTransformer(EMBEDDERS[alias], device=...)`` + ``eval()``: needs the checkpoint in a local directory
+    (``$TS_MODEL_DIR/<name>``); raises when it is absent (no silent stand-in)."""
     model = SentenceEncoder(EMBEDDERS[embedder_alias])
     model.eval()
     return model
 
 
 def embed_texts(embedder, texts_to_embed: list[str], batch_size: int = 16):
-    """Normalised embeddings as ``list[list[float]]`` (reference returns ``embeddings.tolist()``)."""
-    embeddings = embedder.encode(texts_to_embed, normalize_embeddings=True, show_progress_bar=False,
-                                 batch_size=batch_size)
+    """Normalised embeddings as ``list[list[float]]`` (reference returns ``embeddings.tolist()``): a page smaller
+    than the batch size is encoded in this process, a larger one is fanned out over one replica per visible GPU
+    (``encode_multi_process(pool=None)``, embeddings.py:24-38)."""
+    if len(texts_to_embed) < batch_size:
+        embeddings = embedder.encode(texts_to_embed, normalize_embeddings=True, show_progress_bar=False,
+                                     batch_size=batch_size)
+    else:
+        embeddings = embedder.encode_multi_process(texts_to_embed, pool=None, normalize_embeddings=True,
+                                                   show_progress_bar=False, batch_size=batch_size)
     return embeddings.tolist()
 
 
