@@ -158,7 +158,10 @@ def test_shards_on_one_device_answer_like_the_whole_index(ts, ngpu):
         for r0 in range(0, n, 25_000):                      # uploads that straddle shard boundaries
             sh.upload(c[r0:r0 + 25_000], r0)
         scores, idx = sh.search(q, k)
-    assert np.array_equal(idx, want_i) and np.array_equal(scores, want_s)
+    # same ids; scores bit-identical while the shards run the same kernel as the whole index (small shards fall under
+    # the MFMA path's minimum size and take the scan, whose fp32 summation order differs in the last bit)
+    assert np.array_equal(idx, want_i)
+    assert np.array_equal(scores, want_s) if n // ngpu >= 16384 else np.allclose(scores, want_s, atol=1e-6)
     check(q, c, "ip", "bf16", k, scores, idx)
 
 

@@ -13,6 +13,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 
+from . import _ffi
 from .index import TheoremIndex
 
 
