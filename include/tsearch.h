@@ -278,6 +278,13 @@ int ts_pool_normalize(int device, const void *hidden, int h_dtype, const int64_t
 int ts_index_profile_enable(ts_index *ix, int enable);
 int ts_index_profile_read(ts_index *ix, int64_t *launches, double *total_ms, int64_t *rows_per_launch);
 
+/* Clock probe of the MFMA full pass (diagnostic build of the kernel, selected with option TS_MFMA_VARIANT = 3; timing of
+ * that build is not representative): the kernel stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) around its
+ * tile loop; this returns the median over workgroups of the last probed launch: in-kernel clock in GHz, shader cycles
+ * per unit (32 rows x 384 k), units per workgroup.  Zeros when no probe has run.
+ * (MI355X_MICROARCH.md "DVFS give-back" item 6.) */
+int ts_index_probe_read(ts_index *ix, double *ghz, double *cycles_per_unit, double *units_per_workgroup);
+
 /* ---- timing on a given stream (hipEvent pairs; bench.py measures kernels with these) ------- */
 int ts_timer_create(int device, ts_timer **out);
 int ts_timer_start(ts_timer *t, void *stream);

@@ -1,0 +1,346 @@
+// Batched search, bf16, d = 768: the same streaming structure as kernels_mfma.h (queries in registers, corpus
+// HBM -> LDS once per CU by LDS-DMA, fused threshold epilogue, one wave per SIMD with all 512 registers) built on
+// v_mfma_f32_16x16x32_bf16 instead of v_mfma_f32_32x32x16_bf16.
+//
+// Why a second shape: the full pass at batch 256 is bound by the package power limit, not by issue slots or HBM
+// (DESIGN.md section 3.2).  The 16x16x32 instruction does twice the K-depth per accumulator access (4 accumulator
+// registers per 16,384 flops instead of 16 per 32,768), the chip holds a higher clock on it for the same flops
+// (MI355X_MICROARCH.md "DVFS give-back" item 7: 1.12-1.15x), and its accumulators are small enough (NB * 8 registers
+// per tile) to live in architectural VGPRs, so the threshold test reads them directly (no v_accvgpr_read per register).
+//
+// Work split (one workgroup = 4 waves = one CU):
+//   * a tile is 32 corpus rows = two row blocks of 16; the batch is cut into blocks of 16 queries, query block j
+//     belongs to wave j % 4, slot j / 4: every wave holds NB = ceil(blocks / 4) blocks (64 * NB queries per launch:
+//     64, 128, 192 or 256), so partial batches load all four SIMDs evenly and there is no per-wave special case;
+//   * per 32-deep k-step a wave reads its two A fragments (16 rows x 32 k, one ds_read_b128 each) and issues 2 * NB
+//     MFMAs; a query fragment is 4 registers per (block, k-step): NB * 24 * 4 = 384 registers at NB = 4, the first
+//     kQV fragments in VGPRs, the rest in AGPRs (MFMA B operands may be either);
+//   * D[i][j] = <row i, query j>: lane l holds rows 4 (l >> 4) + {0..3} of each row block for query (l & 15) of each of
+//     its blocks, so thresholds are per lane and block; passing scores go to lane-private lists (one writer per
+//     workgroup and lane quarter: 4 * gridDim.x writers, 16 entries each), overflow to the query's shared list.
+//
+// The LDS image, the DMA ring, its counted waits and the barrier protocol are those of kernels_mfma.h (the 16-row
+// operand read of this shape is conflict-free on the same swizzled image: lane (r, q) reads chunk 4 (s & 1) + q of row r).
+//
+// Algorithmic traffic: rows * 2 d bytes per launch; flops 2 * queries * rows * d.
+#pragma once
+#include "kernels_mfma.h"
+
+namespace ts {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int kMfma16PrivCap = 16;   // entries of a lane-private candidate list (4 * gridDim.x writers per query)
+
+// MFMA statements with pinned register classes: accumulator and corpus fragment in VGPRs, query fragment in a VGPR
+// ("v" forms) or an AGPR ("a" forms) quadruple.  No pads inside: the A fragment comes straight from a ds_read (the
+// compiler's lgkmcnt wait covers it), the query fragments are written once before the loop, accumulators chain
+// MFMA -> MFMA; the only non-MFMA reader of an accumulator is the epilogue, behind mfma16_settle().
+__device__ __forceinline__ void mfma16_v_first(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma16_v(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma16_a_first(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b));
+}
+__device__ __forceinline__ void mfma16_a(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+}
+// wait states between the last MFMA writing an accumulator and its first VALU reader (hipcc pads nothing for asm)
+template <int NB>
+__device__ __forceinline__ void mfma16_settle(f32x4 (&acc)[2][NB]) {
+    if constexpr (NB == 4)
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]),
+                     "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
+    else if constexpr (NB == 3)
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[1][0]), "+v"(acc[1][1]),
+                     "+v"(acc[1][2]));
+    else if constexpr (NB == 2)
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+    else
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0][0]), "+v"(acc[1][0]));
+}
+
+// Threshold test of one query block: the lane's 8 scores (4 rows of each row block) against the block's threshold,
+// in 5 instructions with a fixed order (asm volatile statements keep their order among themselves and the MFMAs).
+// Returns the wave mask of lanes with a passing score; `m` = the lane's best score of the block.
+__device__ __forceinline__ u64 mfma16_block_test(const f32x4& a0, const f32x4& a1, float thr, float& m) {
+    u64 mask;
+    asm volatile(
+        "v_max3_f32 %0, %2, %3, %4\n\t"
+        "v_max3_f32 %0, %0, %5, %6\n\t"
+        "v_max3_f32 %0, %0, %7, %8\n\t"
+        "v_max_f32 %0, %0, %9\n\t"
+        "v_cmp_ge_f32 %1, %0, %10"
+        : "=&v"(m), "=s"(mask)
+        : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]), "v"(thr));
+    return mask;
+}
+
+// Append the passing scores of one query block (rare path: entered for a block only when some lane passed).  Written
+// for few instructions when ONE lane holds ONE passing score - the usual case: a slow wave holds up the other three
+// at the next barrier, so this path is paid four-fold.
+__device__ __forceinline__ void mfma16_append_block(const f32x4& a0, const f32x4& a1, float thr, float m, int qid, int writer,
+                                                    int nwriters, u32& cnt, int64_t row_base, const MfmaArgs& a) {
+    if (m >= thr) {
+        u64* mine = a.priv + ((int64_t)qid * nwriters + writer) * kMfma16PrivCap;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float s = (g < 4) ? a0[g & 3] : a1[g & 3];
+            if (s >= thr) {
+                const int64_t row = row_base + (g & 3) + 16 * (g >> 2);
+                // padding rows of the last tile, and the metadata filter: tested only for scores that pass the threshold
+                if (row < a.n && (!a.row_mask || ((a.row_mask[row >> 5] >> (row & 31)) & 1u))) {
+                    const u64 key = make_key(s, (u32)row);
+                    if (cnt < (u32)kMfma16PrivCap) {
+                        mine[cnt] = key;
+                    } else {
+                        const u32 pos = atomicAdd(&a.count[qid], 1u);
+                        if (pos < (u32)a.cap) a.cand[(int64_t)qid * a.cap + pos] = key;
+                    }
+                    ++cnt;
+                }
+            }
+        }
+    }
+}
+
+// NB = query blocks (of 16) per wave: the launch serves 64 * NB queries.
+// VARIANT 0 = the product kernel.  Timing-only diagnostics (wrong results): 1 = no epilogue, 2 = DMA stream only,
+// 7 = no DMA (MFMA + LDS reads), 4 = threshold test without the append path.  3 = product + clock probe: s_memtime / s_memrealtime around the tile loop into a.dbg
+// (4 words per workgroup: shader cycles, 100 MHz ticks, units, 0) - MI355X_MICROARCH.md "DVFS give-back" item 6.
+// SPARSE only changes the symbol (sample levels show up under their own name in kernel traces).
+template <int D, int NB, int VARIANT, bool SPARSE>
+__global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a) {
+    using dims = MfmaDims<D>;
+    constexpr bool kNoEpi = VARIANT == 1 || VARIANT == 7;
+    constexpr bool kNoDma = VARIANT == 7;
+    constexpr bool kNoMma = VARIANT == 2;
+    constexpr int kSteps = D / 32;                       // k-steps per tile
+    constexpr int kUnitSteps = dims::kUnitK / 32;        // k-steps per unit
+    constexpr int kUnits = dims::kUnits, kUnitBytes = dims::kUnitBytes, kSlots = dims::kSlots, kPieces = dims::kPieces;
+    constexpr int kUnitK = dims::kUnitK;
+    constexpr int kPieceEvery = kUnitSteps / kPieces;    // one DMA piece every so many k-steps
+    static_assert(kUnitSteps % kPieces == 0 && kPieceEvery >= 1, "DMA pieces must spread evenly over the k-steps");
+    static_assert(NB >= 1 && NB * kSteps * 4 <= 384, "query fragments must fit the register file");
+    constexpr int kFrags = NB * kSteps;                  // query fragments of this wave
+    constexpr int kQV = kFrags < 36 ? kFrags : 36;       // ... the first kQV of them in VGPRs (144 registers), the rest in AGPRs
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int G = gridDim.x;
+    const int nwriters = 4 * G;
+    const int writer = 4 * blockIdx.x + kq;
+    int qid[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) qid[b] = (b * 4 + wave) * 16 + r16;
+
+    const int64_t t0 = (a.ntiles * (int64_t)blockIdx.x) / G;
+    const int nt = (int)((a.ntiles * (int64_t)(blockIdx.x + 1)) / G - t0);
+    if (nt <= 0) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) a.pcount[(int64_t)qid[b] * nwriters + writer] = 0;
+        return;
+    }
+    const int nu = kUnits * nt;
+
+    // query fragments: fragment f = b * kSteps + ks holds q[qid[b]][32 ks + 8 kq .. + 8]
+    bf16x8 qv[kQV], qa[kFrags > kQV ? kFrags - kQV : 1];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const bf16x8* pq = (const bf16x8*)(a.q + (int64_t)qid[b] * D + 8 * kq);
+#pragma unroll
+        for (int ks = 0; ks < kSteps; ++ks) {
+            const int f = b * kSteps + ks;
+            if (f < kQV) qv[f < kQV ? f : 0] = pq[4 * ks];
+            else qa[f >= kQV ? f - kQV : 0] = pq[4 * ks];
+        }
+    }
+    float thr[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) thr[b] = a.thr[qid[b]];
+    // pin: the loads above complete here, outside the unit loop, in the register class the MFMA statements want
+#pragma unroll
+    for (int f = 0; f < kFrags; ++f) {
+        if (f < kQV) asm volatile("" : "+v"(qv[f < kQV ? f : 0]));
+        else asm volatile("" : "+a"(qa[f >= kQV ? f - kQV : 0]));
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(thr[b]));
+
+    // DMA source of this lane (as kernels_mfma.h): row 8w + (lane >> 3) of the tile, swizzled chunk of K-block 0 of the unit
+    const int drow = 8 * wave + (lane >> 3);
+    const int dchunk = (lane & 7) ^ ((drow >> 1) & 7);
+    const int64_t tile_bytes = (int64_t)kTileRows * D * 2;
+    const int64_t run_jump = tile_bytes * ((int64_t)a.run * a.tile_stride - a.run + 1);
+    const int64_t g0 = (t0 / a.run) * a.run * a.tile_stride + t0 % a.run;
+    const unsigned char* tile_src = (const unsigned char*)a.corpus + (int64_t)drow * (D * 2) + dchunk * 16 + g0 * tile_bytes;
+    int issue_run_pos = (int)(t0 % a.run);
+    int issue_u = 0, issue_ui = 0, issue_slot = 0;
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem + wave * 1024;
+
+    // operand read offsets inside a unit image: row block rb, k-step s -> (s >> 1) * 4096 + rb * 2048 + xo[s & 1]
+    const int lane_off = (r16 >> 3) * 1024 + (r16 & 7) * 128;
+    const int sw = (r16 >> 1) & 7;
+    int xo[2];
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) xo[sp] = lane_off + (((4 * sp + kq) ^ sw) << 4);
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+#define TS16_ISSUED()                                                                 \
+    do {                                                                              \
+        if (++issue_ui == kUnits) {                                                   \
+            issue_ui = 0;                                                             \
+            tile_src += (issue_run_pos + 1 == a.run) ? run_jump : tile_bytes;         \
+            issue_run_pos = (issue_run_pos + 1 == a.run) ? 0 : issue_run_pos + 1;     \
+        }                                                                             \
+        ++issue_u;                                                                    \
+        issue_slot = (issue_slot + 1 == kSlots) ? 0 : issue_slot + 1;                 \
+    } while (0)
+
+    const int ahead = (a.ahead >= 1 && a.ahead < kSlots) ? a.ahead : kSlots - 1;
+    for (int i = 0; i < ahead && issue_u < nu && !kNoDma; ++i) {
+        const unsigned char* src = tile_src + issue_ui * (kUnitK * 2);
+#pragma unroll
+        for (int j = 0; j < kPieces; ++j) lds_dma16(src + j * 128, lds0 + issue_slot * kUnitBytes + j * 4096);
+        TS16_ISSUED();
+    }
+    wait_keep_units<kPieces>(issue_u - 1);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    // A-fragment ring: k-steps s and s + 1 in flight, two row blocks each: af[2 (s & 1) + rb]
+    bf16x8 af[4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) af[2 * s + rb] = *(const bf16x8*)(smem + (s >> 1) * 4096 + rb * 2048 + xo[s & 1]);
+
+    f32x4 acc[2][NB];
+    u32 cnt[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) cnt[b] = 0;
+    int slot = 0, u = 0;
+    unsigned long long c_begin = 0, r_begin = 0;
+    if (VARIANT == 3) {
+        c_begin = __builtin_amdgcn_s_memtime();
+        r_begin = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+    }
+
+    // one MFMA of block B_, row block RB_, global k-step KS_ (all compile-time)
+#define TS16_MMA(RB_, B_, KS_, AF_)                                                                        \
+    do {                                                                                                   \
+        constexpr int f_ = (B_) * kSteps + (KS_);                                                          \
+        if constexpr ((KS_) == 0) {                                                                        \
+            if constexpr (f_ < kQV) mfma16_v_first(acc[RB_][B_], AF_, qv[f_ < kQV ? f_ : 0]);              \
+            else mfma16_a_first(acc[RB_][B_], AF_, qa[f_ >= kQV ? f_ - kQV : 0]);                          \
+        } else {                                                                                           \
+            if constexpr (f_ < kQV) mfma16_v(acc[RB_][B_], AF_, qv[f_ < kQV ? f_ : 0]);                    \
+            else mfma16_a(acc[RB_][B_], AF_, qa[f_ >= kQV ? f_ - kQV : 0]);                                \
+        }                                                                                                  \
+    } while (0)
+
+#define TS16_STEP(UI, S_)                                                                                  \
+    do {                                                                                                   \
+        constexpr int ks_ = (UI) * kUnitSteps + (S_);                                                      \
+        constexpr int r0_ = 2 * ((S_) & 1);                                                                \
+        if constexpr (!kNoMma) {                                                                           \
+            TS16_MMA(0, 0, ks_, af[r0_]);                                                                  \
+            TS16_MMA(1, 0, ks_, af[r0_ + 1]);                                                              \
+            if constexpr (NB > 1) { TS16_MMA(0, 1, ks_, af[r0_]); TS16_MMA(1, 1, ks_, af[r0_ + 1]); }      \
+            if constexpr (NB > 2) { TS16_MMA(0, 2, ks_, af[r0_]); TS16_MMA(1, 2, ks_, af[r0_ + 1]); }      \
+            if constexpr (NB > 3) { TS16_MMA(0, 3, ks_, af[r0_]); TS16_MMA(1, 3, ks_, af[r0_ + 1]); }      \
+            constexpr int n_ = (S_) + 2;                                                                   \
+            if constexpr (n_ < kUnitSteps) {                                                               \
+                af[r0_] = *(const bf16x8*)(unit + (n_ >> 1) * 4096 + xo[n_ & 1]);                          \
+                af[r0_ + 1] = *(const bf16x8*)(unit + (n_ >> 1) * 4096 + 2048 + xo[n_ & 1]);               \
+            } else {                                                                                       \
+                af[r0_] = *(const bf16x8*)(next_unit + ((n_ - kUnitSteps) >> 1) * 4096 + xo[n_ & 1]);      \
+                af[r0_ + 1] = *(const bf16x8*)(next_unit + ((n_ - kUnitSteps) >> 1) * 4096 + 2048 + xo[n_ & 1]); \
+            }                                                                                              \
+        }                                                                                                  \
+        if constexpr ((S_) % kPieceEvery == kPieceEvery - 1)                                               \
+            if (do_issue) lds_dma16(isrc + ((S_) / kPieceEvery) * 128, idst + ((S_) / kPieceEvery) * 4096); \
+    } while (0)
+
+#define TS16_UNIT(UI)                                                                                      \
+    do {                                                                                                   \
+        const int nslot = (slot + 1 == kSlots) ? 0 : slot + 1;                                             \
+        const unsigned char* unit = smem + slot * kUnitBytes;                                              \
+        const unsigned char* next_unit = smem + nslot * kUnitBytes;                                        \
+        /* certify unit u + 1 (own pieces, then everyone's); every wave is past unit u - 1: its slot is free */ \
+        if (u + 1 < nu && !kNoDma) wait_keep_units<kPieces>(issue_u - (u + 2));                            \
+        __builtin_amdgcn_s_barrier();                                                                      \
+        asm volatile("" ::: "memory");                                                                     \
+        const bool do_issue = issue_u < nu && !kNoDma;                                                     \
+        const unsigned char* isrc = tile_src + issue_ui * (kUnitK * 2);                                    \
+        const unsigned idst = lds0 + issue_slot * kUnitBytes;                                              \
+        TS16_STEP(UI, 0); TS16_STEP(UI, 1); TS16_STEP(UI, 2); TS16_STEP(UI, 3);                            \
+        TS16_STEP(UI, 4); TS16_STEP(UI, 5); TS16_STEP(UI, 6); TS16_STEP(UI, 7);                            \
+        if constexpr (kUnitSteps > 8) { TS16_STEP(UI, 8 % kUnitSteps); TS16_STEP(UI, 9 % kUnitSteps); TS16_STEP(UI, 10 % kUnitSteps); TS16_STEP(UI, 11 % kUnitSteps); } \
+        if (do_issue) TS16_ISSUED();                                                                       \
+        slot = nslot;                                                                                      \
+        ++u;                                                                                               \
+    } while (0)
+
+    static_assert(kUnitSteps == 8 || kUnitSteps == 12, "unit = 8 or 12 k-steps of 32");
+    for (int t = 0; t < nt; ++t) {
+        TS16_UNIT(0);
+        TS16_UNIT(1);
+        if constexpr (kUnits == 4) {
+            TS16_UNIT(2 % kUnits);
+            TS16_UNIT(3 % kUnits);
+        }
+        if constexpr (kNoMma) continue;
+        // The last k-step issued its MFMAs in block order, so with NB = 4 the results of block b are at least 6 MFMAs
+        // old when its test (5 VALU instructions per block, in order) reads them; fewer blocks need explicit wait states.
+        if constexpr (NB < 4 || kNoEpi) mfma16_settle<NB>(acc);
+        if constexpr (kNoEpi) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) asm volatile("" ::"v"(acc[0][b]), "v"(acc[1][b]));
+            continue;
+        }
+        // lane holds rows 4 kq + {0..3} of both row blocks for query qid[b]
+        float best[NB];
+        u64 hit[NB], any_hit = 0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            hit[b] = mfma16_block_test(acc[0][b], acc[1][b], thr[b], best[b]);
+            any_hit |= hit[b];
+        }
+        if (VARIANT == 4) {                      // diagnostic: the test without the append path
+            asm volatile("" ::"s"(any_hit));
+            continue;
+        }
+        if (__builtin_expect(any_hit != 0, 0)) {
+            const int64_t lt = t0 + t;
+            const int64_t tile_row = ((lt / a.run) * a.run * a.tile_stride + lt % a.run) * kTileRows;
+            const int64_t row_base = tile_row + 4 * kq;
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                if (hit[b] != 0) mfma16_append_block(acc[0][b], acc[1][b], thr[b], best[b], qid[b], writer, nwriters, cnt[b], row_base, a);
+        }
+    }
+#undef TS16_UNIT
+#undef TS16_STEP
+#undef TS16_MMA
+#undef TS16_ISSUED
+#pragma unroll
+    for (int b = 0; b < NB; ++b) a.pcount[(int64_t)qid[b] * nwriters + writer] = cnt[b];
+    if (VARIANT == 3 && a.dbg && threadIdx.x == 0) {
+        const unsigned long long c_end = __builtin_amdgcn_s_memtime();
+        const unsigned long long r_end = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* d = a.dbg + (size_t)blockIdx.x * 4;
+        d[0] = c_end - c_begin;
+        d[1] = r_end - r_begin;
+        d[2] = (unsigned long long)nu;
+        d[3] = 0;
+    }
+}
+
+}  // namespace ts

@@ -18,6 +18,7 @@
 #include "../../include/tsearch.h"
 #include "common.h"
 #include "kernels_mfma.h"
+#include "kernels_mfma16.h"
 #include "kernels_prep.h"
 #include "kernels_scan.h"
 #include "kernels_select.h"
@@ -112,7 +113,8 @@ struct ts_index {
     Knobs knobs;                                             // env at creation, then ts_index_set_option
     hipStream_t last_stream = nullptr;                       // stream of the previous call that used the scratch buffers
     hipEvent_t order_ev = nullptr;                           // orders a call on another stream behind it
-    unsigned long long* dbg = nullptr;                       // TS_MFMA_VARIANT=3: per-wave cycle sums
+    unsigned long long* dbg = nullptr;                       // TS_MFMA_VARIANT=3: per-wave cycle sums / clock probe
+    double probe_ghz = 0.0, probe_cycles_per_unit = 0.0, probe_units = 0.0;   // last clock probe (16x16 shape, VARIANT 3)
     // optional event brackets around the dominant kernel (ts_index_profile_*)
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;   // pairs: [2i] start, [2i+1] stop
@@ -888,9 +890,42 @@ static int launch_mfma(bool full_pass, int variant, int grid, hipStream_t st, co
     return TS_OK;
 }
 
+template <int D, int NB>
+static int launch_mfma16(bool full_pass, int variant, int grid, hipStream_t st, const MfmaArgs& a) {
+    constexpr int lds = MfmaDims<D>::kLds;
+    static std::atomic<unsigned long long> attr_done{0};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_done.fetch_or(bit, std::memory_order_release);
+    }
+    if (!full_pass) mfma16_topk_kernel<D, NB, 0, true><<<grid, kMfmaThreads, lds, st>>>(a);
+    else if (variant == 1) mfma16_topk_kernel<D, NB, 1, false><<<grid, kMfmaThreads, lds, st>>>(a);
+    else if (variant == 2) mfma16_topk_kernel<D, NB, 2, false><<<grid, kMfmaThreads, lds, st>>>(a);
+    else if (variant == 3) mfma16_topk_kernel<D, NB, 3, false><<<grid, kMfmaThreads, lds, st>>>(a);
+    else if (variant == 7) mfma16_topk_kernel<D, NB, 7, false><<<grid, kMfmaThreads, lds, st>>>(a);
+    else if (variant == 4) mfma16_topk_kernel<D, NB, 4, false><<<grid, kMfmaThreads, lds, st>>>(a);
+    else mfma16_topk_kernel<D, NB, 0, false><<<grid, kMfmaThreads, lds, st>>>(a);
+    HIP_TRY(hipGetLastError());
+    return TS_OK;
+}
+
+// Which MFMA shape serves this index: d = 768 runs the 16x16x32 kernel (kernels_mfma16.h) unless TS_MFMA_SHAPE=32 asks for
+// the 32x32x16 one (kernels_mfma.h), which also serves the other widths.
+static bool use_shape16(const ts_index* ix) { return ix->d == 768 && ix->knobs.get(K_MFMA_SHAPE, 16) != 32; }
+
 // Queries one launch of the MFMA kernel serves for this index / batch: d = 768 holds two query groups per wave
 // (256 queries; one group = half the matrix work when the batch is <= 128), d = 1024 one (128 queries).
 static int mfma_block_queries(const ts_index* ix, int nq) {
+    if (use_shape16(ix)) return 64 * std::min(4, std::max(1, (std::min(nq, 256) + 63) / 64));   // 16 queries x NB blocks x 4 waves
     if (ix->d == 1024) return 128;
     return nq <= 128 && ix->knobs.get(K_MFMA_GROUPS, 0) != 2 ? 128 : 256;
 }
@@ -900,21 +935,26 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
     // lists + spill absorb the run-to-run spread of the candidate count, so no safety margin in the rank
     const int kk = std::max(k, ix->knobs.get(K_MFMA_MIN_RANK, 1));
     const int variant = ix->knobs.get(K_MFMA_VARIANT, 0);
-    const int groups = mfma_block_queries(ix, nq) / 128;
+    const bool shape16 = use_shape16(ix);
+    const int groups = shape16 ? 0 : mfma_block_queries(ix, nq) / 128;
+    const int nb16 = shape16 ? mfma_block_queries(ix, nq) / 64 : 0;
     if (!ix->attr_done) {
         HIP_TRY(hipFuncSetAttribute((const void*)level_select_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelLds));
         HIP_TRY(hipFuncSetAttribute((const void*)level_select_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelLds));
         ix->attr_done = true;
     }
     const int grid = std::max(1, std::min(ix->knobs.get(K_MFMA_GRID, ix->cu_count), 2048));
-    const int nwriters = 2 * grid;
-    if (ix->priv_writers != nwriters) {
+    // lane-private candidate lists: 2 writers x 32 entries per workgroup and query (32x32 shape) or 4 x 16 (16x16 shape)
+    const int nwriters = (shape16 ? 4 : 2) * grid;
+    const int priv_cap = shape16 ? kMfma16PrivCap : kMfmaPrivCap;
+    if (ix->priv_writers < 4 * grid) {
         if (ix->priv) HIP_TRY(hipFree(ix->priv));
         if (ix->pcount) HIP_TRY(hipFree(ix->pcount));
         ix->priv = nullptr; ix->pcount = nullptr; ix->priv_writers = 0;
-        HIP_TRY(hipMalloc((void**)&ix->priv, (size_t)kMfmaQ * nwriters * kMfmaPrivCap * 8));
-        HIP_TRY(hipMalloc((void**)&ix->pcount, (size_t)kMfmaQ * nwriters * 4));
-        ix->priv_writers = nwriters;
+        static_assert(4 * kMfma16PrivCap == 2 * kMfmaPrivCap, "both shapes use the same list bytes per workgroup");
+        HIP_TRY(hipMalloc((void**)&ix->priv, (size_t)kMfmaQ * 4 * grid * kMfma16PrivCap * 8));
+        HIP_TRY(hipMalloc((void**)&ix->pcount, (size_t)kMfmaQ * 4 * grid * 4));
+        ix->priv_writers = 4 * grid;
     }
     init_thr_kernel<<<1, 256, 0, st>>>(ix->thr, nq, ix->fb_count, ix->stat);
     // Threshold of the full pass: by default extrapolated from ONE unthresholded sample (Gaussian tail of the
@@ -965,14 +1005,37 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         }
         hipEvent_t stop = full_pass ? prof_begin(ix, st, ix->n) : nullptr;  // only the full pass is bracketed
         int rc;
-        if (ix->d == 1024) rc = launch_mfma<1024, 1>(full_pass, variant, grid, st, a);
+        if (shape16 && nb16 == 4) rc = launch_mfma16<768, 4>(full_pass, variant, grid, st, a);
+        else if (shape16 && nb16 == 3) rc = launch_mfma16<768, 3>(full_pass, variant, grid, st, a);
+        else if (shape16 && nb16 == 2) rc = launch_mfma16<768, 2>(full_pass, variant, grid, st, a);
+        else if (shape16) rc = launch_mfma16<768, 1>(full_pass, variant, grid, st, a);
+        else if (ix->d == 1024) rc = launch_mfma<1024, 1>(full_pass, variant, grid, st, a);
         else if (ix->d == 512) rc = (groups == 1) ? launch_mfma<512, 1>(full_pass, variant, grid, st, a) : launch_mfma<512, 2>(full_pass, variant, grid, st, a);
         else if (ix->d == 384) rc = (groups == 1) ? launch_mfma<384, 1>(full_pass, variant, grid, st, a) : launch_mfma<384, 2>(full_pass, variant, grid, st, a);
         else if (groups == 1) rc = launch_mfma<768, 1>(full_pass, variant, grid, st, a);
         else rc = launch_mfma<768, 2>(full_pass, variant, grid, st, a);
         prof_end(stop, st);
         TS_TRY(rc);
-        if (a.dbg && full_pass) {
+        if (a.dbg && full_pass && shape16 && variant == 3) {
+            // clock probe (MI355X_MICROARCH.md "DVFS give-back" item 6): shader cycles / 100 MHz ticks around the tile loop,
+            // median over workgroups
+            std::vector<unsigned long long> h((size_t)grid * 4);
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost));
+            std::vector<double> ghz, cpu_;
+            for (int w = 0; w < grid; ++w)
+                if (h[w * 4 + 1] > 0 && h[w * 4 + 2] > 0) {
+                    ghz.push_back((double)h[w * 4] / (double)h[w * 4 + 1] * 0.1);
+                    cpu_.push_back((double)h[w * 4] / (double)h[w * 4 + 2]);
+                }
+            if (!ghz.empty()) {
+                std::sort(ghz.begin(), ghz.end());
+                std::sort(cpu_.begin(), cpu_.end());
+                ix->probe_ghz = ghz[ghz.size() / 2];
+                ix->probe_cycles_per_unit = cpu_[cpu_.size() / 2];
+                ix->probe_units = (double)h[2];
+            }
+        } else if (a.dbg && full_pass && !shape16) {
             std::vector<unsigned long long> h((size_t)grid * 16);
             HIP_TRY(hipStreamSynchronize(st));
             HIP_TRY(hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost));
@@ -988,7 +1051,7 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         l.priv = ix->priv;
         l.pcount = ix->pcount;
         l.nwriters = nwriters;
-        l.priv_cap = kMfmaPrivCap;
+        l.priv_cap = priv_cap;
         l.cand = ix->cand;
         l.count = ix->count;
         l.cap = kCandCap;
@@ -1465,6 +1528,15 @@ extern "C" int ts_index_profile_enable(ts_index* ix, int enable) {
             ix->ev_pool.push_back(e);
         }
     }
+    return TS_OK;
+}
+
+extern "C" int ts_index_probe_read(ts_index* ix, double* ghz, double* cycles_per_unit, double* units_per_workgroup) {
+    if (!ix) return fail(TS_ERR_INVALID, "index is NULL");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    if (ghz) *ghz = ix->probe_ghz;
+    if (cycles_per_unit) *cycles_per_unit = ix->probe_cycles_per_unit;
+    if (units_per_workgroup) *units_per_workgroup = ix->probe_units;
     return TS_OK;
 }
 

@@ -265,6 +265,12 @@ class TheoremIndex:
         _ffi.check(self._lib.ts_index_profile_read(self._h, C.byref(n), C.byref(ms), C.byref(rows)))
         return {"launches": n.value, "total_ms": ms.value, "rows_per_launch": rows.value}
 
+    def probe_read(self) -> dict:
+        """Last in-kernel clock probe of the MFMA full pass (option ``TS_MFMA_VARIANT`` = 3)."""
+        g, c, u = C.c_double(0), C.c_double(0), C.c_double(0)
+        _ffi.check(self._lib.ts_index_probe_read(self._h, C.byref(g), C.byref(c), C.byref(u)))
+        return {"ghz": g.value, "cycles_per_unit": c.value, "units_per_workgroup": u.value}
+
     # -- lifetime ---------------------------------------------------------------------------
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:
