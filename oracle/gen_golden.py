@@ -19,6 +19,11 @@ expected outputs.  Nothing of the reference's source text is written out.
 4. ``text_to_embed.json`` - one synthetic paper through the string assembly of
    ``app_create_embeddings.py:48-70`` (the expression is evaluated from the
    parsed reference module, not retyped).
+5. ``callsites.json`` - what the reference's own call-site bodies print / display:
+   ``compare_embeddings`` and ``evaluate_retrieval`` (``compare_embeddings.py:14-35,55-92``)
+   and ``search_theorems`` (``app_scratchpad.py:120-154``), taken from the parsed files and
+   executed around ``util.cos_sim`` = the published torch formula with a seeded stand-in
+   model and a recording ``st`` (exact score ties included).
 """
 import ast
 import json
@@ -272,6 +277,124 @@ def gen_text():
     print("text_to_embed", len(cases), repr(cases[0]["text_to_embed"][:60]))
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# 5. call-site bodies: the reference's own functions AROUND util.cos_sim, executed here
+# ----------------------------------------------------------------------------------------------------------------
+def stub_embedding(text: str, seed: int, d: int) -> np.ndarray:
+    """The stand-in model of the call-site fixtures: one seeded vector per distinct text (equal texts -> equal rows
+    -> exact score ties).  tests/ rebuild the same model from this rule."""
+    import zlib
+    return np.random.default_rng([seed, zlib.crc32(text.encode("utf-8"))]).standard_normal(d).astype(np.float32)
+
+
+class StubModel:
+    def __init__(self, seed, d):
+        self.seed, self.d = seed, d
+
+    def encode(self, texts, convert_to_tensor=False, **_):
+        single = isinstance(texts, str)
+        rows = np.stack([stub_embedding(t, self.seed, self.d) for t in ([texts] if single else texts)])
+        out = torch.from_numpy(rows[0] if single else rows)
+        return out if convert_to_tensor else out.numpy()
+
+
+class RecordingStreamlit:
+    """Records what search_theorems hands to streamlit (st.subheader / st.expander / st.markdown / st.info / st.write)."""
+
+    def __init__(self):
+        self.calls = []
+
+    def _rec(self, name):
+        def f(*a, **k):
+            self.calls.append([name] + [str(x) for x in a])
+        return f
+
+    def __getattr__(self, name):
+        if name == "expander":
+            outer = self
+
+            class Ctx:
+                def __init__(self, title):
+                    outer.calls.append(["expander", str(title)])
+
+                def __enter__(self):
+                    return self
+
+                def __exit__(self, *exc):
+                    return False
+            return Ctx
+        return self._rec(name)
+
+
+def extract_functions(path, names):
+    tree = ast.parse(open(path, encoding="utf-8").read())
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert sorted(n.name for n in keep) == sorted(names), [n.name for n in keep]
+    return ast.Module(body=keep, type_ignores=[])
+
+
+def gen_callsites():
+    """compare_embeddings (compare_embeddings.py:14-35: argmax + argsort()[::-1]), evaluate_retrieval (:55-92) and
+    search_theorems (app_scratchpad.py:120-154: np.argsort(-scores)[:5]) are pure Python around util.cos_sim.  Their
+    function bodies are taken from the parsed reference files and run with util.cos_sim = the published torch formula,
+    a model that returns seeded vectors, and a recording streamlit; what they print / display is the fixture."""
+    import contextlib
+    import io
+    import re
+    import types
+    util = types.SimpleNamespace(cos_sim=st_cos_sim)
+    ns = load_reference_metrics()
+    ns.update({"util": util, "np": np})
+    exec(compile(extract_functions(os.path.join(REF, "compare_embeddings.py"), ["compare_embeddings", "evaluate_retrieval"]),
+                 "compare_embeddings.py", "exec"), ns)
+    st = RecordingStreamlit()
+    ns2 = {"util": util, "np": np, "st": st, "re": re}
+    exec(compile(extract_functions(os.path.join(REF, "app_scratchpad.py"), ["search_theorems", "clean_latex_for_display"]),
+                 "app_scratchpad.py", "exec"), ns2)
+    out = {"recipe": "model.encode(text) = np.random.default_rng([seed, zlib.crc32(text.encode('utf-8'))]).standard_normal(d)"
+                     ".astype(float32), one row per text; util.cos_sim = F.normalize(p=2, dim=1) both sides + mm",
+           "cases": {}}
+    # compare_embeddings: 3 latex tokens vs 9 concepts, two concepts are the same text (an exact tie)
+    seed, d = 41, 64
+    latex = ["\\alpha", "\\mathbb{R}^n", "G / H"]
+    concepts = ["alpha", "real coordinate space", "quotient group", "tree", "quotient group", "scheme", "alpha", "leaf", "edge"]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        ns["compare_embeddings"](StubModel(seed, d), latex, concepts, top_k=4)
+    out["cases"]["compare_embeddings"] = {"seed": seed, "d": d, "latex_texts": latex, "concept_texts": concepts, "top_k": 4,
+                                          "stdout": buf.getvalue()}
+    # evaluate_retrieval: 40 theorems, 12 queries, graded qrels with one exact match per query
+    seed, d = 42, 96
+    theorems = [(f"theorem number {j} about object {j % 7}", f"paper{j % 5}") for j in range(40)]
+    queries = [(f"query {i} about object {i % 7}", f"paper{i % 5}") for i in range(12)]
+    rng = np.random.default_rng(7)
+    qrels = {i: {int(j): g for j, g in zip(rng.choice(40, size=4, replace=False), [1, 0.5, 2, 3])} for i in range(12)}
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        ns["evaluate_retrieval"](StubModel(seed, d), theorems, queries, qrels, top_k_report=3)
+    out["cases"]["evaluate_retrieval"] = {"seed": seed, "d": d, "theorems": theorems, "queries": queries,
+                                          "qrels": {str(q): {str(j): g for j, g in v.items()} for q, v in qrels.items()},
+                                          "top_k_report": 3, "stdout": buf.getvalue()}
+    # search_theorems: 30 theorems (two share a text), one query
+    seed, d = 43, 128
+    data = [{"type": ["theorem", "lemma", "proposition"][j % 3], "paper_title": f"Paper {j // 3}", "paper_url": f"http://example.org/{j // 3}",
+             "global_context": "" if j % 4 else "**Notations:**\nG is a graph.", "content": f"Statement {j}: $x_{{{j}}} = {j}$.",
+             "text_to_embed": f"Statement {j % 29}"} for j in range(30)]
+    model = StubModel(seed, d)
+    db = model.encode([t["text_to_embed"] for t in data], convert_to_tensor=True)
+    ns2["search_theorems"]("Statement 3", model, data, db)
+    titles = [c[1] for c in st.calls if c[0] == "expander"]
+    out["cases"]["search_theorems"] = {"seed": seed, "d": d, "theorems_data": data, "query": "Statement 3",
+                                       "expander_titles": titles, "calls": st.calls}
+    st2 = RecordingStreamlit()
+    ns2["st"] = st2
+    ns2["search_theorems"]("", model, data, db)
+    out["cases"]["search_theorems"]["empty_query_calls"] = st2.calls
+    with open(os.path.join(OUT, "callsites.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("callsites:", out["cases"]["compare_embeddings"]["stdout"].splitlines()[0], "|", titles[0])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -280,6 +403,7 @@ def main():
     gen_search()
     gen_adversarial()
     gen_text()
+    gen_callsites()
 
 
 if __name__ == "__main__":

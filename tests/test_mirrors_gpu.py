@@ -352,3 +352,29 @@ def test_view_handles_search_the_same_rows_concurrently():
             assert not bad
             with pytest.raises(ts.TSearchError):
                 v.upload(c[:1], 0)
+
+
+# ---- call-site bodies of the reference, executed by oracle/gen_golden.py -> tests/golden/callsites.json ----------------
+def test_callsite_mirrors_reproduce_the_reference_output_through_the_hip_path(capsys):
+    """compare_embeddings / evaluate_retrieval / search_theorems through libtsearch print and display exactly what the
+    reference's own function bodies did on the same model outputs (exact score ties included)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from callsites_common import RecordingStreamlit, StubModel, run_compare, run_evaluate
+    from conftest import load_json
+    from theoremsearch_amd import app_scratchpad, compare_embeddings as ce
+    cases = load_json("callsites.json")["cases"]
+    assert run_compare(ce, cases["compare_embeddings"], capsys) == cases["compare_embeddings"]["stdout"]
+    assert run_evaluate(ce, cases["evaluate_retrieval"], capsys) == cases["evaluate_retrieval"]["stdout"]
+    case = cases["search_theorems"]
+    model = StubModel(case["seed"], case["d"])
+    data = case["theorems_data"]
+    db = model.encode([t["text_to_embed"] for t in data])
+    st = RecordingStreamlit()
+    app_scratchpad.search_theorems(case["query"], model, data, db, st)          # the matrix, as the app passes it
+    assert [c[1] for c in st.calls if c[0] == "expander"] == case["expander_titles"]
+    import theoremsearch_amd as ts
+    with ts.TheoremIndex.from_embeddings(db, metric="cos") as ix:               # or an index kept across calls
+        st2 = RecordingStreamlit()
+        app_scratchpad.search_theorems(case["query"], model, data, ix, st2)
+        assert st2.calls == st.calls

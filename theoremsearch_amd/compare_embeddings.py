@@ -29,11 +29,14 @@ def compare_embeddings(model, latex_texts, concept_texts, top_k=3):
     sim_matrix = util.cos_sim(l_emb, c_emb)
     for i, latex in enumerate(latex_texts):
         sims = sim_matrix[i]
-        vals, idx = util.topk(sims, top_k)
-        print(f"{latex!r}  -> best match: {concept_texts[idx[0]]!r} (score {vals[0]:.4f})")
+        # the reference's two selections, including what they do on exact ties: the best match is the FIRST maximum
+        # (argmax, :28), the list is the reversed ascending sort (:31: among equal scores the higher index comes first)
+        best_idx = int(np.argmax(sims))
+        print(f"{latex!r}  -> best match: {concept_texts[best_idx]!r} (score {sims[best_idx]:.4f})")
+        order = np.lexsort((-np.arange(sims.shape[0]), -sims))[:top_k]     # score descending, then index descending
         print("  top matches:")
-        for rank, (j, v) in enumerate(zip(idx, vals), start=1):
-            print(f"    {rank}. {concept_texts[j]!r} (score {v:.4f})")
+        for rank, j in enumerate(order, start=1):
+            print(f"    {rank}. {concept_texts[j]!r} (score {sims[j]:.4f})")
         print()
 
 
