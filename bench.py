@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # name: (rows, dtype, nq)
     "c2": (1_000_000, "f32", 1),
+    "c2b": (1_000_000, "f32", 256),    # the same fp32 corpus, batch 256: the exact-fp32 MFMA path (kernels_mfma_f32.h)
     "c3": (10_000_000, "bf16", 256),
     "c4": (50_000_000, "bf16", 256),
     "c5": (10_000_000, "bf16", 256),   # encoder-in-loop: sentence-encoder forward feeds the C3 index
@@ -266,12 +267,15 @@ def main():
                                                   "this command (tools/run_profiles.sh), not an observation of this run"}
         except Exception:
             traffic = None
-    kernel_name = {"mfma": "mfma_topk_kernel", "scan": "scan_kernel"}.get(stats_algo or ("scan" if mask_ptr and nq <= 4 else None), "unknown")
+    kernel_name = {"mfma": "mfma16_topk_kernel" if (bf16 and D == 768) else ("mfma_f32_topk_kernel" if not bf16 else "mfma_topk_kernel"),
+                   "scan": "scan_kernel"}.get(stats_algo or ("scan" if mask_ptr and nq <= 4 else None), "unknown")
     if stats_algo is None and encoder is not None:
-        kernel_name = "mfma_topk_kernel"
-    roofline = {"bound": "mfma" if mfma_frac > hbm_frac else "hbm", "kernel": kernel_name,
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4),
-                "hbm_frac": round(hbm_frac, 4),
+        kernel_name = "mfma16_topk_kernel" if D == 768 else "mfma_topk_kernel"
+    by_mfma = mfma_frac > hbm_frac
+    roofline = {"bound": "mfma" if by_mfma else "hbm", "kernel": kernel_name,
+                "achieved": round(tflops if by_mfma else achieved, 1), "peak": mfma_peak if by_mfma else HBM_PEAK_GBS,
+                "unit": "TFLOP/s" if by_mfma else "GB/s", "frac": round(mfma_frac if by_mfma else hbm_frac, 4),
+                "hbm_achieved_gbs": round(achieved, 1), "hbm_peak_gbs": HBM_PEAK_GBS, "hbm_frac": round(hbm_frac, 4),
                 "mfma_achieved_tflops": round(tflops, 1), "mfma_peak_tflops": mfma_peak, "mfma_frac": round(mfma_frac, 4),
                 "mfma_frac_of_measured_gemm_rate": round(tflops / MFMA_RANDOM_DATA_GEMM_TFLOPS, 4) if bf16 else None,
                 "traffic": traffic,
@@ -354,7 +358,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"{rows_total}x{D} {dtype} corpus, batch-{nq} queries, top-{K} "
-                                   f"(BASELINE.json configs[{ {'c2': 1, 'c3': 2, 'c4': 3, 'c5': 4}[args.workload] }])" + (f", encoder forward in the loop ({args.seq_len} tokens/query, random-init BERT-base shape)" if encoder is not None else ""),
+                                   f"(BASELINE.json configs[{ {'c2': 1, 'c2b': 1, 'c3': 2, 'c4': 3, 'c5': 4}[args.workload] }])" + (f", encoder forward in the loop ({args.seq_len} tokens/query, random-init BERT-base shape)" if encoder is not None else ""),
                        "rows": rows_total, "dim": D, "batch": nq, "k": K,
                        **({"mask_frac": args.mask_frac} if args.mask_frac > 0 else {}),
                        "parallelism": f"corpus row-sharded x{world}" + ((", gloo rehearsal on one GPU" if args.share_gpu else (", ncclAllGather of per-shard top-k inside libtsearch (ts_comm)" if searcher.exchange == "native" else ", torch.distributed all-gather of per-shard top-k (RCCL)")) if use_dist else "")},

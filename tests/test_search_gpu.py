@@ -23,7 +23,9 @@ def ts():
 
 
 def algos_for(dtype, d):
-    return ["scan", "mfma"] if (dtype == "bf16" and d in (384, 512, 768, 1024)) else ["scan"]
+    if dtype == "bf16" and d in (384, 512, 768, 1024):
+        return ["scan", "mfma"]
+    return ["scan", "mfma"] if (dtype == "f32" and d == 768) else ["scan"]     # fp32 MFMA (exact fp32) at d = 768
 
 
 def check(q, c, metric, dtype, k, scores, idx):
@@ -539,3 +541,41 @@ def test_empty_and_invalid_arguments(ts):
     with ts.TheoremIndex(0, 16) as empty:
         s, i = empty.search(c[:2], 4)
         assert (i == -1).all() and np.isneginf(s).all()
+
+
+# ---- batched fp32: the exact-fp32 matrix path (v_mfma_f32_32x32x2_f32) ----------------------------------------------
+@pytest.mark.parametrize("n,nq,k,metric", [(200_000, 130, 10, "cos"), (70_001, 73, 200, "ip"), (16_384, 13, 1, "cos"),
+                                           (300_000, 256, 10, "ip")])
+def test_fp32_batches_run_on_the_fp32_mfma_path(ts, n, nq, k, metric):
+    """The reference's evaluation is an fp32 [Q x N] matrix with Q ~ 73 (compare_embeddings.py:61,105): batches of an fp32
+    index go through the fp32 matrix kernel (128 queries per launch) instead of ceil(Q / 4) scan passes - same protocol,
+    same answers as the scan at pinned ranks."""
+    q, c = oracle.golden_inputs(n, nq, 768, 1000 + nq, metric)
+    c[n // 2] = c[3]                                          # an exact tie
+    with ts.TheoremIndex.from_embeddings(c, dtype="f32", metric=metric) as ix:
+        scores, idx, st = ix.search(q, k, return_stats=True)             # auto
+        assert st["algo"] == 2 and st["fallback_queries"] == 0, st
+        check(q, c, metric, "f32", k, scores, idx)
+        s2, i2 = ix.search(q, k, algo="mfma")
+        assert np.array_equal(i2, idx) and np.array_equal(s2, scores)    # deterministic
+        s3, i3 = ix.search(q[:8], k, algo="scan")
+        assert np.array_equal(i3, idx[:8])
+        assert np.allclose(s3, scores[:8], atol=1e-6)
+        # a host mask that keeps a third of the rows: still the matrix path, still exact
+        mask = np.random.default_rng(n).random(n) < 0.34
+        ms, mi = ix.search(q, k, mask=mask)
+        keep = np.flatnonzero(mask)
+        qp, cp = oracle.prepared_inputs(q, c[keep], metric, "f32")
+        local = np.where(mi >= 0, np.searchsorted(keep, np.maximum(mi, 0)), -1)
+        stats = oracle.check_topk_against_truth(oracle.scores_fp64(qp, cp), local, ms, k)
+        assert stats["recall"] == 1.0 and mask[mi[mi >= 0]].all()
+
+
+def test_small_fp32_batches_stay_on_the_scan(ts):
+    q, c = oracle.golden_inputs(50_000, 12, 768, 77, "cos")
+    with ts.TheoremIndex.from_embeddings(c, dtype="f32", metric="cos") as ix:
+        _, _, st = ix.search(q, 10, return_stats=True)
+        assert st["algo"] == 1
+        ix.set_option("TS_MFMA_F32", 0)
+        _, _, st = ix.search(np.tile(q, (3, 1)), 10, return_stats=True)
+        assert st["algo"] == 1

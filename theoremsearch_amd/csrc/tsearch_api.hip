@@ -19,6 +19,7 @@
 #include "common.h"
 #include "kernels_mfma.h"
 #include "kernels_mfma16.h"
+#include "kernels_mfma_f32.h"
 #include "kernels_prep.h"
 #include "kernels_scan.h"
 #include "kernels_select.h"
@@ -608,6 +609,10 @@ __global__ void init_thr_kernel(float* thr, int nq, int* fb_count, unsigned long
 }
 
 static inline bool mfma_dim(int d) { return d == 384 || d == 512 || d == 768 || d == 1024; }
+// indexes the batched MFMA path serves: bf16 at the four widths, fp32 at d = 768 (exact-fp32 MFMA, kernels_mfma_f32.h)
+static inline bool mfma_index(const ts_index* ix) {
+    return (ix->dtype == TS_BF16 && mfma_dim(ix->d)) || (ix->dtype == TS_F32 && ix->d == 768 && ix->knobs.get(K_MFMA_F32, 1) != 0);
+}
 
 static int ensure_search_scratch(ts_index* ix, int k) {
     size_t z = 0;
@@ -636,7 +641,7 @@ static int ensure_search_scratch(ts_index* ix, int k) {
         TS_TRY(ensure(&p, &z, 16));
         ix->stat = (unsigned long long*)p;
     }
-    if (!ix->cand && ix->dtype == TS_BF16 && mfma_dim(ix->d)) {
+    if (!ix->cand && mfma_index(ix)) {
         void* p = nullptr;
         z = 0;
         TS_TRY(ensure(&p, &z, (size_t)kQBlock * kCandCap * 8));
@@ -918,13 +923,33 @@ static int launch_mfma16(bool full_pass, int variant, int grid, hipStream_t st, 
     return TS_OK;
 }
 
+static int launch_mfma_f32(bool full_pass, int variant, int grid, hipStream_t st, const MfmaArgs& a) {
+    constexpr int lds = MfmaF32Dims::kLds;
+    static std::atomic<unsigned long long> attr_done{0};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_f32_topk_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_f32_topk_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma_f32_topk_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_done.fetch_or(bit, std::memory_order_release);
+    }
+    if (!full_pass) mfma_f32_topk_kernel<0, true><<<grid, kMfmaThreads, lds, st>>>(a);
+    else if (variant == 1) mfma_f32_topk_kernel<1, false><<<grid, kMfmaThreads, lds, st>>>(a);
+    else mfma_f32_topk_kernel<0, false><<<grid, kMfmaThreads, lds, st>>>(a);
+    HIP_TRY(hipGetLastError());
+    return TS_OK;
+}
+
 // Which MFMA shape serves this index: d = 768 runs the 16x16x32 kernel (kernels_mfma16.h) unless TS_MFMA_SHAPE=32 asks for
 // the 32x32x16 one (kernels_mfma.h), which also serves the other widths.
-static bool use_shape16(const ts_index* ix) { return ix->d == 768 && ix->knobs.get(K_MFMA_SHAPE, 16) != 32; }
+static bool use_shape16(const ts_index* ix) { return ix->dtype == TS_BF16 && ix->d == 768 && ix->knobs.get(K_MFMA_SHAPE, 16) != 32; }
 
 // Queries one launch of the MFMA kernel serves for this index / batch: d = 768 holds two query groups per wave
 // (256 queries; one group = half the matrix work when the batch is <= 128), d = 1024 one (128 queries).
 static int mfma_block_queries(const ts_index* ix, int nq) {
+    if (ix->dtype == TS_F32) return kMfmaF32Queries;                                             // 32 fp32 queries x 4 waves
     if (use_shape16(ix)) return 64 * std::min(4, std::max(1, (std::min(nq, 256) + 63) / 64));   // 16 queries x NB blocks x 4 waves
     if (ix->d == 1024) return 128;
     return nq <= 128 && ix->knobs.get(K_MFMA_GROUPS, 0) != 2 ? 128 : 256;
@@ -1005,7 +1030,8 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         }
         hipEvent_t stop = full_pass ? prof_begin(ix, st, ix->n) : nullptr;  // only the full pass is bracketed
         int rc;
-        if (shape16 && nb16 == 4) rc = launch_mfma16<768, 4>(full_pass, variant, grid, st, a);
+        if (ix->dtype == TS_F32) rc = launch_mfma_f32(full_pass, variant, grid, st, a);
+        else if (shape16 && nb16 == 4) rc = launch_mfma16<768, 4>(full_pass, variant, grid, st, a);
         else if (shape16 && nb16 == 3) rc = launch_mfma16<768, 3>(full_pass, variant, grid, st, a);
         else if (shape16 && nb16 == 2) rc = launch_mfma16<768, 2>(full_pass, variant, grid, st, a);
         else if (shape16) rc = launch_mfma16<768, 1>(full_pass, variant, grid, st, a);
@@ -1080,6 +1106,14 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
     return TS_OK;
 }
 
+// Largest batch the streaming scan still serves faster than the MFMA path.  bf16: the MFMA pass is ~1.5x a scan pass of 4
+// queries.  fp32: the exact-fp32 matrix pass is bound by the matrix pipe (~3x a scan pass of 4 queries at 128 queries
+// per launch), so it pays from ~13 queries on.  Large k (4 keys per lane in the scan) moves both down to 1.
+static int scan_max_queries(const ts_index* ix, int k) {
+    if (k > 64) return 1;
+    return ix->knobs.get(K_SCAN_MAX_QUERIES, ix->dtype == TS_F32 ? 12 : 4);
+}
+
 static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_device, int32_t nq, int32_t k,
                        float* out_scores, int64_t* out_idx, int out_on_device, void* stream, int algo,
                        ts_search_stats* stats, const uint32_t* row_mask = nullptr, int mask_on_device = 0) {
@@ -1089,9 +1123,9 @@ static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_
     if (nq < 0) return fail(TS_ERR_INVALID, "nq = %d", nq);
     if (k < 1 || k > TS_MAX_K) return fail(TS_ERR_INVALID, "k = %d outside [1, %d]", k, TS_MAX_K);
     if (algo < TS_ALGO_AUTO || algo > TS_ALGO_MFMA) return fail(TS_ERR_INVALID, "algo %d", algo);
-    const bool mfma_ok = ix->dtype == TS_BF16 && mfma_dim(ix->d) && ix->n >= 1;
+    const bool mfma_ok = mfma_index(ix) && ix->n >= 1;
     if (algo == TS_ALGO_MFMA && !mfma_ok)
-        return fail(TS_ERR_UNSUPPORTED, "the MFMA path needs a bf16 index with d = 384, 512, 768 or 1024");
+        return fail(TS_ERR_UNSUPPORTED, "the MFMA path needs a bf16 index with d = 384, 512, 768 or 1024, or an fp32 index with d = 768");
     if (nq == 0) return TS_OK;
     std::lock_guard<std::mutex> lock(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));
@@ -1116,7 +1150,7 @@ static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_
         // masks leave the sample too few allowed rows to estimate from; device masks would need a count + sync first:
         // both go through the scan kernel, 4 queries per pass (or through a subset index).
         bool dense_host_mask = false;
-        if (!mask_on_device && mfma_dim(ix->d) && ix->dtype == TS_BF16 && nq > ix->knobs.get(K_SCAN_MAX_QUERIES, 4) &&
+        if (!mask_on_device && mfma_index(ix) && nq > scan_max_queries(ix, k) &&
             ix->n >= ix->knobs.get(K_MFMA_MIN_ROWS, 16384) && algo != TS_ALGO_SCAN) {
             int64_t allowed = 0;
             for (size_t w = 0; w < words; ++w) allowed += __builtin_popcount(row_mask[w]);
@@ -1133,8 +1167,7 @@ static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_
     // The scan serves 4 queries per pass at the HBM rate; the MFMA path serves up to 256 per pass but its pass is
     // ~1.7x longer (matrix + HBM load drops the clock): a handful of queries is faster through the scan.
     if (use == TS_ALGO_AUTO)
-        use = (mfma_ok && ix->n >= ix->knobs.get(K_MFMA_MIN_ROWS, 16384) && nq > (k > 64 ? 1 : ix->knobs.get(K_SCAN_MAX_QUERIES, 4))) ? TS_ALGO_MFMA
-                                                                                                          : TS_ALGO_SCAN;
+        use = (mfma_ok && ix->n >= ix->knobs.get(K_MFMA_MIN_ROWS, 16384) && nq > scan_max_queries(ix, k)) ? TS_ALGO_MFMA : TS_ALGO_SCAN;
     if (stats) stats->algo = use;
 
     float* dscores = out_scores;
