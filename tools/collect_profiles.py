@@ -33,7 +33,7 @@ def main(src, tag):
     if os.path.exists(tpath):
         traffic = json.load(open(tpath))
     notes = []
-    for w, kern in (("c3", "mfma_topk_kernel<768, 2, 0, false>"), ("c2", "scan_kernel")):
+    for w, kern in (("c3", "mfma16_topk_kernel<768, 4, 0, false>"), ("c2", "scan_kernel"), ("c2b", "mfma_f32_topk_kernel<0, false>")):
         stats = glob.glob(os.path.join(src, f"trace_{w}", "**", "*kernel_stats.csv"), recursive=True)
         if stats:
             shutil.copy(stats[0], os.path.join(out, f"{tag}_{w}_kernel_stats.csv"))
@@ -46,6 +46,16 @@ def main(src, tag):
             traffic[f"{w}_n1"] = int(hbm)
             notes.append(f"{w}: kernel {kern}: FETCH_SIZE {f_kib:.0f} KiB (x2 gfx950 correction) + WRITE_SIZE {w_kib:.0f} KiB "
                          f"= {hbm / 1e9:.3f} GB per launch")
+    for extra in ("clock_probe.json",):
+        if os.path.exists(os.path.join(src, extra)):
+            shutil.copy(os.path.join(src, extra), os.path.join(out, f"{tag}_{extra}"))
+    for w in ("c3", "c2", "c2b"):
+        b = os.path.join(src, f"bench_{w}.json")
+        if os.path.exists(b) and os.path.getsize(b) > 0:
+            shutil.copy(b, os.path.join(out, f"{tag}_bench_{w}.json"))
+    stats = glob.glob(os.path.join(src, "trace_shard", "**", "*kernel_stats.csv"), recursive=True)
+    if stats:
+        shutil.copy(stats[0], os.path.join(out, f"{tag}_shard_1p25M_kernel_stats.csv"))
     json.dump(traffic, open(tpath, "w"), indent=1)
     with open(os.path.join(out, f"{tag}_traffic_notes.txt"), "w") as f:
         f.write("HBM traffic per launch of the dominant kernel, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes),\n"
