@@ -87,7 +87,24 @@ struct MfmaArgs {
     int ahead;                     // units kept in flight by the DMA ring (1 .. kSlots - 1)
     int nq;                        // real queries of this launch: waves / groups holding only padding skip the matrix work
     unsigned long long* dbg;       // VARIANT 3 only: per-wave cycle sums
+    // first level of a search: thresholds are not read but set here (-inf for the nq_real real queries, +inf for padding)
+    // and workgroup 0 resets the per-search counters - the job of a separate one-block launch before
+    int first_level;
+    int nq_real;
+    int* fb_count;
+    unsigned long long* stat;
 };
+
+__device__ __forceinline__ float mfma_level_thr(const MfmaArgs& a, int qid) {
+    if (qid >= a.nq_real) return INFINITY;          // padding queries never produce candidates
+    return a.first_level ? -INFINITY : a.thr[qid];
+}
+__device__ __forceinline__ void mfma_level_begin(const MfmaArgs& a) {
+    if (a.first_level && blockIdx.x == 0 && threadIdx.x == 0) {
+        *a.fb_count = 0;
+        *a.stat = 0ull;
+    }
+}
 
 // One LDS-DMA wave-instruction: 64 lanes x 16 bytes from per-lane global addresses to
 // lds_dst + lane * 16 (lds_dst wave-uniform, in M0).  Inline asm on purpose: hipcc keeps no vmcnt
@@ -216,6 +233,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma_topk_kernel(MfmaArgs a) 
     const bool idle_a = wave * 32 >= a.nq;
     const bool idle_b = 128 + wave * 32 >= a.nq;  // second query group of this wave (GROUPS == 2)
 
+    mfma_level_begin(a);
     // this workgroup's contiguous share of the level's tiles (sequential pages: a round-robin deal of
     // tiles to workgroups measured 1.4x slower on the DMA stream)
     const int64_t t0 = (a.ntiles * (int64_t)blockIdx.x) / G;
@@ -241,7 +259,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma_topk_kernel(MfmaArgs a) 
             if (GROUPS == 2) qb[s] = pb[2 * s];
         }
     }
-    float thr_a = a.thr[qid_a], thr_b = (GROUPS == 2) ? a.thr[qid_b] : INFINITY;
+    float thr_a = mfma_level_thr(a, qid_a), thr_b = (GROUPS == 2) ? mfma_level_thr(a, qid_b) : INFINITY;
     // pin: these loads (and the compiler's waits for them) complete here, outside the unit loop,
     // and the fragments stay in the register class the MFMA statements want
 #pragma unroll

@@ -138,6 +138,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
 #pragma unroll
     for (int b = 0; b < NB; ++b) qid[b] = (b * 4 + wave) * 16 + r16;
 
+    mfma_level_begin(a);
     const int64_t t0 = (a.ntiles * (int64_t)blockIdx.x) / G;
     const int nt = (int)((a.ntiles * (int64_t)(blockIdx.x + 1)) / G - t0);
     if (nt <= 0) {
@@ -161,7 +162,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     }
     float thr[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) thr[b] = a.thr[qid[b]];
+    for (int b = 0; b < NB; ++b) thr[b] = mfma_level_thr(a, qid[b]);
     // pin: the loads above complete here, outside the unit loop, in the register class the MFMA statements want
 #pragma unroll
     for (int f = 0; f < kFrags; ++f) {

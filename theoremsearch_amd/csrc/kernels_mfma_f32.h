@@ -68,6 +68,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma_f32_topk_kernel(MfmaArgs
     const int writer = 2 * blockIdx.x + h;
     const int qid = wave * 32 + r;
 
+    mfma_level_begin(a);
     const int64_t t0 = (a.ntiles * (int64_t)blockIdx.x) / G;
     const int nt = (int)((a.ntiles * (int64_t)(blockIdx.x + 1)) / G - t0);
     if (nt <= 0) {
@@ -86,7 +87,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma_f32_topk_kernel(MfmaArgs
             else qa[c >= kQV ? c - kQV : 0] = pq[2 * c];
         }
     }
-    float thr = a.thr[qid];
+    float thr = mfma_level_thr(a, qid);
 #pragma unroll
     for (int c = 0; c < kChunks; ++c) {
         if (c < kQV) asm volatile("" : "+v"(qv[c < kQV ? c : 0]));

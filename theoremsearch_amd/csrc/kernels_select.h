@@ -96,26 +96,44 @@ struct LevelArgs {
 
 constexpr int kLevelSortMax = 8192;
 constexpr int kLevelThreads = 512;
-constexpr int kLevelLds = kLevelSortMax * 8 + (kLevelThreads / 64) * TS_MAX_K_INTERNAL * 8 + 16;
+constexpr int kLevelSmall = 2048;      // keys the direct sort takes (after the histogram cut)
+constexpr int kLevelBins = 1024;
+// LDS: gathered keys | short list (sorted) | per-wave lists of the streaming path | histogram | counters
+constexpr int kLevelLds = kLevelSortMax * 8 + kLevelSmall * 8 + (kLevelThreads / 64) * TS_MAX_K_INTERNAL * 8 + kLevelBins * 4 + 64;
 
-// KR = key registers per lane of the per-wave running top-k (1: kk <= 64, 4: kk <= 256).
+// KR = key registers per lane of the per-wave running top-k of the streaming path (1: kk <= 64, 4: kk <= 256).
+//
+// Selection of the `kl` best of up to 8192 gathered keys, two ways:
+//   * short path (the usual one): at most kLevelSmall keys -> one bitonic sort of them; more keys -> a 1024-bin histogram
+//     of the scores over [mean - 4 sd, mean + 8 sd] (LDS atomics), a scan of the bins from the top down to the bin that
+//     holds the kl-th best key, and the sort of just the keys in the bins above it (plus that bin);
+//   * streaming path (many equal scores in the cut bin: duplicates, saturated scores): every wave runs its slice through
+//     a running top-kl (WaveTopK) and the eight lists are merged by one sort - what this kernel always did before.
+// Both give the same `best[0 .. kl)`: the kl largest keys in descending order.
 template <int KR>
 __global__ void __launch_bounds__(kLevelThreads) level_select_kernel(LevelArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* keys = (u64*)smem;                                   // kLevelSortMax gathered candidates
-    u64* best = (u64*)(smem + kLevelSortMax * 8);             // 8 waves x kk, then sorted
-    u32* ctr = (u32*)(smem + kLevelSortMax * 8 + (kLevelThreads / 64) * TS_MAX_K_INTERNAL * 8);
+    u64* small = (u64*)(smem + kLevelSortMax * 8);            // short list, then sorted
+    u64* wlists = small + kLevelSmall;                        // streaming path: 8 waves x kl
+    u32* hist = (u32*)(wlists + (kLevelThreads / 64) * TS_MAX_K_INTERNAL);
+    u32* ctr = hist + kLevelBins;
     u32& fill = ctr[0];
     u32& produced = ctr[1];
     u32& base_shared = ctr[2];
+    u32& nsmall = ctr[3];
+    int& cut_bin = *(int*)&ctr[4];
+    double* red = (double*)&ctr[8];                           // 2 doubles: mean, sd (16-byte aligned: ctr is)
     const int q = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     if (threadIdx.x == 0) {
         fill = 0;
         produced = 0;
+        nsmall = 0;
     }
+    for (int i = threadIdx.x; i < kLevelBins; i += blockDim.x) hist[i] = 0;
     __syncthreads();
-    // gather: private lists ...
+    // gather: private lists (a writer's entries are loaded together: one round trip, not one per entry) ...
     for (int w = threadIdx.x; w < a.nwriters; w += blockDim.x) {
         const u32 made = a.pcount[(int64_t)q * a.nwriters + w];
         if (made == 0) continue;
@@ -123,8 +141,12 @@ __global__ void __launch_bounds__(kLevelThreads) level_select_kernel(LevelArgs a
         const u64* src = a.priv + ((int64_t)q * a.nwriters + w) * a.priv_cap;
         const u32 at = atomicAdd(&fill, n);
         atomicAdd(&produced, n);
-        for (u32 e = 0; e < n; ++e)
-            if (at + e < (u32)kLevelSortMax) keys[at + e] = src[e];
+        u64 v[32];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) v[e] = ((u32)e < n) ? src[e] : 0ull;
+#pragma unroll
+        for (int e = 0; e < 32; ++e)
+            if ((u32)e < n && at + e < (u32)kLevelSortMax) keys[at + e] = v[e];
     }
     // ... and the shared spill list
     const u32 raw = a.count[q];
@@ -146,33 +168,134 @@ __global__ void __launch_bounds__(kLevelThreads) level_select_kernel(LevelArgs a
     // the sample level of the estimated threshold also needs the sample's 32 best for the tail fit
     constexpr int kTailM = 32;
     const bool tail_fit = !a.final_level && a.tail_p > 0.0f;
-    const int kl = tail_fit ? max(kk, kTailM) : kk;  // entries kept per wave
+    const int kl = tail_fit ? max(kk, kTailM) : kk;  // entries wanted, sorted
 
-    // every wave streams its slice through a running top-kk (a key enters only if it beats the wave's
-    // kk-th: about kk ln(n / kk) insertions for n keys), then the waves' lists are merged by one sort
-    WaveTopK<KR> tk;
-    tk.init();
-    for (int i0 = wave * 64; i0 < cnt; i0 += nw * 64) {
-        const int i = i0 + lane;
-        const u64 key = (i < cnt) ? keys[i] : 0ull;
-        u64 m = __ballot(key > tk.thr);
-        while (m) {
-            const int src = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const u64 K = shfl_u64(key, src);
-            if (K > tk.thr) tk.insert(K, kl, lane);
+    // mean / sd of the gathered scores: the histogram's range, and the Gaussian-tail estimate of the sample level
+    const bool want_stats = cnt > kLevelSmall || (!a.final_level && a.z_tail > 0.0f && cnt >= 256);
+    double mean = 0.0, sd = 0.0;
+    if (want_stats) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const double v = (double)key_score(keys[i]);
+            s1 += v;
+            s2 += v * v;
+        }
+        s1 = wave_sum_f64_sel(s1);
+        s2 = wave_sum_f64_sel(s2);
+        double* part = (double*)wlists;   // free until the streaming path
+        if (lane == 0) {
+            part[2 * wave] = s1;
+            part[2 * wave + 1] = s2;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t1 = 0.0, t2 = 0.0;
+            for (int w = 0; w < nw; ++w) {
+                t1 += part[2 * w];
+                t2 += part[2 * w + 1];
+            }
+            const double m = t1 / cnt;
+            red[0] = m;
+            red[1] = sqrt(fmax(t2 / cnt - m * m, 0.0));
+        }
+        __syncthreads();
+        mean = red[0];
+        sd = red[1];
+    }
+
+    u64* best = small;
+    bool streamed = false;
+    if (cnt <= kLevelSmall) {
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) small[i] = keys[i];
+        if (threadIdx.x == 0) nsmall = (u32)cnt;
+    } else {
+        // histogram cut: bins of (12 / 1024) sd over [mean - 4 sd, mean + 8 sd], bin 1023 = everything above
+        const float lo = (float)(mean - 4.0 * sd);
+        const float inv = (sd > 0.0) ? (float)((double)kLevelBins / (12.0 * sd)) : 0.0f;
+        auto bin_of = [&](u64 key) -> int {
+            const float t = (key_score(key) - lo) * inv;
+            return (t >= (float)(kLevelBins - 1)) ? kLevelBins - 1 : (t > 0.0f ? (int)t : 0);
+        };
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) atomicAdd(&hist[bin_of(keys[i])], 1u);
+        __syncthreads();
+        if (wave == 0) {
+            // one wave scans the bins from the top: lane l owns bins [1023 - 16 l - 15, 1023 - 16 l]
+            u32 mine = 0;
+            for (int j = 0; j < 16; ++j) mine += hist[kLevelBins - 1 - 16 * lane - j];
+            u32 incl = mine;
+            for (int off = 1; off < 64; off <<= 1) {
+                const u32 up = __shfl_up((int)incl, off, 64);
+                if (lane >= off) incl += up;
+            }
+            const u64 reach = __ballot(incl >= (u32)kl);
+            int cb = 0;
+            if (reach) {
+                const int L = __ffsll((long long)reach) - 1;          // first lane group that reaches kl
+                u32 run = (u32)__shfl((int)(incl - mine), L, 64);
+                if (lane == L) {
+                    int j = 0;
+                    for (; j < 16; ++j) {
+                        run += hist[kLevelBins - 1 - 16 * L - j];
+                        if (run >= (u32)kl) break;
+                    }
+                    cut_bin = kLevelBins - 1 - 16 * L - min(j, 15);
+                }
+            } else if (lane == 0) {
+                cut_bin = 0;
+            }
+            (void)cb;
+        }
+        __syncthreads();
+        const int cb = cut_bin;
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const u64 key = keys[i];
+            if (bin_of(key) >= cb) {
+                const u32 at = atomicAdd(&nsmall, 1u);
+                if (at < (u32)kLevelSmall) small[at] = key;
+            }
         }
     }
-    int P = 2;
-    while (P < nw * kl) P <<= 1;
-    for (int i = threadIdx.x; i < P; i += blockDim.x) best[i] = 0ull;
     __syncthreads();
+    const u32 nsm = nsmall;
+    if (nsm <= (u32)kLevelSmall) {
+        int P = 2;
+        while (P < (int)nsm) P <<= 1;
+        if (P < kl) {
+            P = 2;
+            while (P < kl) P <<= 1;
+        }
+        for (int i = (int)nsm + threadIdx.x; i < P; i += blockDim.x) small[i] = 0ull;
+        bitonic_sort_desc(small, P, threadIdx.x, blockDim.x);
+    } else {
+        // streaming path over all gathered keys
+        streamed = true;
+        WaveTopK<KR> tk;
+        tk.init();
+        for (int i0 = wave * 64; i0 < cnt; i0 += nw * 64) {
+            const int i = i0 + lane;
+            const u64 key = (i < cnt) ? keys[i] : 0ull;
+            u64 m = __ballot(key > tk.thr);
+            while (m) {
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const u64 K = shfl_u64(key, src);
+                if (K > tk.thr) tk.insert(K, kl, lane);
+            }
+        }
+        int P = 2;
+        while (P < nw * kl) P <<= 1;
+        __syncthreads();
+        for (int i = threadIdx.x; i < P; i += blockDim.x) wlists[i] = 0ull;
+        __syncthreads();
 #pragma unroll
-    for (int r = 0; r < KR; ++r) {
-        const int s = r * 64 + lane;
-        if (s < kl) best[wave * kl + s] = tk.key[r];
+        for (int r = 0; r < KR; ++r) {
+            const int s = r * 64 + lane;
+            if (s < kl) wlists[wave * kl + s] = tk.key[r];
+        }
+        bitonic_sort_desc(wlists, P, threadIdx.x, blockDim.x);
+        best = wlists;
     }
-    bitonic_sort_desc(best, P, threadIdx.x, blockDim.x);
+    (void)streamed;
 
     if (threadIdx.x == 0) a.count[q] = 0;
     if (!a.final_level) {
@@ -205,32 +328,9 @@ __global__ void __launch_bounds__(kLevelThreads) level_select_kernel(LevelArgs a
             // query over the corpus are close to Gaussian (normalised, high-dimensional rows), so the sample's
             // mean + z * std estimates the score that only the wanted number of rows exceed.  NOT a bound: the
             // final level checks that at least min_fill candidates came back and re-runs the query exactly if not.
-            double s1 = 0.0, s2 = 0.0;
-            for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
-                const double v = (double)key_score(keys[i]);
-                s1 += v;
-                s2 += v * v;
-            }
-            s1 = wave_sum_f64_sel(s1);
-            s2 = wave_sum_f64_sel(s2);
-            double* red = (double*)best;  // the sorted list has been read (kth) by every thread that needs it
-            __syncthreads();
-            if (lane == 0) {
-                red[2 * wave] = s1;
-                red[2 * wave + 1] = s2;
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                double t1 = 0.0, t2 = 0.0;
-                for (int w = 0; w < nw; ++w) {
-                    t1 += red[2 * w];
-                    t2 += red[2 * w + 1];
-                }
-                const double mean = t1 / cnt, var = fmax(t2 / cnt - mean * mean, 0.0), sd = sqrt(var);
-                thr = fmaxf(thr, (float)(mean + (double)a.z_tail * sd));
-                const bool heavy_tail = (double)x_m > mean + ((double)a.tail_z + 0.5) * sd;
-                if (heavy_tail) thr = fmaxf(thr, thr_tail);
-            }
+            thr = fmaxf(thr, (float)(mean + (double)a.z_tail * sd));
+            const bool heavy_tail = (double)x_m > mean + ((double)a.tail_z + 0.5) * sd;
+            if (heavy_tail) thr = fmaxf(thr, thr_tail);
         }
         if (threadIdx.x == 0) a.thr[q] = thr;
         return;

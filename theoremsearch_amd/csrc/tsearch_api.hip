@@ -598,16 +598,6 @@ extern "C" int ts_index_download(ts_index* ix, void* host_rows, int64_t row0, in
 // ---------------------------------------------------------------------------------------------
 // search
 // ---------------------------------------------------------------------------------------------
-// Per search: thresholds of level 0 and the two per-search counters (one launch instead of memsets).
-__global__ void init_thr_kernel(float* thr, int nq, int* fb_count, unsigned long long* stat) {
-    const int i = threadIdx.x;
-    if (i < kMfmaQ) thr[i] = (i < nq) ? -INFINITY : INFINITY;
-    if (i == 0) {
-        *fb_count = 0;
-        *stat = 0ull;
-    }
-}
-
 static inline bool mfma_dim(int d) { return d == 384 || d == 512 || d == 768 || d == 1024; }
 // indexes the batched MFMA path serves: bf16 at the four widths, fp32 at d = 768 (exact-fp32 MFMA, kernels_mfma_f32.h)
 static inline bool mfma_index(const ts_index* ix) {
@@ -981,7 +971,6 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         HIP_TRY(hipMalloc((void**)&ix->pcount, (size_t)kMfmaQ * 4 * grid * 4));
         ix->priv_writers = 4 * grid;
     }
-    init_thr_kernel<<<1, 256, 0, st>>>(ix->thr, nq, ix->fb_count, ix->stat);
     // Threshold of the full pass: by default extrapolated from ONE unthresholded sample (Gaussian tail of the
     // sample's scores, verified afterwards by the candidate count); TS_MFMA_STAT=0 selects the chain of
     // guaranteed lower bounds (more sample rows to scan, no re-runs ever).
@@ -1023,6 +1012,10 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         a.cand = ix->cand;
         a.count = ix->count;
         a.cap = kCandCap;
+        a.first_level = (i == 0) ? 1 : 0;      // thresholds and per-search counters are initialised inside this launch
+        a.nq_real = nq;
+        a.fb_count = ix->fb_count;
+        a.stat = ix->stat;
         a.dbg = nullptr;
         if (variant >= 3) {
             if (!ix->dbg) HIP_TRY(hipMalloc((void**)&ix->dbg, 2048 * 4 * 4 * 8));
