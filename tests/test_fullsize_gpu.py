@@ -3,6 +3,8 @@ sets, scores within 1e-5 of the fp64 truth of the same operands):
 
   configs[2]  10M x 768 bf16, 256 queries, top-10, algo = auto  (the level plan, estimated thresholds and tail-fit gate
               of the MFMA path exactly as bench.py runs them; no query may need the exact re-run)
+  configs[4]  encoder-in-loop over that same 10M index: encoder forward + fused pooling on the device, embeddings handed
+              to the search by device pointer, all 256 answers checked
   configs[1]  1M x 768 fp32, one query, top-10                 (the streaming scan)
 
 plus a fixed-seed slice of the randomised sweep of tests/stress_parity.py, small and --big (1M-2.5M rows, clusters,
@@ -62,21 +64,50 @@ def build_index(ts, rows_total, dtype):
 
 
 def chunked_truth_check(q_host, dtype, rows_total, chunks, idx, scores, k):
+    return chunked_truth_check_many(dtype, rows_total, chunks, [(q_host, idx, scores)], k)[0]
+
+
+def chunked_truth_check_many(dtype, rows_total, chunks, answers, k):
+    """``answers``: list of (queries as stored [bf16 bits / f32], idx, scores); one pass over the corpus checks them all."""
     import synthetic
     bf16 = dtype == "bf16"
     ch = synthetic.CHUNK_ROWS
-    qf = oracle.bf16_bits_to_f32(q_host) if bf16 else q_host
-    truth = oracle.ChunkedTruth(qf, idx, k)
+    truths = [oracle.ChunkedTruth(oracle.bf16_bits_to_f32(q) if bf16 else q, idx, k) for q, idx, _ in answers]
 
     def chunk_scores(c):
         data = synthetic.synth_chunk(c, ch, D, bf16=bf16)[: min(rows_total, (c + 1) * ch) - c * ch]
-        vals = oracle.bf16_bits_to_f32(data) if bf16 else data
-        return c, truth.scores_of_chunk(vals)
+        vals = (oracle.bf16_bits_to_f32(data) if bf16 else data).astype(np.float64)
+        return c, [t.q64 @ vals.T for t in truths]
 
     with ThreadPoolExecutor(max(1, _threads() // 2)) as ex:
-        for c, s in ex.map(chunk_scores, chunks):
-            truth.add_scores(s, c * ch)
-    return truth.check(scores, gap=1e-6, score_tol=1e-5)
+        for c, ss in ex.map(chunk_scores, chunks):
+            for t, s in zip(truths, ss):
+                t.add_scores(s, c * ch)
+    return [t.check(scores, gap=1e-6, score_tol=1e-5) for t, (_, _, scores) in zip(truths, answers)]
+
+
+def encoder_in_loop_step(ix, nq, seq_len=32):
+    """One step of configs[4]: encoder forward + fused pooling on the device -> search by device pointer.  Returns the
+    bf16 bits of the embeddings the index multiplied (what the oracle needs), and the answer."""
+    import torch
+    from theoremsearch_amd.encoder import SentenceEncoder
+    enc = SentenceEncoder(allow_random_init=True, num_layers=2)
+    g = torch.Generator(device="cpu").manual_seed(5678)
+    tok = torch.randint(1000, 30000, (nq, seq_len), generator=g).cuda()
+    tok[:, 0], tok[:, -1] = 101, 102
+    mask = torch.ones_like(tok)
+    st = torch.cuda.Stream()
+    out_s = torch.empty((nq, K), dtype=torch.float32, device="cuda")
+    out_i = torch.empty((nq, K), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(2):                                             # twice: the second step reuses every buffer
+        with torch.cuda.stream(st), torch.inference_mode():
+            hidden = enc.model(input_ids=tok, attention_mask=mask).last_hidden_state
+            emb = enc.pool(hidden, mask, True)
+            ix.search_device(emb.data_ptr(), "f32", nq, K, out_s.data_ptr(), out_i.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    bits = oracle.f32_to_bf16_bits(emb.cpu().numpy())               # the search rounds fp32 queries to bf16 (RNE)
+    return bits, out_s.cpu().numpy(), out_i.cpu().numpy()
 
 
 @pytest.mark.timeout(1500)
@@ -98,13 +129,18 @@ def test_config2_10m_bf16_batch256_every_query(ts):
         # and the exact scan agrees on a slice of the batch (4 queries = one pass over the corpus)
         s3, i3 = ix.search(q[:4], K, algo="scan")
         assert np.array_equal(i3, idx[:4])
+        # configs[4], encoder-in-loop over the SAME 10M index: the sentence encoder's forward (PyTorch-ROCm; random-init
+        # stand-in, no weights offline) + the fused pooling kernel produce 256 query embeddings on the device, which
+        # are handed to the search by pointer (no host hop) - the loop bench.py --workload c5 times
+        enc_q, enc_scores, enc_idx = encoder_in_loop_step(ix, nq)
     finally:
         ix.close()
     t2 = time.time()
-    stats = chunked_truth_check(q, "bf16", rows_total, chunks, idx, scores, K)
-    print(f"[fullsize] build {t1 - t0:.0f}s, search {t2 - t1:.0f}s, truth {time.time() - t2:.0f}s, {stats}")
+    stats, enc_stats = chunked_truth_check_many("bf16", rows_total, chunks, [(q, idx, scores), (enc_q, enc_idx, enc_scores)], K)
+    print(f"[fullsize] build {t1 - t0:.0f}s, search {t2 - t1:.0f}s, truth {time.time() - t2:.0f}s, {stats}, encoder-in-loop {enc_stats}")
     assert stats["recall"] == 1.0 and stats["positions"] == nq * K
     assert stats["pinned"] >= 0.99 * stats["positions"]
+    assert enc_stats["recall"] == 1.0 and enc_stats["positions"] == nq * K
 
 
 @pytest.mark.timeout(600)

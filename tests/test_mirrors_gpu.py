@@ -380,3 +380,23 @@ def test_callsite_mirrors_reproduce_the_reference_output_through_the_hip_path(ca
         st2 = RecordingStreamlit()
         app_scratchpad.search_theorems(case["query"], model, data, ix, st2)
         assert st2.calls == st.calls
+
+
+def test_encode_multi_process_replicas_on_the_gpu(encoder):
+    """ec2/generate_embeddings/embeddings.py:32-38 fans a page out over devices; here two replicas share the one GPU of
+    the box (one process per replica): rows come back in input order and equal the single-process embeddings (both run
+    the same seeded weights in bf16; the fused pooling kernel is deterministic)."""
+    from theoremsearch_amd import generate_embeddings as ge
+    texts = [f"Theorem {i}: every tree on $n_{i}$ vertices has $n_{i} - 1$ edges " + "and more " * (i % 7) for i in range(61)]
+    want = encoder.encode(texts, batch_size=16, normalize_embeddings=True)
+    pool = encoder.start_multi_process_pool(["cuda:0", "cuda:0"])
+    try:
+        got = encoder.encode_multi_process(texts, pool=pool, batch_size=16, normalize_embeddings=True)
+    finally:
+        encoder.stop_multi_process_pool(pool)
+    assert got.shape == want.shape == (61, 768)
+    assert np.allclose(got, want, atol=2e-3)           # bf16 forward: batch composition differs between the two splits
+    assert np.allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-4)
+    # the mirror of embed_texts takes the multi-process branch for a page of at least batch_size texts
+    out = ge.embed_texts(encoder, texts, batch_size=16)
+    assert isinstance(out, list) and len(out) == 61 and np.allclose(np.array(out, dtype=np.float32), want, atol=2e-3)

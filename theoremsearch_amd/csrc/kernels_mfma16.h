@@ -1,4 +1,4 @@
-// Batched search, bf16, d = 768: the same streaming structure as kernels_mfma.h (queries in registers, corpus
+// Batched search, bf16, d = 768 or 1024: the same streaming structure as kernels_mfma.h (queries in registers, corpus
 // HBM -> LDS once per CU by LDS-DMA, fused threshold epilogue, one wave per SIMD with all 512 registers) built on
 // v_mfma_f32_16x16x32_bf16 instead of v_mfma_f32_32x32x16_bf16.
 //

@@ -888,6 +888,7 @@ static int launch_mfma(bool full_pass, int variant, int grid, hipStream_t st, co
 template <int D, int NB>
 static int launch_mfma16(bool full_pass, int variant, int grid, hipStream_t st, const MfmaArgs& a) {
     constexpr int lds = MfmaDims<D>::kLds;
+    constexpr bool kDiag = (D == 768 && NB == 4);     // the timing-only variants exist for the headline shape only
     static std::atomic<unsigned long long> attr_done{0};
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
@@ -895,20 +896,29 @@ static int launch_mfma16(bool full_pass, int variant, int grid, hipStream_t st, 
     if (!(attr_done.load(std::memory_order_acquire) & bit)) {
         HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        if constexpr (kDiag) {
+            HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        }
         attr_done.fetch_or(bit, std::memory_order_release);
     }
-    if (!full_pass) mfma16_topk_kernel<D, NB, 0, true><<<grid, kMfmaThreads, lds, st>>>(a);
-    else if (variant == 1) mfma16_topk_kernel<D, NB, 1, false><<<grid, kMfmaThreads, lds, st>>>(a);
-    else if (variant == 2) mfma16_topk_kernel<D, NB, 2, false><<<grid, kMfmaThreads, lds, st>>>(a);
-    else if (variant == 3) mfma16_topk_kernel<D, NB, 3, false><<<grid, kMfmaThreads, lds, st>>>(a);
-    else if (variant == 7) mfma16_topk_kernel<D, NB, 7, false><<<grid, kMfmaThreads, lds, st>>>(a);
-    else if (variant == 4) mfma16_topk_kernel<D, NB, 4, false><<<grid, kMfmaThreads, lds, st>>>(a);
-    else mfma16_topk_kernel<D, NB, 0, false><<<grid, kMfmaThreads, lds, st>>>(a);
+    if (!full_pass) {
+        mfma16_topk_kernel<D, NB, 0, true><<<grid, kMfmaThreads, lds, st>>>(a);
+    } else if (kDiag && variant != 0) {
+        if constexpr (kDiag) {
+            if (variant == 1) mfma16_topk_kernel<D, NB, 1, false><<<grid, kMfmaThreads, lds, st>>>(a);
+            else if (variant == 2) mfma16_topk_kernel<D, NB, 2, false><<<grid, kMfmaThreads, lds, st>>>(a);
+            else if (variant == 3) mfma16_topk_kernel<D, NB, 3, false><<<grid, kMfmaThreads, lds, st>>>(a);
+            else if (variant == 4) mfma16_topk_kernel<D, NB, 4, false><<<grid, kMfmaThreads, lds, st>>>(a);
+            else if (variant == 7) mfma16_topk_kernel<D, NB, 7, false><<<grid, kMfmaThreads, lds, st>>>(a);
+            else mfma16_topk_kernel<D, NB, 0, false><<<grid, kMfmaThreads, lds, st>>>(a);
+        }
+    } else {
+        mfma16_topk_kernel<D, NB, 0, false><<<grid, kMfmaThreads, lds, st>>>(a);
+    }
     HIP_TRY(hipGetLastError());
     return TS_OK;
 }
@@ -934,13 +944,22 @@ static int launch_mfma_f32(bool full_pass, int variant, int grid, hipStream_t st
 
 // Which MFMA shape serves this index: d = 768 runs the 16x16x32 kernel (kernels_mfma16.h) unless TS_MFMA_SHAPE=32 asks for
 // the 32x32x16 one (kernels_mfma.h), which also serves the other widths.
-static bool use_shape16(const ts_index* ix) { return ix->dtype == TS_BF16 && ix->d == 768 && ix->knobs.get(K_MFMA_SHAPE, 16) != 32; }
+static bool use_shape16(const ts_index* ix) {
+    return ix->dtype == TS_BF16 && (ix->d == 768 || ix->d == 1024) && ix->knobs.get(K_MFMA_SHAPE, 16) != 32;
+}
 
 // Queries one launch of the MFMA kernel serves for this index / batch: d = 768 holds two query groups per wave
 // (256 queries; one group = half the matrix work when the batch is <= 128), d = 1024 one (128 queries).
 static int mfma_block_queries(const ts_index* ix, int nq) {
     if (ix->dtype == TS_F32) return kMfmaF32Queries;                                             // 32 fp32 queries x 4 waves
-    if (use_shape16(ix)) return 64 * std::min(4, std::max(1, (std::min(nq, 256) + 63) / 64));   // 16 queries x NB blocks x 4 waves
+    if (use_shape16(ix)) {
+        // 16 queries x NB blocks x 4 waves; d = 1024 has registers for 3 blocks per wave, and a batch of more than 192
+        // queries is cut into equal launches (two of 128 for 256: both then stream at the HBM rate)
+        const int max_nb = ix->d == 1024 ? 3 : 4;
+        const int blocks = (std::min(nq, 256) + 63) / 64;
+        if (blocks <= max_nb) return 64 * std::max(1, blocks);
+        return 64 * ((blocks + 1) / 2);
+    }
     if (ix->d == 1024) return 128;
     return nq <= 128 && ix->knobs.get(K_MFMA_GROUPS, 0) != 2 ? 128 : 256;
 }
@@ -1024,6 +1043,9 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         hipEvent_t stop = full_pass ? prof_begin(ix, st, ix->n) : nullptr;  // only the full pass is bracketed
         int rc;
         if (ix->dtype == TS_F32) rc = launch_mfma_f32(full_pass, variant, grid, st, a);
+        else if (shape16 && ix->d == 1024 && nb16 == 3) rc = launch_mfma16<1024, 3>(full_pass, variant, grid, st, a);
+        else if (shape16 && ix->d == 1024 && nb16 == 2) rc = launch_mfma16<1024, 2>(full_pass, variant, grid, st, a);
+        else if (shape16 && ix->d == 1024) rc = launch_mfma16<1024, 1>(full_pass, variant, grid, st, a);
         else if (shape16 && nb16 == 4) rc = launch_mfma16<768, 4>(full_pass, variant, grid, st, a);
         else if (shape16 && nb16 == 3) rc = launch_mfma16<768, 3>(full_pass, variant, grid, st, a);
         else if (shape16 && nb16 == 2) rc = launch_mfma16<768, 2>(full_pass, variant, grid, st, a);
