@@ -109,7 +109,9 @@ __device__ __forceinline__ void mfma16_append_block(const f32x4& a0, const f32x4
 
 // NB = query blocks (of 16) per wave: the launch serves 64 * NB queries.
 // VARIANT 0 = the product kernel.  Timing-only diagnostics (wrong results): 1 = no epilogue, 2 = DMA stream only,
-// 7 = no DMA (MFMA + LDS reads), 4 = threshold test without the append path.  3 = product + clock probe: s_memtime / s_memrealtime around the tile loop into a.dbg
+// 7 = no DMA (MFMA + LDS reads), 4 = threshold test without the append path, 5 = product + per-unit cycle stamps around
+// the vmcnt wait, the barrier and each DMA issue (sums per wave into a.dbg; the stamps drain the LDS queue: read the
+// SHARES, not the length).  3 = product + clock probe: s_memtime / s_memrealtime around the tile loop into a.dbg
 // (4 words per workgroup: shader cycles, 100 MHz ticks, units, 0) - MI355X_MICROARCH.md "DVFS give-back" item 6.
 // SPARSE only changes the symbol (sample levels show up under their own name in kernel traces).
 template <int D, int NB, int VARIANT, bool SPARSE>
@@ -226,6 +228,8 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
 #pragma unroll
     for (int b = 0; b < NB; ++b) cnt[b] = 0;
     int slot = 0, u = 0;
+    unsigned long long t_vm = 0, t_bar = 0, t_dma = 0, t_all0 = 0;   // VARIANT 5: cycle sums of the waits / DMA issue
+    if (VARIANT == 5) t_all0 = cycle_stamp();
     unsigned long long c_begin = 0, r_begin = 0;
     if (VARIANT == 3) {
         c_begin = __builtin_amdgcn_s_memtime();
@@ -266,7 +270,12 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
             }                                                                                              \
         }                                                                                                  \
         if constexpr ((S_) % kPieceEvery == kPieceEvery - 1)                                               \
-            if (do_issue) lds_dma16(isrc + ((S_) / kPieceEvery) * 128, idst + ((S_) / kPieceEvery) * 4096); \
+            if (do_issue) {                                                                                \
+                unsigned long long d0_ = 0;                                                                \
+                if (VARIANT == 5) d0_ = cycle_stamp();                                                     \
+                lds_dma16(isrc + ((S_) / kPieceEvery) * 128, idst + ((S_) / kPieceEvery) * 4096);          \
+                if (VARIANT == 5) t_dma += cycle_stamp() - d0_;                                            \
+            }                                                                                              \
     } while (0)
 
 #define TS16_UNIT(UI)                                                                                      \
@@ -275,9 +284,13 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         const unsigned char* unit = smem + slot * kUnitBytes;                                              \
         const unsigned char* next_unit = smem + nslot * kUnitBytes;                                        \
         /* certify unit u + 1 (own pieces, then everyone's); every wave is past unit u - 1: its slot is free */ \
+        unsigned long long s0_ = 0, s1_ = 0;                                                               \
+        if (VARIANT == 5) s0_ = cycle_stamp();                                                             \
         if (u + 1 < nu && !kNoDma) wait_keep_units<kPieces>(issue_u - (u + 2));                            \
+        if (VARIANT == 5) s1_ = cycle_stamp();                                                             \
         __builtin_amdgcn_s_barrier();                                                                      \
         asm volatile("" ::: "memory");                                                                     \
+        if (VARIANT == 5) { t_vm += s1_ - s0_; t_bar += cycle_stamp() - s1_; }                             \
         const bool do_issue = issue_u < nu && !kNoDma;                                                     \
         const unsigned char* isrc = tile_src + issue_ui * (kUnitK * 2);                                    \
         const unsigned idst = lds0 + issue_slot * kUnitBytes;                                              \
@@ -333,6 +346,13 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
 #undef TS16_ISSUED
 #pragma unroll
     for (int b = 0; b < NB; ++b) a.pcount[(int64_t)qid[b] * nwriters + writer] = cnt[b];
+    if (VARIANT == 5 && a.dbg && lane == 0) {
+        unsigned long long* d = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 4;
+        d[0] = cycle_stamp() - t_all0;
+        d[1] = t_vm;
+        d[2] = t_bar;
+        d[3] = t_dma;
+    }
     if (VARIANT == 3 && a.dbg && threadIdx.x == 0) {
         const unsigned long long c_end = __builtin_amdgcn_s_memtime();
         const unsigned long long r_end = __builtin_amdgcn_s_memrealtime();

@@ -902,6 +902,7 @@ static int launch_mfma16(bool full_pass, int variant, int grid, hipStream_t st, 
             HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         }
         attr_done.fetch_or(bit, std::memory_order_release);
     }
@@ -914,6 +915,7 @@ static int launch_mfma16(bool full_pass, int variant, int grid, hipStream_t st, 
             else if (variant == 3) mfma16_topk_kernel<D, NB, 3, false><<<grid, kMfmaThreads, lds, st>>>(a);
             else if (variant == 4) mfma16_topk_kernel<D, NB, 4, false><<<grid, kMfmaThreads, lds, st>>>(a);
             else if (variant == 7) mfma16_topk_kernel<D, NB, 7, false><<<grid, kMfmaThreads, lds, st>>>(a);
+            else if (variant == 5) mfma16_topk_kernel<D, NB, 5, false><<<grid, kMfmaThreads, lds, st>>>(a);
             else mfma16_topk_kernel<D, NB, 0, false><<<grid, kMfmaThreads, lds, st>>>(a);
         }
     } else {
@@ -1075,6 +1077,17 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
                 ix->probe_ghz = ghz[ghz.size() / 2];
                 ix->probe_cycles_per_unit = cpu_[cpu_.size() / 2];
                 ix->probe_units = (double)h[2];
+            }
+        } else if (a.dbg && full_pass && shape16 && variant == 5) {
+            std::vector<unsigned long long> h((size_t)grid * 16);
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost));
+            const double units = (double)(lv.back().ntiles * MfmaDims<768>::kUnits) / grid;
+            for (int wv = 0; wv < 4; ++wv) {
+                double tot = 0, vm = 0, bar = 0, dma = 0;
+                for (int w = wv; w < grid * 4; w += 4) { tot += h[w * 4]; vm += h[w * 4 + 1]; bar += h[w * 4 + 2]; dma += h[w * 4 + 3]; }
+                fprintf(stderr, "[tsearch stamps16] wave %d per unit: total %.0f cycles, vmcnt wait %.0f, barrier wait %.0f, DMA issue %.0f (6 pieces; stamp cost ~40 each included)\n",
+                        wv, tot / grid / units, vm / grid / units, bar / grid / units, dma / grid / units);
             }
         } else if (a.dbg && full_pass && !shape16) {
             std::vector<unsigned long long> h((size_t)grid * 16);
