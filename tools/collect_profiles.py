@@ -16,9 +16,14 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def newest(paths):
+    """gpurun merges every run's files into the same directory: the latest run's file is the one that counts."""
+    return sorted(paths, key=os.path.getmtime)[-1:] if paths else []
+
+
 def pmc_per_launch(d, counter, kernel_substr):
     vals = []
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter and kernel_substr in r["Kernel_Name"]:
                 vals.append(float(r["Counter_Value"]))
@@ -34,7 +39,7 @@ def main(src, tag):
         traffic = json.load(open(tpath))
     notes = []
     for w, kern in (("c3", "mfma16_topk_kernel<768, 4, 0, false>"), ("c2", "scan_kernel"), ("c2b", "mfma_f32_topk_kernel<0, false>")):
-        stats = glob.glob(os.path.join(src, f"trace_{w}", "**", "*kernel_stats.csv"), recursive=True)
+        stats = newest(glob.glob(os.path.join(src, f"trace_{w}", "**", "*kernel_stats.csv"), recursive=True))
         if stats:
             shutil.copy(stats[0], os.path.join(out, f"{tag}_{w}_kernel_stats.csv"))
         fetch = pmc_per_launch(os.path.join(src, f"pmc_{w}_FETCH_SIZE"), "FETCH_SIZE", kern)
@@ -53,7 +58,7 @@ def main(src, tag):
         b = os.path.join(src, f"bench_{w}.json")
         if os.path.exists(b) and os.path.getsize(b) > 0:
             shutil.copy(b, os.path.join(out, f"{tag}_bench_{w}.json"))
-    stats = glob.glob(os.path.join(src, "trace_shard", "**", "*kernel_stats.csv"), recursive=True)
+    stats = newest(glob.glob(os.path.join(src, "trace_shard", "**", "*kernel_stats.csv"), recursive=True))
     if stats:
         shutil.copy(stats[0], os.path.join(out, f"{tag}_shard_1p25M_kernel_stats.csv"))
     json.dump(traffic, open(tpath, "w"), indent=1)

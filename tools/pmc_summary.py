@@ -7,7 +7,8 @@ import sys
 from collections import defaultdict
 
 def main(d):
-    files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+    import os
+    files = sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)[-1:]   # latest run only
     rows = []
     for f in files:
         rows += list(csv.DictReader(open(f)))
