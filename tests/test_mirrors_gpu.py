@@ -400,3 +400,25 @@ def test_encode_multi_process_replicas_on_the_gpu(encoder):
     # the mirror of embed_texts takes the multi-process branch for a page of at least batch_size texts
     out = ge.embed_texts(encoder, texts, batch_size=16)
     assert isinstance(out, list) and len(out) == 61 and np.allclose(np.array(out, dtype=np.float32), want, atol=2e-3)
+
+
+def test_generate_embeddings_appends_new_slogan_ids(encoder):
+    """The growing form of the upsert loop (ec2/generate_embeddings/__main__.py:85-99): a slogan_id the slot map does not
+    know is an INSERT (appended behind the last row), a known one is skipped, or re-embedded in place with overwrite."""
+    import theoremsearch_amd as ts
+    from theoremsearch_amd import generate_embeddings as ge
+    rows = [{"slogan_id": 1000 + 7 * i, "slogan": f"Slogan {i}: a tree on {i} vertices has {i - 1} edges."} for i in range(150)]
+    pages = [rows[i:i + 64] for i in range(0, 150, 64)]
+    slots = {}
+    with ts.TheoremIndex(0, 768, dtype="bf16", metric="ip") as ix:
+        assert ge.generate_embeddings(pages[:2], "gemma", ix, embedder=encoder, slots=slots) == 128
+        assert ix.n == 128 and slots[1000] == 0 and slots[1000 + 7 * 127] == 127
+        assert ge.generate_embeddings(pages, "gemma", ix, embedder=encoder, slots=slots) == 22       # only the new ids
+        assert ix.n == 150 and len(slots) == 150
+        want = encoder.encode([r["slogan"] for r in rows], normalize_embeddings=True, batch_size=16)
+        scores, idx = ix.search(want[[3, 140]], 1)
+        assert idx[:, 0].tolist() == [slots[rows[3]["slogan_id"]], slots[rows[140]["slogan_id"]]] and (scores[:, 0] > 0.99).all()
+        before = ix.download(5, 1).copy()
+        rows[5]["slogan"] = "Completely different text about schemes."
+        assert ge.generate_embeddings([rows[:8]], "gemma", ix, embedder=encoder, slots=slots, overwrite=True) == 8
+        assert ix.n == 150 and not np.array_equal(ix.download(5, 1), before)

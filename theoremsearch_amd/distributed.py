@@ -85,7 +85,21 @@ class ShardedSearcher:
         self.exchange = exchange
         self.backend = backend
         if exchange == "native" and self.world > 1:
-            self._init_native_comm()
+            try:
+                self._init_native_comm()
+            except Exception as e:            # RCCL not loadable / communicator refused: the same block goes over torch.distributed
+                import warnings
+                warnings.warn(f"native RCCL exchange unavailable ({e}); falling back to torch.distributed")
+                ok = False
+            else:
+                ok = True
+            # every rank must take the same path: one all-reduce of the outcome (start-up, not the search path)
+            import torch
+            flag = torch.tensor([1 if ok else 0], device=torch.device("cuda", index.device) if backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if int(flag.item()) == 0:
+                self.close()
+                self.exchange = "torch"
 
     # -- construction ---------------------------------------------------------------------------------------------
     @classmethod
