@@ -14,6 +14,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The first `import torch` on a fresh box can take minutes while the image pages in: do it here, outside any test's
+    # timeout (pytest.ini: 300 s per test), instead of inside whichever test happens to need it first.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
 
 
 def golden_path(name):

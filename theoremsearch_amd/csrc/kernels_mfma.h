@@ -393,7 +393,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma_topk_kernel(MfmaArgs a) 
         if (GROUPS == 2 && !(NOB)) hit_b = __any(max16(acc_b) >= thr_b);                                          \
         if (__builtin_expect(hit_a || hit_b, 0)) {                                                                \
             const int64_t lt = t0 + t; /* level tile -> global tile -> first row */                               \
-            const int64_t tile_row = ((lt / a.run) * a.run * a.tile_stride + lt % a.run) * kTileRows;             \
+            const int64_t tile_row = (a.run == 1 ? lt * a.tile_stride : (lt / a.run) * a.run * a.tile_stride + lt % a.run) * kTileRows; \
             const int64_t row_base = tile_row + 4 * h;                                                            \
             if (tile_row + kTileRows <= a.n) {                                                                    \
                 if (hit_a) mfma_append<true>(acc_a, thr_a, qid_a, writer, nwriters, cnt_a, row_base, a);          \

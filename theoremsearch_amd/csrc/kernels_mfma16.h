@@ -31,6 +31,12 @@ namespace ts {
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int kMfma16PrivCap = 16;   // entries of a lane-private candidate list (4 * gridDim.x writers per query)
+// Full pass: candidates are staged in LDS (16 bytes each: key, query) and written to the queries' shared lists when the
+// workgroup has finished.  A global store inside the tile loop joins the vmcnt queue of the DMA ring, whose counted waits
+// then ask for one piece more than intended: measured ~470 cycles of stall (x 4 waves at the barrier) per candidate -
+// 1 % of the pass at 10M rows, 18 % on a 1.25M-row shard (the candidates per query do not shrink with the shard).
+constexpr int kMfma16StageCap = 192;                                 // entries per wave (~40 expected at k = 10)
+constexpr int kMfma16StageBytes = 4 * kMfma16StageCap * 16 + 16;     // + one counter per wave
 
 // MFMA statements with pinned register classes: accumulator and corpus fragment in VGPRs, query fragment in a VGPR
 // ("v" forms) or an AGPR ("a" forms) quadruple.  No pads inside: the A fragment comes straight from a ds_read (the
@@ -81,9 +87,12 @@ __device__ __forceinline__ u64 mfma16_block_test(const f32x4& a0, const f32x4& a
 
 // Append the passing scores of one query block (rare path: entered for a block only when some lane passed).  Written
 // for few instructions when ONE lane holds ONE passing score - the usual case: a slow wave holds up the other three
-// at the next barrier, so this path is paid four-fold.
+// at the next barrier, so this path is paid four-fold.  STAGED: into the wave's LDS list (stage / stage_cnt); else into
+// the lane-private global list (sample levels: every score is a candidate there).
+template <bool STAGED>
 __device__ __forceinline__ void mfma16_append_block(const f32x4& a0, const f32x4& a1, float thr, float m, int qid, int writer,
-                                                    int nwriters, u32& cnt, int64_t row_base, const MfmaArgs& a) {
+                                                    int nwriters, u32& cnt, int64_t row_base, const MfmaArgs& a,
+                                                    uint4* stage, u32* stage_cnt) {
     if (m >= thr) {
         u64* mine = a.priv + ((int64_t)qid * nwriters + writer) * kMfma16PrivCap;
 #pragma unroll
@@ -94,13 +103,21 @@ __device__ __forceinline__ void mfma16_append_block(const f32x4& a0, const f32x4
                 // padding rows of the last tile, and the metadata filter: tested only for scores that pass the threshold
                 if (row < a.n && (!a.row_mask || ((a.row_mask[row >> 5] >> (row & 31)) & 1u))) {
                     const u64 key = make_key(s, (u32)row);
-                    if (cnt < (u32)kMfma16PrivCap) {
-                        mine[cnt] = key;
-                    } else {
-                        const u32 pos = atomicAdd(&a.count[qid], 1u);
-                        if (pos < (u32)a.cap) a.cand[(int64_t)qid * a.cap + pos] = key;
+                    bool direct = !STAGED;
+                    if (STAGED) {
+                        const u32 at = atomicAdd(stage_cnt, 1u);                   // LDS atomic: lgkmcnt, not vmcnt
+                        if (at < (u32)kMfma16StageCap) stage[at] = make_uint4((u32)key, (u32)(key >> 32), (u32)qid, 0u);
+                        else direct = true;                                        // list full: the slow way, still exact
                     }
-                    ++cnt;
+                    if (direct) {
+                        if (!STAGED && cnt < (u32)kMfma16PrivCap) {
+                            mine[cnt] = key;
+                        } else {
+                            const u32 pos = atomicAdd(&a.count[qid], 1u);
+                            if (pos < (u32)a.cap) a.cand[(int64_t)qid * a.cap + pos] = key;
+                        }
+                        ++cnt;
+                    }
                 }
             }
         }
@@ -127,6 +144,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     constexpr int kPieceEvery = kUnitSteps / kPieces;    // one DMA piece every so many k-steps
     static_assert(kUnitSteps % kPieces == 0 && kPieceEvery >= 1, "DMA pieces must spread evenly over the k-steps");
     static_assert(NB >= 1 && NB * kSteps * 4 <= 384, "query fragments must fit the register file");
+    constexpr bool kStaged = !SPARSE;                    // full pass: candidates through LDS (see kMfma16StageCap)
     constexpr int kFrags = NB * kSteps;                  // query fragments of this wave
     constexpr int kQV = kFrags < 36 ? kFrags : 36;       // ... the first kQV of them in VGPRs (144 registers), the rest in AGPRs
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -141,11 +159,16 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     for (int b = 0; b < NB; ++b) qid[b] = (b * 4 + wave) * 16 + r16;
 
     mfma_level_begin(a);
+    uint4* stage = (uint4*)(smem + dims::kLds) + wave * kMfma16StageCap;          // this wave's staged candidates
+    u32* stage_cnt = (u32*)(smem + dims::kLds + 4 * kMfma16StageCap * 16) + wave;
+    if (kStaged && lane == 0) *stage_cnt = 0;
     const int64_t t0 = (a.ntiles * (int64_t)blockIdx.x) / G;
     const int nt = (int)((a.ntiles * (int64_t)(blockIdx.x + 1)) / G - t0);
     if (nt <= 0) {
+        if (!kStaged) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) a.pcount[(int64_t)qid[b] * nwriters + writer] = 0;
+            for (int b = 0; b < NB; ++b) a.pcount[(int64_t)qid[b] * nwriters + writer] = 0;
+        }
         return;
     }
     const int nu = kUnits * nt;
@@ -333,19 +356,32 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         }
         if (__builtin_expect(any_hit != 0, 0)) {
             const int64_t lt = t0 + t;
-            const int64_t tile_row = ((lt / a.run) * a.run * a.tile_stride + lt % a.run) * kTileRows;
+            // (64-bit divisions are hundreds of instructions: runs of one tile - the default - take the short way)
+            const int64_t tile_row = (a.run == 1 ? lt * a.tile_stride : (lt / a.run) * a.run * a.tile_stride + lt % a.run) * kTileRows;
             const int64_t row_base = tile_row + 4 * kq;
 #pragma unroll
             for (int b = 0; b < NB; ++b)
-                if (hit[b] != 0) mfma16_append_block(acc[0][b], acc[1][b], thr[b], best[b], qid[b], writer, nwriters, cnt[b], row_base, a);
+                if (hit[b] != 0)
+                    mfma16_append_block<kStaged>(acc[0][b], acc[1][b], thr[b], best[b], qid[b], writer, nwriters, cnt[b], row_base, a,
+                                                 stage, stage_cnt);
         }
     }
 #undef TS16_UNIT
 #undef TS16_STEP
 #undef TS16_MMA
 #undef TS16_ISSUED
+    if (kStaged) {
+        // the tile loop is over (no DMA in flight that a counted wait still watches): staged candidates -> shared lists
+        const u32 n = min(*stage_cnt, (u32)kMfma16StageCap);
+        for (u32 e = lane; e < n; e += 64) {
+            const uint4 v = stage[e];
+            const u32 pos = atomicAdd(&a.count[v.z], 1u);
+            if (pos < (u32)a.cap) a.cand[(int64_t)v.z * a.cap + pos] = ((u64)v.y << 32) | v.x;
+        }
+    } else {
 #pragma unroll
-    for (int b = 0; b < NB; ++b) a.pcount[(int64_t)qid[b] * nwriters + writer] = cnt[b];
+        for (int b = 0; b < NB; ++b) a.pcount[(int64_t)qid[b] * nwriters + writer] = cnt[b];
+    }
     if (VARIANT == 5 && a.dbg && lane == 0) {
         unsigned long long* d = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 4;
         d[0] = cycle_stamp() - t_all0;

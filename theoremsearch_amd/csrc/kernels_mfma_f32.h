@@ -207,7 +207,8 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma_f32_topk_kernel(MfmaArgs
         // lane holds rows (g & 3) + 8 (g >> 2) + 4 h of this tile for query qid
         if (__builtin_expect(__any(max16(acc) >= thr), 0)) {
             const int64_t lt = t0 + t;
-            const int64_t tile_row = ((lt / a.run) * a.run * a.tile_stride + lt % a.run) * kTileRows;
+            // (64-bit divisions are hundreds of instructions: runs of one tile - the default - take the short way)
+            const int64_t tile_row = (a.run == 1 ? lt * a.tile_stride : (lt / a.run) * a.run * a.tile_stride + lt % a.run) * kTileRows;
             const int64_t row_base = tile_row + 4 * h;
             if (tile_row + kTileRows <= a.n) mfma_append<true>(acc, thr, qid, writer, nwriters, cnt, row_base, a);
             else mfma_append<false>(acc, thr, qid, writer, nwriters, cnt, row_base, a);

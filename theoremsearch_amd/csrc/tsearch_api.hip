@@ -887,7 +887,8 @@ static int launch_mfma(bool full_pass, int variant, int grid, hipStream_t st, co
 
 template <int D, int NB>
 static int launch_mfma16(bool full_pass, int variant, int grid, hipStream_t st, const MfmaArgs& a) {
-    constexpr int lds = MfmaDims<D>::kLds;
+    constexpr int lds = MfmaDims<D>::kLds + kMfma16StageBytes;
+    static_assert(lds <= 160 * 1024, "DMA ring + staged candidates must fit the CU's LDS");
     constexpr bool kDiag = (D == 768 && NB == 4);     // the timing-only variants exist for the headline shape only
     static std::atomic<unsigned long long> attr_done{0};
     int dev = 0;
@@ -997,10 +998,13 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
     // guaranteed lower bounds (more sample rows to scan, no re-runs ever).
     const bool statistical = ix->knobs.get(K_MFMA_STAT, 1) != 0;
     const std::vector<Level> lv = plan_levels(ix->knobs, ix->n, kk, statistical);
-    // expected candidates per query of the full pass under the estimate: 16x the k that must come back (an
-    // under-filled query costs an exact scan pass), few enough that the append path (~0.27 us per candidate and
-    // query, whatever N) stays cheap: 10M rows measured 3.91 / 3.94 / 4.02 ms per search at 128 / 256 / 512
-    const int stat_cands = std::min(2048, std::max(ix->knobs.get(K_MFMA_STAT_CANDS, 128), 16 * kk));
+    // Expected candidates per query of the full pass under the estimate.  Every candidate costs the pass ~0.3 us of one
+    // CU's time (the appending wave holds the other three at the next barrier), whatever N: 160 per query were 10 % of
+    // a 1.25M-row shard's pass and 1 % of the 10M pass; an under-filled query (fewer than k back) costs an exact scan
+    // pass.  6 k (at least 64) keeps the under-fill probability negligible for Gaussian-like scores (Poisson mean 64
+    // against k = 10, estimate error e^+-0.15) - measured on 10M / 1.25M x 768: 160 / 96 / 64 / 40 expected candidates
+    // -> 0 re-runs, 24 -> 5-7 re-runs per 256 queries; full pass 0.459 / 0.447 / 0.438 / 0.424 ms on the shard.
+    const int stat_cands = std::min(2048, std::max(2 * kk, ix->knobs.get(K_MFMA_STAT_CANDS, std::max(64, 6 * kk))));
     // rows the candidates are drawn from: all of them, or the rows a filter allows (the sample sees only those too)
     const int64_t pop = ix->active_mask ? ix->active_allowed : ix->n;
     const float z_tail = (statistical && lv.size() == 2)
@@ -1104,7 +1108,7 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         memset(&l, 0, sizeof(l));
         l.priv = ix->priv;
         l.pcount = ix->pcount;
-        l.nwriters = nwriters;
+        l.nwriters = (shape16 && full_pass) ? 0 : nwriters;   // the 16x16 full pass stages its candidates in LDS: shared lists only
         l.priv_cap = priv_cap;
         l.cand = ix->cand;
         l.count = ix->count;

@@ -72,6 +72,10 @@ def main():
             p = ix.profile_read()
             ix.profile_enable(False)
             got = out_i.cpu().numpy()
+            if rnd == 0:
+                _, _, st_ = ix.search(q, 10, return_stats=True)
+                print(f"   {name}: levels {st_['levels']}, candidates per query {st_['candidates'] / max(1, args.nq):.1f}, "
+                      f"queries re-run exactly {st_['fallback_queries']}", flush=True)
             if ref is None:
                 ref = got
             same = bool(np.array_equal(ref, got))
