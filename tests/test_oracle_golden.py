@@ -180,3 +180,55 @@ def test_bench_generator_agrees_with_the_oracle_restatement():
     x = np.random.default_rng(0).standard_normal(1000).astype(np.float32)
     assert np.array_equal(synthetic.bf16_bits(x), oracle.f32_to_bf16_bits(x))
     assert np.array_equal(synthetic.bf16_bits_to_f32(synthetic.bf16_bits(x)), oracle.round_to_bf16(x))
+
+
+def test_chunked_truth_applies_the_same_protocol_as_the_matrix_form():
+    """oracle.ChunkedTruth (full-size checks, bench.py's parity leg) against check_topk_against_truth on a corpus small
+    enough for both: same statistics on a right answer (ties and a masked chunk included), same verdict on wrong ones."""
+    rng = np.random.default_rng(3)
+    q = rng.standard_normal((9, 48)).astype(np.float32)
+    c = rng.standard_normal((6000, 48)).astype(np.float32)
+    c[4100] = c[77]                                             # an exact tie that straddles two chunks
+    truth = oracle.scores_fp64(q, c)
+    scores, idx = oracle.search(q, c, 10)
+    want = oracle.check_topk_against_truth(truth, idx, scores, 10)
+
+    def run(idx_, scores_, allowed=None):
+        ct = oracle.ChunkedTruth(q, idx_, 10)
+        for r0 in range(0, 6000, 1700):
+            ct.add(c[r0:r0 + 1700], r0, None if allowed is None else allowed[r0:r0 + 1700])
+        return ct.check(scores_)
+
+    assert run(idx, scores) == want and want["recall"] == 1.0
+    # a swapped pair at a pinned rank, a duplicated index, a row outside the top-k, a score off by 1e-4: all rejected
+    bad = idx.copy(); bad[2, [3, 4]] = bad[2, [4, 3]]
+    dup = idx.copy(); dup[1, 9] = dup[1, 0]
+    out = idx.copy(); out[5, 9] = int(np.argsort(truth[5])[0])
+    off = scores.copy(); off[7, 2] += 1e-4
+    for i_, s_ in ((bad, scores), (dup, scores), (out, scores), (idx, off)):
+        with pytest.raises(AssertionError):
+            run(i_, s_)
+    # restricted to allowed rows: equals the matrix form over exactly those rows
+    allowed = rng.random(6000) < 0.4
+    keep = np.flatnonzero(allowed)
+    ms, mi_local = oracle.search(q, c[keep], 10)
+    mi = keep[mi_local]
+    assert run(mi, ms, allowed) == oracle.check_topk_against_truth(truth[:, keep], mi_local, ms, 10)
+    # sharded accumulation: two accumulators merged = one
+    a, b = oracle.ChunkedTruth(q, idx, 10), oracle.ChunkedTruth(q, idx, 10)
+    a.add(c[:3000], 0)
+    b.add(c[3000:], 3000)
+    a.merge(b.best_s, b.best_i, b.got_s, b.n)
+    assert a.check(scores) == want
+
+
+def test_packed_result_blocks_round_trip():
+    from theoremsearch_amd.distributed import pack_results, packed_bytes, packed_idx_off, unpack_results
+    rng = np.random.default_rng(1)
+    for nq, k in ((1, 1), (3, 5), (256, 10), (7, 200)):
+        parts = [(rng.standard_normal((nq, k)).astype(np.float32), rng.integers(-1, 10**10, (nq, k))) for _ in range(3)]
+        blob = np.concatenate([pack_results(s, i) for s, i in parts])
+        assert blob.size == 3 * packed_bytes(nq, k) and packed_idx_off(nq, k) % 8 == 0
+        s, i = unpack_results(blob, 3, nq, k)
+        for p in range(3):
+            assert np.array_equal(s[p], parts[p][0]) and np.array_equal(i[p], parts[p][1])
