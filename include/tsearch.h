@@ -121,6 +121,12 @@ int ts_index_reserve(ts_index *ix, int64_t capacity_rows);
 int ts_index_append(ts_index *ix, const void *host_rows, int src_dtype, int64_t nrows, int64_t *first_row);
 int ts_index_append_device(ts_index *ix, const void *dev_rows, int src_dtype, int64_t src_ld, int64_t nrows,
                            void *stream, int64_t *first_row);
+/* Zero-copy: the index adopts rows that already sit in device memory - e.g. the tensor an encoder
+ * wrote.  They must be what the kernels multiply: the index's storage dtype, row stride = ld (d padded to 64 elements),
+ * normalised already when the metric is cosine; the allocation must hold capacity_rows >= n rounded up to 256 rows (whole
+ * 32-row tiles are read; rows past n are never returned).  The caller keeps ownership: the memory must stay alive and
+ * unchanged while searches run; the index's own allocation is released; an attached index cannot grow. */
+int ts_index_attach_device(ts_index *ix, void *dev_rows, int64_t capacity_rows);
 /* Stored rows back to the host in the storage dtype, dense [nrows x d] (what the kernels multiply). */
 int ts_index_download(ts_index *ix, void *host_rows, int64_t row0, int64_t nrows);
 

@@ -81,6 +81,32 @@ def test_append_device_rows_with_row_offset(ts):
         check(q, c, "cos", "bf16", 5, scores, idx - 1_000_000)
 
 
+def test_attach_device_rows_zero_copy(ts):
+    """ts_index_attach_device: the index searches a tensor in place (bf16 rows a torch kernel wrote) - same answer as an
+    index that was uploaded; too small an allocation and host pointers are refused."""
+    import torch
+    from theoremsearch_amd import _ffi
+    n, d = 100_000, 768
+    q, c = oracle.golden_inputs(n, 40, d, 31, "ip")
+    cap = (n + 255) // 256 * 256
+    dev = torch.zeros((cap, d), dtype=torch.bfloat16, device="cuda")
+    dev[:n] = torch.from_numpy(c).cuda().to(torch.bfloat16)            # RNE, like the library's own rounding
+    torch.cuda.synchronize()
+    with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as ref, ts.TheoremIndex(n, d, dtype="bf16", metric="ip") as ix:
+        want_s, want_i = ref.search(q, 10)
+        with pytest.raises(_ffi.TSearchError):
+            ix.attach_device(dev.data_ptr(), n)                         # not rounded up to 256 rows
+        with pytest.raises(_ffi.TSearchError):
+            ix.attach_device(c.ctypes.data, cap)                        # host memory
+        ix.attach_device(dev.data_ptr(), cap, keep_alive=dev)
+        assert np.array_equal(ix.download(), ref.download())
+        for algo in ("mfma", "scan"):
+            s, i = ix.search(q, 10, algo=algo)
+            assert np.array_equal(i, want_i) and np.allclose(s, want_s, atol=1e-6)
+        with pytest.raises(_ffi.TSearchError):
+            ix.append(c[:500])                                          # past the attached allocation: it cannot grow
+
+
 # ---- ordering across streams ---------------------------------------------------------------------------------------
 def test_calls_on_different_streams_share_the_scratch_safely(ts):
     """Two searches enqueued back to back on two different streams of one handle, device outputs: the second must not

@@ -58,6 +58,7 @@ _SIGNATURES = {
     "ts_index_append": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_int64)]),
     "ts_index_append_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
                                          C.POINTER(C.c_int64)]),
+    "ts_index_attach_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "ts_index_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
     "ts_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                             C.c_int, C.c_void_p]),

@@ -105,6 +105,7 @@ struct ts_index {
     u32* mask_dev = nullptr;    size_t mask_bytes = 0;       // filtered search: device copy of a host bitmask
     int64_t* id_map = nullptr;                               // subset index: local row -> global id
     bool borrowed = false;                                   // a view: rows / id_map belong to another handle
+    bool attached = false;                                   // rows adopted from the caller (ts_index_attach_device): never freed here
     ts_index* parent = nullptr;                              // a view: the handle that owns the rows
     std::atomic<int> nviews{0};                              // live views of this handle (it cannot grow meanwhile)
     void* rank_buf = nullptr;   size_t rank_bytes = 0;       // ts_rank_of: targets | counts | target scores, one query block
@@ -305,6 +306,7 @@ extern "C" int ts_index_destroy(ts_index* ix) {
         ix->id_map = nullptr;
         if (ix->parent) ix->parent->nviews.fetch_sub(1);
     }
+    if (ix->attached) ix->rows = nullptr;
     void* ptrs[] = {ix->rows,  ix->stage,   ix->qstore,   ix->qf32,     ix->cand,       ix->count,  ix->thr, ix->priv, ix->pcount, ix->mask_dev, ix->rank_buf, ix->id_map,
                     ix->fb_list, ix->fb_count, ix->stat, ix->partial, ix->partial2, ix->res_scores, ix->res_idx, ix->dbg};
     for (void* p : ptrs)
@@ -507,6 +509,7 @@ static int grow_locked(ts_index* ix, int64_t want_rows) {
     const int64_t new_pad = std::max<int64_t>(kRowPad, (want_rows + kRowPad - 1) / kRowPad * kRowPad);
     if (new_pad <= ix->n_pad) return TS_OK;
     if (ix->borrowed || ix->id_map) return fail(TS_ERR_UNSUPPORTED, "a view / subset index cannot grow");
+    if (ix->attached) return fail(TS_ERR_UNSUPPORTED, "an index over attached rows cannot grow: the rows belong to the caller");
     if (ix->nviews.load() > 0) return fail(TS_ERR_UNSUPPORTED, "the index has %d live views: destroy them before growing it", ix->nviews.load());
     HIP_TRY(hipSetDevice(ix->device));
     const size_t row_bytes = (size_t)ix->ld * ix->elem();
@@ -529,6 +532,38 @@ static int grow_locked(ts_index* ix, int64_t want_rows) {
     hipFree(ix->rows);
     ix->rows = fresh;
     ix->n_pad = new_pad;
+    return TS_OK;
+}
+
+// Zero-copy: the index adopts rows that already sit in device memory (SURVEY.md section 8b "ts_index_attach_device": the
+// encoder's output tensor as the corpus).  The rows must be what the kernels multiply: the index's storage dtype, row
+// stride = the index's ld (d padded to 64 elements, zeros in the padding), already normalised when the metric is cosine,
+// and the allocation must hold capacity_rows >= n rounded up to 256 rows (the matrix kernels read whole 32-row tiles;
+// rows past n are never returned).  The caller keeps ownership and must keep the memory alive and unchanged while
+// searches run; uploads into an attached index write into the caller's memory.
+extern "C" int ts_index_attach_device(ts_index* ix, void* dev_rows, int64_t capacity_rows) {
+    if (!ix || !dev_rows) return fail(TS_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    if (ix->id_map || ix->parent) return fail(TS_ERR_UNSUPPORTED, "a view / subset index cannot adopt rows");
+    if (ix->nviews.load() > 0) return fail(TS_ERR_UNSUPPORTED, "the index has live views");
+    const int64_t need = std::max<int64_t>(kRowPad, (ix->n + kRowPad - 1) / kRowPad * kRowPad);
+    if (capacity_rows < need)
+        return fail(TS_ERR_INVALID, "the attached allocation holds %lld rows, %lld are needed (n = %lld rounded up to %d)",
+                    (long long)capacity_rows, (long long)need, (long long)ix->n, kRowPad);
+    if (((uintptr_t)dev_rows & 15) != 0) return fail(TS_ERR_INVALID, "attached rows must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(ix->device));
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, dev_rows) != hipSuccess || attr.type != hipMemoryTypeDevice || attr.device != ix->device) {
+        (void)hipGetLastError();
+        return fail(TS_ERR_INVALID, "attached rows are not device memory of device %d", ix->device);
+    }
+    hipStream_t own;
+    TS_TRY(enter_stream(ix, nullptr, &own));
+    HIP_TRY(hipStreamSynchronize(own));
+    if (!ix->attached && ix->rows) HIP_TRY(hipFree(ix->rows));
+    ix->rows = dev_rows;
+    ix->n_pad = capacity_rows / kRowPad * kRowPad;
+    ix->attached = true;       // destroy / grow must not free it
     return TS_OK;
 }
 

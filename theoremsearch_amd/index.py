@@ -130,6 +130,12 @@ class TheoremIndex:
         self.n += int(nrows)
         return first.value
 
+    def attach_device(self, dev_ptr: int, capacity_rows: int, keep_alive=None) -> None:
+        """Adopt rows already in device memory (zero-copy; e.g. ``tensor.data_ptr()`` of an encoder output in the index's
+        dtype with ``capacity_rows >= n`` rounded up to 256).  ``keep_alive``: an object to hold on to (the tensor)."""
+        _ffi.check(self._lib.ts_index_attach_device(self._h, C.c_void_p(dev_ptr), int(capacity_rows)))
+        self._attached = keep_alive
+
     def set_row_offset(self, offset: int) -> None:
         _ffi.check(self._lib.ts_index_set_row_offset(self._h, int(offset)))
         self.row_offset = int(offset)
