@@ -146,7 +146,13 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     static_assert(NB >= 1 && NB * kSteps * 4 <= 384, "query fragments must fit the register file");
     constexpr bool kStaged = !SPARSE;                    // full pass: candidates through LDS (see kMfma16StageCap)
     constexpr int kFrags = NB * kSteps;                  // query fragments of this wave
-    constexpr int kQV = kFrags < 36 ? kFrags : 36;       // ... the first kQV of them in VGPRs (144 registers), the rest in AGPRs
+#ifndef TS16_AHEAD
+#define TS16_AHEAD 2
+#endif
+    // k-steps of A fragments in flight (TS16_AHEAD, where it divides the unit): 2 measured best (3: see DESIGN.md 3.2)
+    constexpr int kA = (kUnitSteps % TS16_AHEAD == 0) ? TS16_AHEAD : 2;
+    constexpr int kQVmax = 36 - 2 * (kA - 2);            // the ring's registers come out of the VGPR share of the queries
+    constexpr int kQV = kFrags < kQVmax ? kFrags : kQVmax;   // ... the first kQV of them in VGPRs, the rest in AGPRs
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -239,10 +245,10 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    // A-fragment ring: k-steps s and s + 1 in flight, two row blocks each: af[2 (s & 1) + rb]
-    bf16x8 af[4];
+    // A-fragment ring: k-steps s .. s + kA - 1 in flight, two row blocks each: af[2 (s % kA) + rb]
+    bf16x8 af[2 * kA];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < kA; ++s)
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) af[2 * s + rb] = *(const bf16x8*)(smem + (s >> 1) * 4096 + rb * 2048 + xo[s & 1]);
 
@@ -273,17 +279,38 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         }                                                                                                  \
     } while (0)
 
+    /* issue order of the 2 NB MFMAs of a k-step: query-block major (consecutive MFMAs share the query fragment; the */ \
+    /* epilogue's block order relies on it) - TS16_ORDER_A builds the row-block-major order for A/B runs */
+#ifndef TS16_ORDER_A
+#define TS16_MMA_ORDER(KS_, R0_)                                                                           \
+    do {                                                                                                   \
+        TS16_MMA(0, 0, KS_, af[R0_]);                                                                      \
+        TS16_MMA(1, 0, KS_, af[R0_ + 1]);                                                                  \
+        if constexpr (NB > 1) { TS16_MMA(0, 1, KS_, af[R0_]); TS16_MMA(1, 1, KS_, af[R0_ + 1]); }          \
+        if constexpr (NB > 2) { TS16_MMA(0, 2, KS_, af[R0_]); TS16_MMA(1, 2, KS_, af[R0_ + 1]); }          \
+        if constexpr (NB > 3) { TS16_MMA(0, 3, KS_, af[R0_]); TS16_MMA(1, 3, KS_, af[R0_ + 1]); }          \
+    } while (0)
+#else
+#define TS16_MMA_ORDER(KS_, R0_)                                                                           \
+    do {                                                                                                   \
+        TS16_MMA(0, 0, KS_, af[R0_]);                                                                      \
+        if constexpr (NB > 1) TS16_MMA(0, 1, KS_, af[R0_]);                                                \
+        if constexpr (NB > 2) TS16_MMA(0, 2, KS_, af[R0_]);                                                \
+        if constexpr (NB > 3) TS16_MMA(0, 3, KS_, af[R0_]);                                                \
+        TS16_MMA(1, 0, KS_, af[R0_ + 1]);                                                                  \
+        if constexpr (NB > 1) TS16_MMA(1, 1, KS_, af[R0_ + 1]);                                            \
+        if constexpr (NB > 2) TS16_MMA(1, 2, KS_, af[R0_ + 1]);                                            \
+        if constexpr (NB > 3) TS16_MMA(1, 3, KS_, af[R0_ + 1]);                                            \
+    } while (0)
+#endif
+
 #define TS16_STEP(UI, S_)                                                                                  \
     do {                                                                                                   \
         constexpr int ks_ = (UI) * kUnitSteps + (S_);                                                      \
-        constexpr int r0_ = 2 * ((S_) & 1);                                                                \
+        constexpr int r0_ = 2 * ((S_) % kA);                                                               \
         if constexpr (!kNoMma) {                                                                           \
-            TS16_MMA(0, 0, ks_, af[r0_]);                                                                  \
-            TS16_MMA(1, 0, ks_, af[r0_ + 1]);                                                              \
-            if constexpr (NB > 1) { TS16_MMA(0, 1, ks_, af[r0_]); TS16_MMA(1, 1, ks_, af[r0_ + 1]); }      \
-            if constexpr (NB > 2) { TS16_MMA(0, 2, ks_, af[r0_]); TS16_MMA(1, 2, ks_, af[r0_ + 1]); }      \
-            if constexpr (NB > 3) { TS16_MMA(0, 3, ks_, af[r0_]); TS16_MMA(1, 3, ks_, af[r0_ + 1]); }      \
-            constexpr int n_ = (S_) + 2;                                                                   \
+            TS16_MMA_ORDER(ks_, r0_);                                                                      \
+            constexpr int n_ = (S_) + kA;                                                                  \
             if constexpr (n_ < kUnitSteps) {                                                               \
                 af[r0_] = *(const bf16x8*)(unit + (n_ >> 1) * 4096 + xo[n_ & 1]);                          \
                 af[r0_ + 1] = *(const bf16x8*)(unit + (n_ >> 1) * 4096 + 2048 + xo[n_ & 1]);               \
@@ -369,6 +396,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
 #undef TS16_UNIT
 #undef TS16_STEP
 #undef TS16_MMA
+#undef TS16_MMA_ORDER
 #undef TS16_ISSUED
     if (kStaged) {
         // the tile loop is over (no DMA in flight that a counted wait still watches): staged candidates -> shared lists
