@@ -25,7 +25,7 @@ def ts():
 def algos_for(dtype, d):
     if dtype == "bf16" and d in (384, 512, 768, 1024):
         return ["scan", "mfma"]
-    return ["scan", "mfma"] if (dtype == "f32" and d == 768) else ["scan"]     # fp32 MFMA (exact fp32) at d = 768
+    return ["scan", "mfma"] if (dtype == "f32" and d in (768, 1024)) else ["scan"]     # fp32 MFMA (exact fp32) at d = 768 / 1024
 
 
 def check(q, c, metric, dtype, k, scores, idx):
@@ -569,6 +569,21 @@ def test_fp32_batches_run_on_the_fp32_mfma_path(ts, n, nq, k, metric):
         local = np.where(mi >= 0, np.searchsorted(keep, np.maximum(mi, 0)), -1)
         stats = oracle.check_topk_against_truth(oracle.scores_fp64(qp, cp), local, ms, k)
         assert stats["recall"] == 1.0 and mask[mi[mi >= 0]].all()
+
+
+@pytest.mark.parametrize("n,nq,k,metric", [(150_000, 70, 10, "cos"), (40_000, 129, 50, "ip")])
+def test_fp32_batches_at_d1024_run_on_the_fp32_mfma_path(ts, n, nq, k, metric):
+    """The Qwen-sized tables (vector(1024), rds_schema.sql:50-56) in fp32: 64 queries per launch on v_mfma_f32_16x16x4_f32."""
+    q, c = oracle.golden_inputs(n, nq, 1024, 2000 + nq, metric)
+    c[n - 7] = c[11]
+    with ts.TheoremIndex.from_embeddings(c, dtype="f32", metric=metric) as ix:
+        scores, idx, st = ix.search(q, k, return_stats=True)
+        assert st["algo"] == 2 and st["fallback_queries"] == 0, st
+        check(q, c, metric, "f32", k, scores, idx)
+        s2, i2 = ix.search(q, k, algo="mfma")
+        assert np.array_equal(i2, idx) and np.array_equal(s2, scores)
+        s3, i3 = ix.search(q[:5], k, algo="scan")
+        assert np.array_equal(i3, idx[:5]) and np.allclose(s3, scores[:5], atol=1e-6)
 
 
 def test_small_fp32_batches_stay_on_the_scan(ts):

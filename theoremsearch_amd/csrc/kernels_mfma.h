@@ -56,6 +56,8 @@ template <> struct MfmaGeom<1024> { static constexpr int kUnitK = 256, kSlots = 
 // the narrower common widths: same unit image (blocks of 64 columns), two units per tile, two query groups per wave
 template <> struct MfmaGeom<512> { static constexpr int kUnitK = 256, kSlots = 8; };
 template <> struct MfmaGeom<384> { static constexpr int kUnitK = 192, kSlots = 8; };
+// fp32 rows seen as twice as many 2-byte elements (kernels_mfma16.h, F32): 1024 floats = 4096-byte rows, eight 16 KiB units
+template <> struct MfmaGeom<2048> { static constexpr int kUnitK = 256, kSlots = 8; };
 template <int D> struct MfmaDims {
     static constexpr int kKSteps = D / 16;
     static constexpr int kUnitK = MfmaGeom<D>::kUnitK;

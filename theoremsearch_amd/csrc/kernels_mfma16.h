@@ -54,6 +54,16 @@ __device__ __forceinline__ void mfma16_a_first(f32x4& acc, const bf16x8& a, cons
 __device__ __forceinline__ void mfma16_a(f32x4& acc, const bf16x8& a, const bf16x8& b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
 }
+// fp32 rows (F32): v_mfma_f32_16x16x4_f32, one float of the corpus chunk x one float of the query chunk per instruction
+__device__ __forceinline__ void mfma16f_v_first(f32x4& acc, float a, float b) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma16f_v(f32x4& acc, float a, float b) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma16f_a(f32x4& acc, float a, float b) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+}
 // wait states between the last MFMA writing an accumulator and its first VALU reader (hipcc pads nothing for asm)
 template <int NB>
 __device__ __forceinline__ void mfma16_settle(f32x4 (&acc)[2][NB]) {
@@ -131,19 +141,30 @@ __device__ __forceinline__ void mfma16_append_block(const f32x4& a0, const f32x4
 // SHARES, not the length).  3 = product + clock probe: s_memtime / s_memrealtime around the tile loop into a.dbg
 // (4 words per workgroup: shader cycles, 100 MHz ticks, units, 0) - MI355X_MICROARCH.md "DVFS give-back" item 6.
 // SPARSE only changes the symbol (sample levels show up under their own name in kernel traces).
-template <int D, int NB, int VARIANT, bool SPARSE>
+//
+// F32: the same kernel over an fp32 index (exact fp32: v_mfma_f32_16x16x4_f32, bit for bit an fmaf chain).  A row of D
+// floats is treated as 2 D two-byte elements by the DMA ring and the LDS image; a "k-step" is still one 16-byte chunk per
+// lane and row block, now four floats that feed FOUR MFMAs per (row block, query block): MFMA i multiplies float i of the
+// corpus chunk by float i of the matching query chunk, i.e. k = 16 s + 4 (lane >> 4) + i - a fixed permutation of k in the
+// fp32 sum.  The four MFMAs of a chunk go to the accumulators in turn (i-major), so that no accumulator is used twice in a
+// row (16x16x4: 32-cycle issue, 40-cycle dependent latency).  d = 1024: one block of 16 queries per wave (256 registers),
+// 64 queries per launch - the Qwen-sized fp32 tables; d = 768 fp32 has its own kernel (kernels_mfma_f32.h, 128 per launch).
+template <int D, int NB, int VARIANT, bool SPARSE, bool F32 = false>
 __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a) {
-    using dims = MfmaDims<D>;
+    constexpr int Deq = F32 ? 2 * D : D;                 // row length in 2-byte elements
+    using dims = MfmaDims<Deq>;
     constexpr bool kNoEpi = VARIANT == 1 || VARIANT == 7;
     constexpr bool kNoDma = VARIANT == 7;
     constexpr bool kNoMma = VARIANT == 2;
-    constexpr int kSteps = D / 32;                       // k-steps per tile
+    constexpr int kSteps = Deq / 32;                     // k-steps (16-byte chunks per lane) per tile
     constexpr int kUnitSteps = dims::kUnitK / 32;        // k-steps per unit
     constexpr int kUnits = dims::kUnits, kUnitBytes = dims::kUnitBytes, kSlots = dims::kSlots, kPieces = dims::kPieces;
     constexpr int kUnitK = dims::kUnitK;
     constexpr int kPieceEvery = kUnitSteps / kPieces;    // one DMA piece every so many k-steps
     static_assert(kUnitSteps % kPieces == 0 && kPieceEvery >= 1, "DMA pieces must spread evenly over the k-steps");
     static_assert(NB >= 1 && NB * kSteps * 4 <= 384, "query fragments must fit the register file");
+    static_assert(!F32 || NB <= 2, "the fp32 issue order is written for one or two query blocks per wave");
+    static_assert(kUnits == 2 || kUnits == 4 || kUnits == 8, "units per tile");
     constexpr bool kStaged = !SPARSE;                    // full pass: candidates through LDS (see kMfma16StageCap)
     constexpr int kFrags = NB * kSteps;                  // query fragments of this wave
 #ifndef TS16_AHEAD
@@ -183,7 +204,8 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     bf16x8 qv[kQV], qa[kFrags > kQV ? kFrags - kQV : 1];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        const bf16x8* pq = (const bf16x8*)(a.q + (int64_t)qid[b] * D + 8 * kq);
+        const bf16x8* pq = F32 ? (const bf16x8*)((const float*)a.q + (int64_t)qid[b] * D + 4 * kq)
+                               : (const bf16x8*)(a.q + (int64_t)qid[b] * D + 8 * kq);
 #pragma unroll
         for (int ks = 0; ks < kSteps; ++ks) {
             const int f = b * kSteps + ks;
@@ -206,10 +228,10 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     // DMA source of this lane (as kernels_mfma.h): row 8w + (lane >> 3) of the tile, swizzled chunk of K-block 0 of the unit
     const int drow = 8 * wave + (lane >> 3);
     const int dchunk = (lane & 7) ^ ((drow >> 1) & 7);
-    const int64_t tile_bytes = (int64_t)kTileRows * D * 2;
+    const int64_t tile_bytes = (int64_t)kTileRows * Deq * 2;
     const int64_t run_jump = tile_bytes * ((int64_t)a.run * a.tile_stride - a.run + 1);
     const int64_t g0 = (t0 / a.run) * a.run * a.tile_stride + t0 % a.run;
-    const unsigned char* tile_src = (const unsigned char*)a.corpus + (int64_t)drow * (D * 2) + dchunk * 16 + g0 * tile_bytes;
+    const unsigned char* tile_src = (const unsigned char*)a.corpus + (int64_t)drow * (Deq * 2) + dchunk * 16 + g0 * tile_bytes;
     int issue_run_pos = (int)(t0 % a.run);
     int issue_u = 0, issue_ui = 0, issue_slot = 0;
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem + wave * 1024;
@@ -266,7 +288,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         __builtin_amdgcn_s_waitcnt(0xC07F);
     }
 
-    // one MFMA of block B_, row block RB_, global k-step KS_ (all compile-time)
+    // one MFMA of block B_, row block RB_, global k-step KS_ (all compile-time); F32: MFMA I_ of the chunk's four
 #define TS16_MMA(RB_, B_, KS_, AF_)                                                                        \
     do {                                                                                                   \
         constexpr int f_ = (B_) * kSteps + (KS_);                                                          \
@@ -276,6 +298,19 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         } else {                                                                                           \
             if constexpr (f_ < kQV) mfma16_v(acc[RB_][B_], AF_, qv[f_ < kQV ? f_ : 0]);                    \
             else mfma16_a(acc[RB_][B_], AF_, qa[f_ >= kQV ? f_ - kQV : 0]);                                \
+        }                                                                                                  \
+    } while (0)
+#define TS16_MMAF(RB_, B_, KS_, AF_, I_)                                                                   \
+    do {                                                                                                   \
+        constexpr int f_ = (B_) * kSteps + (KS_);                                                          \
+        const f32x4& af4_ = reinterpret_cast<const f32x4&>(AF_);                                           \
+        if constexpr ((KS_) == 0 && (I_) == 0) {                                                           \
+            static_assert(kQV >= 1, "the first query fragment lives in a VGPR");                           \
+            mfma16f_v_first(acc[RB_][B_], af4_[I_], reinterpret_cast<const f32x4&>(qv[0])[I_]);            \
+        } else if constexpr (f_ < kQV) {                                                                   \
+            mfma16f_v(acc[RB_][B_], af4_[I_], reinterpret_cast<const f32x4&>(qv[f_ < kQV ? f_ : 0])[I_]);  \
+        } else {                                                                                           \
+            mfma16f_a(acc[RB_][B_], af4_[I_], reinterpret_cast<const f32x4&>(qa[f_ >= kQV ? f_ - kQV : 0])[I_]); \
         }                                                                                                  \
     } while (0)
 
@@ -308,8 +343,19 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     do {                                                                                                   \
         constexpr int ks_ = (UI) * kUnitSteps + (S_);                                                      \
         constexpr int r0_ = 2 * ((S_) % kA);                                                               \
+        if constexpr (!kNoMma && F32) {                                                                    \
+            /* i-major: the 2 NB accumulators in turn for each of the chunk's four floats */               \
+            TS16_MMAF(0, 0, ks_, af[r0_], 0); TS16_MMAF(1, 0, ks_, af[r0_ + 1], 0);                        \
+            if constexpr (NB > 1) { TS16_MMAF(0, 1, ks_, af[r0_], 0); TS16_MMAF(1, 1, ks_, af[r0_ + 1], 0); } \
+            TS16_MMAF(0, 0, ks_, af[r0_], 1); TS16_MMAF(1, 0, ks_, af[r0_ + 1], 1);                        \
+            if constexpr (NB > 1) { TS16_MMAF(0, 1, ks_, af[r0_], 1); TS16_MMAF(1, 1, ks_, af[r0_ + 1], 1); } \
+            TS16_MMAF(0, 0, ks_, af[r0_], 2); TS16_MMAF(1, 0, ks_, af[r0_ + 1], 2);                        \
+            if constexpr (NB > 1) { TS16_MMAF(0, 1, ks_, af[r0_], 2); TS16_MMAF(1, 1, ks_, af[r0_ + 1], 2); } \
+            TS16_MMAF(0, 0, ks_, af[r0_], 3); TS16_MMAF(1, 0, ks_, af[r0_ + 1], 3);                        \
+            if constexpr (NB > 1) { TS16_MMAF(0, 1, ks_, af[r0_], 3); TS16_MMAF(1, 1, ks_, af[r0_ + 1], 3); } \
+        }                                                                                                  \
+        if constexpr (!kNoMma && !F32) TS16_MMA_ORDER(ks_, r0_);                                           \
         if constexpr (!kNoMma) {                                                                           \
-            TS16_MMA_ORDER(ks_, r0_);                                                                      \
             constexpr int n_ = (S_) + kA;                                                                  \
             if constexpr (n_ < kUnitSteps) {                                                               \
                 af[r0_] = *(const bf16x8*)(unit + (n_ >> 1) * 4096 + xo[n_ & 1]);                          \
@@ -356,9 +402,15 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     for (int t = 0; t < nt; ++t) {
         TS16_UNIT(0);
         TS16_UNIT(1);
-        if constexpr (kUnits == 4) {
+        if constexpr (kUnits >= 4) {
             TS16_UNIT(2 % kUnits);
             TS16_UNIT(3 % kUnits);
+        }
+        if constexpr (kUnits == 8) {
+            TS16_UNIT(4 % kUnits);
+            TS16_UNIT(5 % kUnits);
+            TS16_UNIT(6 % kUnits);
+            TS16_UNIT(7 % kUnits);
         }
         if constexpr (kNoMma) continue;
         // The last k-step issued its MFMAs in block order, so with NB = 4 the results of block b are at least 6 MFMAs
@@ -396,6 +448,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
 #undef TS16_UNIT
 #undef TS16_STEP
 #undef TS16_MMA
+#undef TS16_MMAF
 #undef TS16_MMA_ORDER
 #undef TS16_ISSUED
     if (kStaged) {
