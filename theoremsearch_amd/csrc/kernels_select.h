@@ -101,78 +101,20 @@ constexpr int kLevelBins = 1024;
 // LDS: gathered keys | short list (sorted) | per-wave lists of the streaming path | histogram | counters
 constexpr int kLevelLds = kLevelSortMax * 8 + kLevelSmall * 8 + (kLevelThreads / 64) * TS_MAX_K_INTERNAL * 8 + kLevelBins * 4 + 64;
 
-// KR = key registers per lane of the per-wave running top-k of the streaming path (1: kk <= 64, 4: kk <= 256).
-//
-// Selection of the `kl` best of up to 8192 gathered keys, two ways:
-//   * short path (the usual one): at most kLevelSmall keys -> one bitonic sort of them; more keys -> a 1024-bin histogram
-//     of the scores over [mean - 4 sd, mean + 8 sd] (LDS atomics), a scan of the bins from the top down to the bin that
-//     holds the kl-th best key, and the sort of just the keys in the bins above it (plus that bin);
-//   * streaming path (many equal scores in the cut bin: duplicates, saturated scores): every wave runs its slice through
-//     a running top-kl (WaveTopK) and the eight lists are merged by one sort - what this kernel always did before.
-// Both give the same `best[0 .. kl)`: the kl largest keys in descending order.
+// The kl best of `cnt` keys in LDS, sorted descending (shared by level_select_kernel and select_hist_kernel); returns the
+// sorted list (at least kl entries, zero = empty).  LDS areas: small[kLevelSmall], wlists[8 x TS_MAX_K_INTERNAL],
+// hist[kLevelBins], ctr[16] (ctr[3] = nsmall must be 0 on entry, hist zeroed).  `want_stats`: mean / sd of the scores are
+// needed by the caller even when the short path does not need them.
 template <int KR>
-__global__ void __launch_bounds__(kLevelThreads) level_select_kernel(LevelArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64* keys = (u64*)smem;                                   // kLevelSortMax gathered candidates
-    u64* small = (u64*)(smem + kLevelSortMax * 8);            // short list, then sorted
-    u64* wlists = small + kLevelSmall;                        // streaming path: 8 waves x kl
-    u32* hist = (u32*)(wlists + (kLevelThreads / 64) * TS_MAX_K_INTERNAL);
-    u32* ctr = hist + kLevelBins;
-    u32& fill = ctr[0];
-    u32& produced = ctr[1];
-    u32& base_shared = ctr[2];
+__device__ __forceinline__ u64* lds_select_top(u64* keys, int cnt, int kl, u64* small, u64* wlists, u32* hist, u32* ctr,
+                                               bool want_stats_in, double& mean, double& sd) {
     u32& nsmall = ctr[3];
     int& cut_bin = *(int*)&ctr[4];
-    double* red = (double*)&ctr[8];                           // 2 doubles: mean, sd (16-byte aligned: ctr is)
-    const int q = blockIdx.x;
+    double* red = (double*)&ctr[8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    if (threadIdx.x == 0) {
-        fill = 0;
-        produced = 0;
-        nsmall = 0;
-    }
-    for (int i = threadIdx.x; i < kLevelBins; i += blockDim.x) hist[i] = 0;
-    __syncthreads();
-    // gather: private lists (a writer's entries are loaded together: one round trip, not one per entry) ...
-    for (int w = threadIdx.x; w < a.nwriters; w += blockDim.x) {
-        const u32 made = a.pcount[(int64_t)q * a.nwriters + w];
-        if (made == 0) continue;
-        const u32 n = min(made, (u32)a.priv_cap);
-        const u64* src = a.priv + ((int64_t)q * a.nwriters + w) * a.priv_cap;
-        const u32 at = atomicAdd(&fill, n);
-        atomicAdd(&produced, n);
-        u64 v[32];
-#pragma unroll
-        for (int e = 0; e < 32; ++e) v[e] = ((u32)e < n) ? src[e] : 0ull;
-#pragma unroll
-        for (int e = 0; e < 32; ++e)
-            if ((u32)e < n && at + e < (u32)kLevelSortMax) keys[at + e] = v[e];
-    }
-    // ... and the shared spill list
-    const u32 raw = a.count[q];
-    const u32 ns = min(raw, (u32)a.cap);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        base_shared = fill;
-        fill += ns;
-        produced += raw;
-    }
-    __syncthreads();
-    for (u32 i = threadIdx.x; i < ns; i += blockDim.x)
-        if (base_shared + i < (u32)kLevelSortMax) keys[base_shared + i] = a.cand[(int64_t)q * a.cap + i];
-    __syncthreads();
-    const u32 total = fill;
-    const bool lost = raw > (u32)a.cap || total > (u32)kLevelSortMax;
-    const int cnt = (int)min(total, (u32)kLevelSortMax);
-    const int kk = a.kk;
-    // the sample level of the estimated threshold also needs the sample's 32 best for the tail fit
-    constexpr int kTailM = 32;
-    const bool tail_fit = !a.final_level && a.tail_p > 0.0f;
-    const int kl = tail_fit ? max(kk, kTailM) : kk;  // entries wanted, sorted
-
-    // mean / sd of the gathered scores: the histogram's range, and the Gaussian-tail estimate of the sample level
-    const bool want_stats = cnt > kLevelSmall || (!a.final_level && a.z_tail > 0.0f && cnt >= 256);
-    double mean = 0.0, sd = 0.0;
+    const bool want_stats = cnt > kLevelSmall || want_stats_in;
+    mean = 0.0;
+    sd = 0.0;
     if (want_stats) {
         double s1 = 0.0, s2 = 0.0;
         for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
@@ -296,6 +238,80 @@ __global__ void __launch_bounds__(kLevelThreads) level_select_kernel(LevelArgs a
         best = wlists;
     }
     (void)streamed;
+    return best;
+
+}
+
+// KR = key registers per lane of the per-wave running top-k of the streaming path (1: kk <= 64, 4: kk <= 256).
+//
+// Selection of the `kl` best of up to 8192 gathered keys, two ways:
+//   * short path (the usual one): at most kLevelSmall keys -> one bitonic sort of them; more keys -> a 1024-bin histogram
+//     of the scores over [mean - 4 sd, mean + 8 sd] (LDS atomics), a scan of the bins from the top down to the bin that
+//     holds the kl-th best key, and the sort of just the keys in the bins above it (plus that bin);
+//   * streaming path (many equal scores in the cut bin: duplicates, saturated scores): every wave runs its slice through
+//     a running top-kl (WaveTopK) and the eight lists are merged by one sort - what this kernel always did before.
+// Both give the same `best[0 .. kl)`: the kl largest keys in descending order.
+template <int KR>
+__global__ void __launch_bounds__(kLevelThreads) level_select_kernel(LevelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* keys = (u64*)smem;                                   // kLevelSortMax gathered candidates
+    u64* small = (u64*)(smem + kLevelSortMax * 8);            // short list, then sorted
+    u64* wlists = small + kLevelSmall;                        // streaming path: 8 waves x kl
+    u32* hist = (u32*)(wlists + (kLevelThreads / 64) * TS_MAX_K_INTERNAL);
+    u32* ctr = hist + kLevelBins;
+    u32& fill = ctr[0];
+    u32& produced = ctr[1];
+    u32& base_shared = ctr[2];
+    u32& nsmall = ctr[3];                                     // (ctr[4], ctr[8..11]: lds_select_top's cut bin, mean, sd)
+    const int q = blockIdx.x;
+    if (threadIdx.x == 0) {
+        fill = 0;
+        produced = 0;
+        nsmall = 0;
+    }
+    for (int i = threadIdx.x; i < kLevelBins; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    // gather: private lists (a writer's entries are loaded together: one round trip, not one per entry) ...
+    for (int w = threadIdx.x; w < a.nwriters; w += blockDim.x) {
+        const u32 made = a.pcount[(int64_t)q * a.nwriters + w];
+        if (made == 0) continue;
+        const u32 n = min(made, (u32)a.priv_cap);
+        const u64* src = a.priv + ((int64_t)q * a.nwriters + w) * a.priv_cap;
+        const u32 at = atomicAdd(&fill, n);
+        atomicAdd(&produced, n);
+        u64 v[32];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) v[e] = ((u32)e < n) ? src[e] : 0ull;
+#pragma unroll
+        for (int e = 0; e < 32; ++e)
+            if ((u32)e < n && at + e < (u32)kLevelSortMax) keys[at + e] = v[e];
+    }
+    // ... and the shared spill list
+    const u32 raw = a.count[q];
+    const u32 ns = min(raw, (u32)a.cap);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        base_shared = fill;
+        fill += ns;
+        produced += raw;
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < ns; i += blockDim.x)
+        if (base_shared + i < (u32)kLevelSortMax) keys[base_shared + i] = a.cand[(int64_t)q * a.cap + i];
+    __syncthreads();
+    const u32 total = fill;
+    const bool lost = raw > (u32)a.cap || total > (u32)kLevelSortMax;
+    const int cnt = (int)min(total, (u32)kLevelSortMax);
+    const int kk = a.kk;
+    // the sample level of the estimated threshold also needs the sample's 32 best for the tail fit
+    constexpr int kTailM = 32;
+    const bool tail_fit = !a.final_level && a.tail_p > 0.0f;
+    const int kl = tail_fit ? max(kk, kTailM) : kk;  // entries wanted, sorted
+
+    // mean / sd of the gathered scores (the histogram's range, and the Gaussian-tail estimate of the sample level) and the
+    // kl best keys, sorted
+    double mean = 0.0, sd = 0.0;
+    u64* best = lds_select_top<KR>(keys, cnt, kl, small, wlists, hist, ctr, !a.final_level && a.z_tail > 0.0f && cnt >= 256, mean, sd);
 
     if (threadIdx.x == 0) a.count[q] = 0;
     if (!a.final_level) {
@@ -344,6 +360,53 @@ __global__ void __launch_bounds__(kLevelThreads) level_select_kernel(LevelArgs a
         const u64 key = best[i];
         a.out_scores[(int64_t)q * a.k_user + i] = key ? key_score(key) : -INFINITY;
         a.out_idx[(int64_t)q * a.k_user + i] = !key ? -1 : a.id_map ? a.id_map[key_row(key)] : (int64_t)key_row(key) + a.row_offset;
+    }
+}
+
+// One-launch reduction of the scan's partial lists (up to kHistSelectMax keys per query: 1024 workgroups x k <= 12) to the
+// final k: the keys are loaded into LDS (empty slots squeezed out by ballot), then lds_select_top's histogram cut + short
+// sort.  Replaces two select_kernel rounds (10 bitonic sorts of 1024 keys + a final one: 22 + 7 us and a kernel boundary)
+// by ~10 us: what the single-query searches of the apps wait for (streamlit_app.py:282-283, app_showcase_model.py:93-96).
+constexpr int kHistSelectMax = 12288;   // 96 KiB of keys: with the short list, the per-wave lists and the histogram 132 KiB of LDS
+constexpr int kHistSelectLds = kHistSelectMax * 8 + kLevelSmall * 8 + (kLevelThreads / 64) * TS_MAX_K_INTERNAL * 8 + kLevelBins * 4 + 64;
+static_assert(kHistSelectLds <= 160 * 1024 && kLevelLds <= 160 * 1024, "select kernels must fit the CU's LDS");
+
+__global__ void __launch_bounds__(kLevelThreads) select_hist_kernel(SelectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* keys = (u64*)smem;
+    u64* small = keys + kHistSelectMax;
+    u64* wlists = small + kLevelSmall;
+    u32* hist = (u32*)(wlists + (kLevelThreads / 64) * TS_MAX_K_INTERNAL);
+    u32* ctr = hist + kLevelBins;
+    const int slot = blockIdx.x;
+    if (a.qcount && slot >= *a.qcount) return;
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) {
+        ctr[0] = 0;
+        ctr[3] = 0;
+    }
+    for (int i = threadIdx.x; i < kLevelBins; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const u64* src = a.in + (int64_t)slot * a.in_stride;
+    const int m = min(a.m, kHistSelectMax);
+    for (int i0 = (threadIdx.x & ~63); i0 < m; i0 += blockDim.x) {
+        const int i = i0 + lane;
+        const u64 key = (i < m) ? src[i] : 0ull;
+        const u64 live = __ballot(key != 0ull);
+        u32 base = 0;
+        if (lane == 0 && live) base = atomicAdd(&ctr[0], (u32)__popcll(live));
+        base = (u32)__shfl((int)base, 0, 64);
+        if (key != 0ull) keys[base + __popcll(live & ((1ull << lane) - 1ull))] = key;
+    }
+    __syncthreads();
+    const int cnt = (int)ctr[0];
+    double mean, sd;
+    u64* best = lds_select_top<1>(keys, cnt, a.k_user, small, wlists, hist, ctr, false, mean, sd);
+    const int qid = a.qlist ? a.qlist[slot] : slot;
+    for (int i = threadIdx.x; i < a.k_user; i += blockDim.x) {
+        const u64 key = best[i];
+        a.out_scores[(int64_t)qid * a.k_user + i] = key ? key_score(key) : -INFINITY;
+        a.out_idx[(int64_t)qid * a.k_user + i] = !key ? -1 : a.id_map ? a.id_map[key_row(key)] : (int64_t)key_row(key) + a.row_offset;
     }
 }
 

@@ -112,6 +112,7 @@ struct ts_index {
     const u32* active_mask = nullptr;                        // bitmask of the search in progress (under `mu`)
     int64_t active_allowed = 0;                              // rows that bitmask allows (host masks: counted; else n)
     bool attr_done = false;
+    bool attr_done_hist = false;
     Knobs knobs;                                             // env at creation, then ts_index_set_option
     hipStream_t last_stream = nullptr;                       // stream of the previous call that used the scratch buffers
     hipEvent_t order_ev = nullptr;                           // orders a call on another stream behind it
@@ -749,6 +750,29 @@ static int run_select_rounds(ts_index* ix, int slots, int m, int k, float* out_s
     u64* scratch[2] = {ix->partial2, ix->partial};
     int which = 0;
     int64_t in_stride = m;
+    if (m > 1024 && m <= kHistSelectMax && k <= 64) {
+        // the usual case (k <= 12 over 1024 workgroups): one launch, histogram cut instead of two rounds of bitonic sorts
+        if (!ix->attr_done_hist) {
+            HIP_TRY(hipFuncSetAttribute((const void*)select_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kHistSelectLds));
+            ix->attr_done_hist = true;
+        }
+        SelectArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in = in;
+        a.in_stride = in_stride;
+        a.m = m;
+        a.kout = k;
+        a.k_user = k;
+        a.row_offset = ix->row_offset;
+        a.id_map = ix->id_map;
+        a.qlist = qlist;
+        a.qcount = qcount;
+        a.out_scores = out_scores;
+        a.out_idx = out_idx;
+        select_hist_kernel<<<slots, kLevelThreads, kHistSelectLds, st>>>(a);
+        HIP_TRY(hipGetLastError());
+        return TS_OK;
+    }
     for (;;) {
         SelectArgs a;
         memset(&a, 0, sizeof(a));
