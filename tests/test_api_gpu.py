@@ -195,6 +195,7 @@ def test_comm_of_one_rank_runs_the_rccl_exchange(ts):
     """ts_comm_*: the RCCL communicator inside libtsearch (ncclCommInitRank, ncclAllGather) with world = 1 - all a one-GPU
     box can run - must reproduce the plain search through search -> all-gather -> merge."""
     from theoremsearch_amd import _ffi
+    _ffi.prefer_torch_rccl()
     lib = _ffi.load()
     q, c = oracle.golden_inputs(50_000, 17, 768, 13, "cos")
     ident = C.create_string_buffer(128)

@@ -134,6 +134,22 @@ def _preload_torch_hip_runtime() -> None:
         pass   # fall back to the system runtime
 
 
+def prefer_torch_rccl() -> None:
+    """One RCCL per process: when PyTorch-ROCm is installed, point libtsearch's lazy RCCL binding (dlopen at the first
+    ts_comm_* / ts_shards_* call) at the copy torch bundles and may already have mapped, unless TS_RCCL_LIB says otherwise."""
+    if os.environ.get("TS_RCCL_LIB"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is not None and spec.submodule_search_locations:
+            path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
+            if os.path.exists(path):
+                os.environ["TS_RCCL_LIB"] = path
+    except Exception:
+        pass
+
+
 def load() -> C.CDLL:
     """Load libtsearch.so (once).  Raises if it has not been built."""
     global _lib

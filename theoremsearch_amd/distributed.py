@@ -118,6 +118,7 @@ class ShardedSearcher:
     def _init_native_comm(self) -> None:
         """ts_comm_create on every rank; torch.distributed only carries the unique id (start-up, not the search path)."""
         from . import _ffi
+        _ffi.prefer_torch_rccl()
         lib = _ffi.load()
         ident = [None]
         if self.rank == 0:
@@ -279,6 +280,7 @@ class Shards:
     def __init__(self, n_total: int, d: int, ngpu: int, dtype: str = "bf16", metric: str = "ip", devices=None):
         from . import _ffi
         from .index import _DTYPES, _METRICS
+        _ffi.prefer_torch_rccl()
         self._lib = _ffi.load()
         self._h = C.c_void_p()
         self.n_total, self.d, self.ngpu = int(n_total), int(d), int(ngpu)
