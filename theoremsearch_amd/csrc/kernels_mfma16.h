@@ -16,8 +16,9 @@
 //     MFMAs; a query fragment is 4 registers per (block, k-step): NB * 24 * 4 = 384 registers at NB = 4, the first
 //     kQV fragments in VGPRs, the rest in AGPRs (MFMA B operands may be either);
 //   * D[i][j] = <row i, query j>: lane l holds rows 4 (l >> 4) + {0..3} of each row block for query (l & 15) of each of
-//     its blocks, so thresholds are per lane and block; passing scores go to lane-private lists (one writer per
-//     workgroup and lane quarter: 4 * gridDim.x writers, 16 entries each), overflow to the query's shared list.
+//     its blocks, so thresholds are per lane and block.  Passing scores of the FULL pass are staged in LDS and written
+//     to the queries' shared lists after the tile loop; the sample levels (every score is a candidate) write lane-private
+//     lists in global memory (one writer per workgroup and lane quarter: 4 * gridDim.x writers, 16 entries each).
 //
 // The LDS image, the DMA ring, its counted waits and the barrier protocol are those of kernels_mfma.h (the 16-row
 // operand read of this shape is conflict-free on the same swizzled image: lane (r, q) reads chunk 4 (s & 1) + q of row r).
@@ -32,9 +33,11 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int kMfma16PrivCap = 16;   // entries of a lane-private candidate list (4 * gridDim.x writers per query)
 // Full pass: candidates are staged in LDS (16 bytes each: key, query) and written to the queries' shared lists when the
-// workgroup has finished.  A global store inside the tile loop joins the vmcnt queue of the DMA ring, whose counted waits
-// then ask for one piece more than intended: measured ~470 cycles of stall (x 4 waves at the barrier) per candidate -
-// 1 % of the pass at 10M rows, 18 % on a 1.25M-row shard (the candidates per query do not shrink with the shard).
+// workgroup has finished its tiles: no vector-memory operation of the append path joins the vmcnt queue of the DMA ring
+// (its counted waits would ask for one piece more than intended), and the final select gathers one list per query
+// instead of 4 * gridDim.x private ones.  What an appended candidate still costs is the path's own ~150 instructions on a
+// wave the other three wait for at the next barrier: ~0.3 us of one CU per candidate, whatever N - 10 % of a 1.25M-row
+// shard's pass at 160 candidates per query, which is why the threshold estimate aims at 6 k of them (tsearch_api.hip).
 constexpr int kMfma16StageCap = 192;                                 // entries per wave (~40 expected at k = 10)
 constexpr int kMfma16StageBytes = 4 * kMfma16StageCap * 16 + 16;     // + one counter per wave
 
