@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # name: (rows, dtype, nq)
     "c2": (1_000_000, "f32", 1),
-    "c2b": (1_000_000, "f32", 256),    # the same fp32 corpus, batch 256: the exact-fp32 MFMA path (kernels_mfma_f32.h)
+    "c2b": (1_000_000, "f32", 256),    # the same fp32 corpus, batch 256: the exact-fp32 MFMA path (kernels_mfma16.h, F32 mode)
     "c3": (10_000_000, "bf16", 256),
     "c4": (50_000_000, "bf16", 256),
     "c5": (10_000_000, "bf16", 256),   # encoder-in-loop: sentence-encoder forward feeds the C3 index
@@ -267,7 +267,7 @@ def main():
                                                   "this command (tools/run_profiles.sh), not an observation of this run"}
         except Exception:
             traffic = None
-    kernel_name = {"mfma": "mfma16_topk_kernel" if (bf16 and D == 768) else ("mfma_f32_topk_kernel" if not bf16 else "mfma_topk_kernel"),
+    kernel_name = {"mfma": "mfma16_topk_kernel" if (D == 768 or not bf16) else "mfma_topk_kernel",
                    "scan": "scan_kernel"}.get(stats_algo or ("scan" if mask_ptr and nq <= 4 else None), "unknown")
     if stats_algo is None and encoder is not None:
         kernel_name = "mfma16_topk_kernel" if D == 768 else "mfma_topk_kernel"

@@ -543,16 +543,18 @@ def test_empty_and_invalid_arguments(ts):
         assert (i == -1).all() and np.isneginf(s).all()
 
 
-# ---- batched fp32: the exact-fp32 matrix path (v_mfma_f32_32x32x2_f32) ----------------------------------------------
+# ---- batched fp32: the exact-fp32 matrix paths (v_mfma_f32_16x16x4_f32, v_mfma_f32_32x32x2_f32) ---------------------
+@pytest.mark.parametrize("shape", [16, 32])
 @pytest.mark.parametrize("n,nq,k,metric", [(200_000, 130, 10, "cos"), (70_001, 73, 200, "ip"), (16_384, 13, 1, "cos"),
-                                           (300_000, 256, 10, "ip")])
-def test_fp32_batches_run_on_the_fp32_mfma_path(ts, n, nq, k, metric):
+                                           (300_000, 256, 10, "ip"), (120_000, 64, 10, "cos"), (90_000, 193, 33, "ip")])
+def test_fp32_batches_run_on_the_fp32_mfma_path(ts, n, nq, k, metric, shape):
     """The reference's evaluation is an fp32 [Q x N] matrix with Q ~ 73 (compare_embeddings.py:61,105): batches of an fp32
-    index go through the fp32 matrix kernel (128 queries per launch) instead of ceil(Q / 4) scan passes - same protocol,
-    same answers as the scan at pinned ranks."""
+    index go through an fp32 matrix kernel (64 / 128 queries per launch on the 16x16x4 form, the default; 128 on the
+    32x32x2 kernel) instead of ceil(Q / 4) scan passes - same protocol, same answers as the scan at pinned ranks."""
     q, c = oracle.golden_inputs(n, nq, 768, 1000 + nq, metric)
     c[n // 2] = c[3]                                          # an exact tie
     with ts.TheoremIndex.from_embeddings(c, dtype="f32", metric=metric) as ix:
+        ix.set_option("TS_MFMA_F32", shape)
         scores, idx, st = ix.search(q, k, return_stats=True)             # auto
         assert st["algo"] == 2 and st["fallback_queries"] == 0, st
         check(q, c, metric, "f32", k, scores, idx)

@@ -58,6 +58,7 @@ template <> struct MfmaGeom<512> { static constexpr int kUnitK = 256, kSlots = 8
 template <> struct MfmaGeom<384> { static constexpr int kUnitK = 192, kSlots = 8; };
 // fp32 rows seen as twice as many 2-byte elements (kernels_mfma16.h, F32): 1024 floats = 4096-byte rows, eight 16 KiB units
 template <> struct MfmaGeom<2048> { static constexpr int kUnitK = 256, kSlots = 8; };
+template <> struct MfmaGeom<1536> { static constexpr int kUnitK = 384, kSlots = 6; };   // 768 floats: 3072-byte rows, four 24 KiB units
 template <int D> struct MfmaDims {
     static constexpr int kKSteps = D / 16;
     static constexpr int kUnitK = MfmaGeom<D>::kUnitK;

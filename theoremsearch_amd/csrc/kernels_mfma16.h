@@ -67,6 +67,9 @@ __device__ __forceinline__ void mfma16f_v(f32x4& acc, float a, float b) {
 __device__ __forceinline__ void mfma16f_a(f32x4& acc, float a, float b) {
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
 }
+__device__ __forceinline__ void mfma16f_a_first(f32x4& acc, float a, float b) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b));
+}
 // wait states between the last MFMA writing an accumulator and its first VALU reader (hipcc pads nothing for asm)
 template <int NB>
 __device__ __forceinline__ void mfma16_settle(f32x4 (&acc)[2][NB]) {
@@ -308,8 +311,8 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         constexpr int f_ = (B_) * kSteps + (KS_);                                                          \
         const f32x4& af4_ = reinterpret_cast<const f32x4&>(AF_);                                           \
         if constexpr ((KS_) == 0 && (I_) == 0) {                                                           \
-            static_assert(kQV >= 1, "the first query fragment lives in a VGPR");                           \
-            mfma16f_v_first(acc[RB_][B_], af4_[I_], reinterpret_cast<const f32x4&>(qv[0])[I_]);            \
+            if constexpr (f_ < kQV) mfma16f_v_first(acc[RB_][B_], af4_[I_], reinterpret_cast<const f32x4&>(qv[f_ < kQV ? f_ : 0])[I_]); \
+            else mfma16f_a_first(acc[RB_][B_], af4_[I_], reinterpret_cast<const f32x4&>(qa[f_ >= kQV ? f_ - kQV : 0])[I_]); \
         } else if constexpr (f_ < kQV) {                                                                   \
             mfma16f_v(acc[RB_][B_], af4_[I_], reinterpret_cast<const f32x4&>(qv[f_ < kQV ? f_ : 0])[I_]);  \
         } else {                                                                                           \

@@ -639,7 +639,7 @@ static inline bool mfma_dim(int d) { return d == 384 || d == 512 || d == 768 || 
 // (kernels_mfma16.h, F32) on the exact-fp32 matrix instructions
 static inline bool mfma_index(const ts_index* ix) {
     return (ix->dtype == TS_BF16 && mfma_dim(ix->d)) ||
-           (ix->dtype == TS_F32 && (ix->d == 768 || ix->d == 1024) && ix->knobs.get(K_MFMA_F32, 1) != 0);
+           (ix->dtype == TS_F32 && (ix->d == 768 || ix->d == 1024) && ix->knobs.get(K_MFMA_F32, 16) != 0);
 }
 
 static int ensure_search_scratch(ts_index* ix, int k) {
@@ -1009,25 +1009,29 @@ static int launch_mfma_f32(bool full_pass, int variant, int grid, hipStream_t st
 // Which MFMA shape serves this index: d = 768 runs the 16x16x32 kernel (kernels_mfma16.h) unless TS_MFMA_SHAPE=32 asks for
 // the 32x32x16 one (kernels_mfma.h), which also serves the other widths.
 static bool use_shape16(const ts_index* ix) {
-    if (ix->dtype == TS_F32) return ix->d == 1024;      // fp32 x 1024: the 16x16x4 form of the same kernel
+    // fp32: the 16x16x4 form of the same kernel (10M x 768, 256 queries: 14.1 ms a pass against 14.8 ms of the 32x32x2
+    // kernel, which TS_MFMA_F32=32 still selects for d = 768)
+    if (ix->dtype == TS_F32) return ix->d == 1024 || ix->knobs.get(K_MFMA_F32, 16) != 32;
     return ix->dtype == TS_BF16 && (ix->d == 768 || ix->d == 1024) && ix->knobs.get(K_MFMA_SHAPE, 16) != 32;
 }
 
-// fp32 index, d = 1024: mfma16_topk_kernel<1024, 1, ., ., F32 = true> - one block of 16 queries per wave, 64 per launch
-static int launch_mfma16_f32_1024(bool full_pass, int grid, hipStream_t st, const MfmaArgs& a) {
-    constexpr int lds = MfmaDims<2048>::kLds + kMfma16StageBytes;
+// fp32 index: mfma16_topk_kernel<D, NB, ., ., F32 = true>.  d = 1024: one block of 16 queries per wave, 64 per launch;
+// d = 768: two blocks, 128 per launch (one block when the batch has at most 64 queries)
+template <int D, int NB>
+static int launch_mfma16_f32(bool full_pass, int grid, hipStream_t st, const MfmaArgs& a) {
+    constexpr int lds = MfmaDims<2 * D>::kLds + kMfma16StageBytes;
     static_assert(lds <= 160 * 1024, "DMA ring + staged candidates must fit the CU's LDS");
     static std::atomic<unsigned long long> attr_done{0};
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<1024, 1, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<1024, 1, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done.fetch_or(bit, std::memory_order_release);
     }
-    if (!full_pass) mfma16_topk_kernel<1024, 1, 0, true, true><<<grid, kMfmaThreads, lds, st>>>(a);
-    else mfma16_topk_kernel<1024, 1, 0, false, true><<<grid, kMfmaThreads, lds, st>>>(a);
+    if (!full_pass) mfma16_topk_kernel<D, NB, 0, true, true><<<grid, kMfmaThreads, lds, st>>>(a);
+    else mfma16_topk_kernel<D, NB, 0, false, true><<<grid, kMfmaThreads, lds, st>>>(a);
     HIP_TRY(hipGetLastError());
     return TS_OK;
 }
@@ -1035,7 +1039,11 @@ static int launch_mfma16_f32_1024(bool full_pass, int grid, hipStream_t st, cons
 // Queries one launch of the MFMA kernel serves for this index / batch: d = 768 holds two query groups per wave
 // (256 queries; one group = half the matrix work when the batch is <= 128), d = 1024 one (128 queries).
 static int mfma_block_queries(const ts_index* ix, int nq) {
-    if (ix->dtype == TS_F32) return ix->d == 1024 ? 64 : kMfmaF32Queries;   // 16 (d = 1024) / 32 fp32 queries x 4 waves
+    if (ix->dtype == TS_F32) {
+        if (ix->d == 1024) return 64;                          // one block of 16 queries x 4 waves
+        if (use_shape16(ix)) return nq <= 64 ? 64 : 128;       // one or two blocks per wave
+        return kMfmaF32Queries;                                // 32x32x2 kernel: 32 queries x 4 waves
+    }
     if (use_shape16(ix)) {
         // 16 queries x NB blocks x 4 waves; d = 1024 has registers for 3 blocks per wave, and a batch of more than 192
         // queries is cut into equal launches (two of 128 for 256: both then stream at the HBM rate)
@@ -1129,7 +1137,9 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         }
         hipEvent_t stop = full_pass ? prof_begin(ix, st, ix->n) : nullptr;  // only the full pass is bracketed
         int rc;
-        if (ix->dtype == TS_F32 && ix->d == 1024) rc = launch_mfma16_f32_1024(full_pass, grid, st, a);
+        if (ix->dtype == TS_F32 && ix->d == 1024) rc = launch_mfma16_f32<1024, 1>(full_pass, grid, st, a);
+        else if (ix->dtype == TS_F32 && shape16 && nb16 == 1) rc = launch_mfma16_f32<768, 1>(full_pass, grid, st, a);
+        else if (ix->dtype == TS_F32 && shape16) rc = launch_mfma16_f32<768, 2>(full_pass, grid, st, a);
         else if (ix->dtype == TS_F32) rc = launch_mfma_f32(full_pass, variant, grid, st, a);
         else if (shape16 && ix->d == 1024 && nb16 == 3) rc = launch_mfma16<1024, 3>(full_pass, variant, grid, st, a);
         else if (shape16 && ix->d == 1024 && nb16 == 2) rc = launch_mfma16<1024, 2>(full_pass, variant, grid, st, a);

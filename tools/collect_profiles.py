@@ -38,7 +38,7 @@ def main(src, tag):
     if os.path.exists(tpath):
         traffic = json.load(open(tpath))
     notes = []
-    for w, kern in (("c3", "mfma16_topk_kernel<768, 4, 0, false"), ("c2", "scan_kernel"), ("c2b", "mfma_f32_topk_kernel<0, false>")):
+    for w, kern in (("c3", "mfma16_topk_kernel<768, 4, 0, false"), ("c2", "scan_kernel"), ("c2b", "mfma16_topk_kernel<768, 2, 0, false, true")):
         stats = newest(glob.glob(os.path.join(src, f"trace_{w}", "**", "*kernel_stats.csv"), recursive=True))
         if stats:
             shutil.copy(stats[0], os.path.join(out, f"{tag}_{w}_kernel_stats.csv"))
