@@ -23,7 +23,9 @@
  *     stream: it is ordered with the legacy null stream, so NULL is also the right value for work
  *     that lives on the default stream of the caller (torch.cuda.current_stream().cuda_stream is 0
  *     there).  A call that arrives on a different stream than the previous call on the same handle
- *     is ordered behind that call by the library (the handle's scratch buffers are shared).
+ *     is ordered behind that call by the library (the handle's scratch buffers are shared); for
+ *     that the library records an event on the previous call's stream, so a caller-owned stream
+ *     must stay alive until the next call on the handle or until ts_index_synchronize has returned.
  *   - one handle may be used from several threads (the Streamlit apps share one model and one
  *     library across session threads, streamlit_app.py:52); calls on one handle are serialised
  *     inside, different handles are independent.
@@ -88,6 +90,7 @@ int ts_device_synchronize(int device);
  * rounds to bf16 when dtype is TS_BF16.  row_offset is the global id of row 0 (sharded use).
  */
 int ts_index_create(int device, int64_t n, int32_t d, int dtype, int metric, ts_index **out);
+/* Waits for the handle's work in flight, then frees it.  TS_ERR_UNSUPPORTED while views of it are alive (ts_index_view). */
 int ts_index_destroy(ts_index *ix);
 int ts_index_set_row_offset(ts_index *ix, int64_t row_offset);
 /* The index's own HIP stream (hipStream_t as void*): what stream = NULL means in the calls below. */

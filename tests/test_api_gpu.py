@@ -59,6 +59,11 @@ def test_append_is_refused_while_views_exist_and_on_derived_indexes(ts):
         assert e.value.code == -5 and ix.n == 300
         with pytest.raises(_ffi.TSearchError):
             v.append(c[300:301])
+        with pytest.raises(_ffi.TSearchError) as e:
+            ix.close()                                     # the view reads the owner's rows: destroy refused, handle kept
+        assert e.value.code == -5
+        sv, iv = v.search(q, 3)
+        assert np.array_equal(iv, ix.search(q, 3)[1])
         v.close()
         assert ix.append(c[300:2000]) == 300 and ix.n == 2000
         sub = ix.subset(np.arange(0, 2000, 2))

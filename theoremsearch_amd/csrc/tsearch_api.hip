@@ -13,6 +13,7 @@
 #include <atomic>
 #include <mutex>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/tsearch.h"
@@ -273,6 +274,7 @@ extern "C" int ts_index_view(ts_index* src, ts_index** out) {
     if (!out) return fail(TS_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (!src) return fail(TS_ERR_INVALID, "index is NULL");
+    std::lock_guard<std::mutex> lock(src->mu);      // not while the rows are being moved by an append
     HIP_TRY(hipSetDevice(src->device));
     ts_index* ix = new (std::nothrow) ts_index();
     if (!ix) return fail(TS_ERR_NOMEM, "host allocation failed");
@@ -300,7 +302,10 @@ extern "C" int ts_index_view(ts_index* src, ts_index** out) {
 
 extern "C" int ts_index_destroy(ts_index* ix) {
     if (!ix) return TS_OK;
+    if (ix->nviews.load() > 0)
+        return fail(TS_ERR_UNSUPPORTED, "the index has %d live views: destroy them first (they read its rows)", ix->nviews.load());
     hipSetDevice(ix->device);
+    if (ix->last_stream && ix->last_stream != ix->stream) hipStreamSynchronize(ix->last_stream);   // scratch still in use there
     if (ix->stream) hipStreamSynchronize(ix->stream);
     if (ix->borrowed) {
         ix->rows = nullptr;
@@ -365,7 +370,12 @@ extern "C" int ts_index_subset(ts_index* src, const int64_t* rows, int64_t nrows
         return TS_OK;
     }
     std::lock_guard<std::mutex> lock(src->mu);
-    hipStreamSynchronize(src->stream);  // uploads enqueued on the source's own stream
+    hipStream_t src_own;
+    if (enter_stream(src, nullptr, &src_own) != TS_OK) {   // uploads enqueued on the source's own or a caller's stream
+        ts_index_destroy(ix);
+        return TS_ERR_HIP;
+    }
+    hipStreamSynchronize(src_own);
     hipError_t e = hipMalloc((void**)&ix->id_map, (size_t)nrows * 8);
     if (e == hipSuccess) e = hipMemcpyAsync(ix->id_map, rows, (size_t)nrows * 8, hipMemcpyHostToDevice, ix->stream);
     if (e == hipSuccess) {
@@ -389,6 +399,7 @@ extern "C" int ts_index_synchronize(ts_index* ix) {
     HIP_TRY(hipSetDevice(ix->device));
     if (ix->last_stream && ix->last_stream != ix->stream) HIP_TRY(hipStreamSynchronize(ix->last_stream));
     HIP_TRY(hipStreamSynchronize(ix->stream));
+    ix->last_stream = nullptr;      // nothing in flight: the caller may destroy that stream now, the next call orders behind nothing
     return TS_OK;
 }
 
@@ -643,38 +654,29 @@ static inline bool mfma_index(const ts_index* ix) {
 }
 
 static int ensure_search_scratch(ts_index* ix, int k) {
-    size_t z = 0;
-    if (!ix->qstore) {
+    // each buffer on its own: a failed allocation leaves the others as they are and is retried by the next call
+    auto need = [](auto** slot, size_t bytes, bool zero) -> int {
+        if (*slot) return TS_OK;
         void* p = nullptr;
-        z = 0;
-        TS_TRY(ensure(&p, &z, (size_t)kQBlock * ix->ld * ix->elem()));
-        ix->qstore = p;
-        p = nullptr; z = 0;
-        TS_TRY(ensure(&p, &z, (size_t)kQBlock * ix->ld * 4));
-        ix->qf32 = (float*)p;
-        p = nullptr; z = 0;
-        TS_TRY(ensure(&p, &z, (size_t)kQBlock * 4));
-        ix->count = (u32*)p;
-        HIP_TRY(hipMemset(ix->count, 0, kQBlock * 4));
-        p = nullptr; z = 0;
-        TS_TRY(ensure(&p, &z, (size_t)kQBlock * 4));
-        ix->thr = (float*)p;
-        p = nullptr; z = 0;
-        TS_TRY(ensure(&p, &z, (size_t)kQBlock * 4));
-        ix->fb_list = (int*)p;
-        p = nullptr; z = 0;
-        TS_TRY(ensure(&p, &z, 16));
-        ix->fb_count = (int*)p;
-        p = nullptr; z = 0;
-        TS_TRY(ensure(&p, &z, 16));
-        ix->stat = (unsigned long long*)p;
-    }
-    if (!ix->cand && mfma_index(ix)) {
-        void* p = nullptr;
-        z = 0;
-        TS_TRY(ensure(&p, &z, (size_t)kQBlock * kCandCap * 8));
-        ix->cand = (u64*)p;
-    }
+        HIP_TRY(hipMalloc(&p, bytes));
+        if (zero) {
+            const hipError_t e = hipMemset(p, 0, bytes);
+            if (e != hipSuccess) {
+                hipFree(p);
+                return fail(TS_ERR_HIP, "hipMemset of search scratch failed: %s", hipGetErrorString(e));
+            }
+        }
+        *slot = (std::remove_pointer_t<decltype(slot)>)p;
+        return TS_OK;
+    };
+    TS_TRY(need(&ix->qstore, (size_t)kQBlock * ix->ld * ix->elem(), false));
+    TS_TRY(need(&ix->qf32, (size_t)kQBlock * ix->ld * 4, false));
+    TS_TRY(need(&ix->count, (size_t)kQBlock * 4, true));
+    TS_TRY(need(&ix->thr, (size_t)kQBlock * 4, false));
+    TS_TRY(need(&ix->fb_list, (size_t)kQBlock * 4, false));
+    TS_TRY(need(&ix->fb_count, 16, true));
+    TS_TRY(need(&ix->stat, 16, true));
+    if (mfma_index(ix)) TS_TRY(need(&ix->cand, (size_t)kQBlock * kCandCap * 8, false));
     // scan partials: [256 slots][grid][k] keys, twice (ping-pong for the select rounds)
     const size_t grid = (size_t)ix->cu_count * kScanGridPerCU;
     const size_t want = (size_t)kQBlock * grid * (size_t)k * 8;

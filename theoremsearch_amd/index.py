@@ -280,7 +280,7 @@ class TheoremIndex:
     # -- lifetime ---------------------------------------------------------------------------
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:
-            self._lib.ts_index_destroy(self._h)
+            _ffi.check(self._lib.ts_index_destroy(self._h))      # refused while views of this index are alive
             self._h = C.c_void_p()
 
     def __del__(self):
