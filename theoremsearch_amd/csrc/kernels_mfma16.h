@@ -70,6 +70,13 @@ __device__ __forceinline__ void mfma16f_a(f32x4& acc, float a, float b) {
 __device__ __forceinline__ void mfma16f_a_first(f32x4& acc, float a, float b) {
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b));
 }
+// A-fragment read with a fixed place in the instruction stream (asm volatile statements keep their order among themselves):
+// the compiler does not know the result is asynchronous - every consumer sits behind an explicit s_waitcnt lgkmcnt below.
+template <int OFF>
+__device__ __forceinline__ void lds_read16(bf16x8& dst, unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
 // wait states between the last MFMA writing an accumulator and its first VALU reader (hipcc pads nothing for asm)
 template <int NB>
 __device__ __forceinline__ void mfma16_settle(f32x4 (&acc)[2][NB]) {
@@ -146,6 +153,7 @@ __device__ __forceinline__ void mfma16_append_block(const f32x4& a0, const f32x4
 // the vmcnt wait, the barrier and each DMA issue (sums per wave into a.dbg; the stamps drain the LDS queue: read the
 // SHARES, not the length).  3 = product + clock probe: s_memtime / s_memrealtime around the tile loop into a.dbg
 // (4 words per workgroup: shader cycles, 100 MHz ticks, units, 0) - MI355X_MICROARCH.md "DVFS give-back" item 6.
+// 6 = product + s_sleep of ~256 cycles per unit (how much of an added idle cycle shows up as time under the power cap).
 // SPARSE only changes the symbol (sample levels show up under their own name in kernel traces).
 //
 // F32: the same kernel over an fp32 index (exact fp32: v_mfma_f32_16x16x4_f32, bit for bit an fmaf chain).  A row of D
@@ -173,11 +181,10 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     static_assert(kUnits == 2 || kUnits == 4 || kUnits == 8, "units per tile");
     constexpr bool kStaged = !SPARSE;                    // full pass: candidates through LDS (see kMfma16StageCap)
     constexpr int kFrags = NB * kSteps;                  // query fragments of this wave
-#ifndef TS16_AHEAD
-#define TS16_AHEAD 2
-#endif
-    // k-steps of A fragments in flight (TS16_AHEAD, where it divides the unit): 2 measured best (3: see DESIGN.md 3.2)
-    constexpr int kA = (kUnitSteps % TS16_AHEAD == 0) ? TS16_AHEAD : 2;
+    // A-fragment ring of kA k-steps: during k-step s the two reads of k-step s + kA - 1 are issued into the slot k-step s - 1
+    // has just left, right behind the first two MFMAs of s (two k-steps = 16 MFMAs of latency cover at NB = 4).  The ring
+    // position is s % kA inside every unit, so kA divides the unit: 3 for units of 12 k-steps, 4 for units of 8.
+    constexpr int kA = (kUnitSteps % 3 == 0) ? 3 : 4;
     constexpr int kQVmax = 36 - 2 * (kA - 2);            // the ring's registers come out of the VGPR share of the queries
     constexpr int kQV = kFrags < kQVmax ? kFrags : kQVmax;   // ... the first kQV of them in VGPRs, the rest in AGPRs
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -240,7 +247,8 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     const unsigned char* tile_src = (const unsigned char*)a.corpus + (int64_t)drow * (Deq * 2) + dchunk * 16 + g0 * tile_bytes;
     int issue_run_pos = (int)(t0 % a.run);
     int issue_u = 0, issue_ui = 0, issue_slot = 0;
-    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem + wave * 1024;
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned lds0 = lds_base + wave * 1024;
 
     // operand read offsets inside a unit image: row block rb, k-step s -> (s >> 1) * 4096 + rb * 2048 + xo[s & 1]
     const int lane_off = (r16 >> 3) * 1024 + (r16 & 7) * 128;
@@ -273,12 +281,20 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    // A-fragment ring: k-steps s .. s + kA - 1 in flight, two row blocks each: af[2 (s % kA) + rb]
+    // A-fragment ring: af[2 (s % kA) + rb]; k-steps 0 .. kA - 2 of the first unit are fetched here
     bf16x8 af[2 * kA];
-#pragma unroll
-    for (int s = 0; s < kA; ++s)
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) af[2 * s + rb] = *(const bf16x8*)(smem + (s >> 1) * 4096 + rb * 2048 + xo[s & 1]);
+    {
+        const unsigned p0 = lds_base + xo[0], p1 = lds_base + xo[1];
+        lds_read16<0>(af[0], p0);
+        lds_read16<2048>(af[1], p0);
+        lds_read16<0>(af[2], p1);
+        lds_read16<2048>(af[3], p1);
+        if constexpr (kA > 3) {
+            lds_read16<4096>(af[4], p0);
+            lds_read16<4096 + 2048>(af[5], p0);
+        }
+        static_assert(kA == 3 || kA == 4, "prologue written for rings of 3 or 4 k-steps");
+    }
 
     f32x4 acc[2][NB];
     u32 cnt[NB];
@@ -320,57 +336,15 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         }                                                                                                  \
     } while (0)
 
-    /* issue order of the 2 NB MFMAs of a k-step: query-block major (consecutive MFMAs share the query fragment; the */ \
-    /* epilogue's block order relies on it) - TS16_ORDER_A builds the row-block-major order for A/B runs */
-#ifndef TS16_ORDER_A
-#define TS16_MMA_ORDER(KS_, R0_)                                                                           \
+    /* the two reads of k-step N_ (this unit's or the next one's image) into the ring slot of N_ */
+#define TS16_LOAD(RB_, N_)                                                                                 \
     do {                                                                                                   \
-        TS16_MMA(0, 0, KS_, af[R0_]);                                                                      \
-        TS16_MMA(1, 0, KS_, af[R0_ + 1]);                                                                  \
-        if constexpr (NB > 1) { TS16_MMA(0, 1, KS_, af[R0_]); TS16_MMA(1, 1, KS_, af[R0_ + 1]); }          \
-        if constexpr (NB > 2) { TS16_MMA(0, 2, KS_, af[R0_]); TS16_MMA(1, 2, KS_, af[R0_ + 1]); }          \
-        if constexpr (NB > 3) { TS16_MMA(0, 3, KS_, af[R0_]); TS16_MMA(1, 3, KS_, af[R0_ + 1]); }          \
+        constexpr int w_ = 2 * ((N_) % kA) + (RB_);                                                        \
+        if constexpr ((N_) < kUnitSteps) lds_read16<((N_) >> 1) * 4096 + (RB_) * 2048>(af[w_], ua[(N_) & 1]); \
+        else lds_read16<(((N_) - kUnitSteps) >> 1) * 4096 + (RB_) * 2048>(af[w_], na[(N_) & 1]);          \
     } while (0)
-#else
-#define TS16_MMA_ORDER(KS_, R0_)                                                                           \
+#define TS16_PIECE(S_)                                                                                     \
     do {                                                                                                   \
-        TS16_MMA(0, 0, KS_, af[R0_]);                                                                      \
-        if constexpr (NB > 1) TS16_MMA(0, 1, KS_, af[R0_]);                                                \
-        if constexpr (NB > 2) TS16_MMA(0, 2, KS_, af[R0_]);                                                \
-        if constexpr (NB > 3) TS16_MMA(0, 3, KS_, af[R0_]);                                                \
-        TS16_MMA(1, 0, KS_, af[R0_ + 1]);                                                                  \
-        if constexpr (NB > 1) TS16_MMA(1, 1, KS_, af[R0_ + 1]);                                            \
-        if constexpr (NB > 2) TS16_MMA(1, 2, KS_, af[R0_ + 1]);                                            \
-        if constexpr (NB > 3) TS16_MMA(1, 3, KS_, af[R0_ + 1]);                                            \
-    } while (0)
-#endif
-
-#define TS16_STEP(UI, S_)                                                                                  \
-    do {                                                                                                   \
-        constexpr int ks_ = (UI) * kUnitSteps + (S_);                                                      \
-        constexpr int r0_ = 2 * ((S_) % kA);                                                               \
-        if constexpr (!kNoMma && F32) {                                                                    \
-            /* i-major: the 2 NB accumulators in turn for each of the chunk's four floats */               \
-            TS16_MMAF(0, 0, ks_, af[r0_], 0); TS16_MMAF(1, 0, ks_, af[r0_ + 1], 0);                        \
-            if constexpr (NB > 1) { TS16_MMAF(0, 1, ks_, af[r0_], 0); TS16_MMAF(1, 1, ks_, af[r0_ + 1], 0); } \
-            TS16_MMAF(0, 0, ks_, af[r0_], 1); TS16_MMAF(1, 0, ks_, af[r0_ + 1], 1);                        \
-            if constexpr (NB > 1) { TS16_MMAF(0, 1, ks_, af[r0_], 1); TS16_MMAF(1, 1, ks_, af[r0_ + 1], 1); } \
-            TS16_MMAF(0, 0, ks_, af[r0_], 2); TS16_MMAF(1, 0, ks_, af[r0_ + 1], 2);                        \
-            if constexpr (NB > 1) { TS16_MMAF(0, 1, ks_, af[r0_], 2); TS16_MMAF(1, 1, ks_, af[r0_ + 1], 2); } \
-            TS16_MMAF(0, 0, ks_, af[r0_], 3); TS16_MMAF(1, 0, ks_, af[r0_ + 1], 3);                        \
-            if constexpr (NB > 1) { TS16_MMAF(0, 1, ks_, af[r0_], 3); TS16_MMAF(1, 1, ks_, af[r0_ + 1], 3); } \
-        }                                                                                                  \
-        if constexpr (!kNoMma && !F32) TS16_MMA_ORDER(ks_, r0_);                                           \
-        if constexpr (!kNoMma) {                                                                           \
-            constexpr int n_ = (S_) + kA;                                                                  \
-            if constexpr (n_ < kUnitSteps) {                                                               \
-                af[r0_] = *(const bf16x8*)(unit + (n_ >> 1) * 4096 + xo[n_ & 1]);                          \
-                af[r0_ + 1] = *(const bf16x8*)(unit + (n_ >> 1) * 4096 + 2048 + xo[n_ & 1]);               \
-            } else {                                                                                       \
-                af[r0_] = *(const bf16x8*)(next_unit + ((n_ - kUnitSteps) >> 1) * 4096 + xo[n_ & 1]);      \
-                af[r0_ + 1] = *(const bf16x8*)(next_unit + ((n_ - kUnitSteps) >> 1) * 4096 + 2048 + xo[n_ & 1]); \
-            }                                                                                              \
-        }                                                                                                  \
         if constexpr ((S_) % kPieceEvery == kPieceEvery - 1)                                               \
             if (do_issue) {                                                                                \
                 unsigned long long d0_ = 0;                                                                \
@@ -379,12 +353,51 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
                 if (VARIANT == 5) t_dma += cycle_stamp() - d0_;                                            \
             }                                                                                              \
     } while (0)
+    // One k-step.  The fillers have fixed places between the MFMAs (a 16x16x32 MFMA leaves 8 of its 16 cycles of vector
+    // issue free: two simple instructions per gap hide, a cluster behind the last MFMA does not): the wait for this
+    // k-step's fragments, MFMA, read, MFMA, read, two MFMAs, the DMA piece when one is due, the remaining MFMAs.
+#define TS16_STEP(UI, S_)                                                                                  \
+    do {                                                                                                   \
+        constexpr int ks_ = (UI) * kUnitSteps + (S_);                                                      \
+        constexpr int r0_ = 2 * ((S_) % kA);                                                               \
+        constexpr int n_ = (S_) + kA - 1;                                                                  \
+        if constexpr (!kNoMma) {                                                                           \
+            /* all but the reads of the kA - 2 k-steps after this one have landed (LDS returns in order); the wait */ \
+            /* names this k-step's fragments, so that no consumer of them is placed above it */             \
+            if constexpr (kA == 3) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(af[r0_]), "+v"(af[r0_ + 1])); \
+            else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[r0_]), "+v"(af[r0_ + 1]));                  \
+        }                                                                                                  \
+        if constexpr (!kNoMma && F32) {                                                                    \
+            /* i-major: the 2 NB accumulators in turn for each of the chunk's four floats */               \
+            TS16_MMAF(0, 0, ks_, af[r0_], 0); TS16_LOAD(0, n_);                                            \
+            TS16_MMAF(1, 0, ks_, af[r0_ + 1], 0); TS16_LOAD(1, n_);                                        \
+            if constexpr (NB > 1) { TS16_MMAF(0, 1, ks_, af[r0_], 0); TS16_MMAF(1, 1, ks_, af[r0_ + 1], 0); } \
+            TS16_MMAF(0, 0, ks_, af[r0_], 1); TS16_MMAF(1, 0, ks_, af[r0_ + 1], 1);                        \
+            TS16_PIECE(S_);                                                                                \
+            if constexpr (NB > 1) { TS16_MMAF(0, 1, ks_, af[r0_], 1); TS16_MMAF(1, 1, ks_, af[r0_ + 1], 1); } \
+            TS16_MMAF(0, 0, ks_, af[r0_], 2); TS16_MMAF(1, 0, ks_, af[r0_ + 1], 2);                        \
+            if constexpr (NB > 1) { TS16_MMAF(0, 1, ks_, af[r0_], 2); TS16_MMAF(1, 1, ks_, af[r0_ + 1], 2); } \
+            TS16_MMAF(0, 0, ks_, af[r0_], 3); TS16_MMAF(1, 0, ks_, af[r0_ + 1], 3);                        \
+            if constexpr (NB > 1) { TS16_MMAF(0, 1, ks_, af[r0_], 3); TS16_MMAF(1, 1, ks_, af[r0_ + 1], 3); } \
+        }                                                                                                  \
+        if constexpr (!kNoMma && !F32) {                                                                   \
+            /* query-block major (consecutive MFMAs share the query fragment; the epilogue's block order relies on it) */ \
+            TS16_MMA(0, 0, ks_, af[r0_]); TS16_LOAD(0, n_);                                                \
+            TS16_MMA(1, 0, ks_, af[r0_ + 1]); TS16_LOAD(1, n_);                                            \
+            if constexpr (NB > 1) { TS16_MMA(0, 1, ks_, af[r0_]); TS16_MMA(1, 1, ks_, af[r0_ + 1]); }      \
+            TS16_PIECE(S_);                                                                                \
+            if constexpr (NB > 2) { TS16_MMA(0, 2, ks_, af[r0_]); TS16_MMA(1, 2, ks_, af[r0_ + 1]); }      \
+            if constexpr (NB > 3) { TS16_MMA(0, 3, ks_, af[r0_]); TS16_MMA(1, 3, ks_, af[r0_ + 1]); }      \
+        }                                                                                                  \
+        if constexpr (kNoMma) TS16_PIECE(S_);                                                              \
+    } while (0)
 
 #define TS16_UNIT(UI)                                                                                      \
     do {                                                                                                   \
         const int nslot = (slot + 1 == kSlots) ? 0 : slot + 1;                                             \
-        const unsigned char* unit = smem + slot * kUnitBytes;                                              \
-        const unsigned char* next_unit = smem + nslot * kUnitBytes;                                        \
+        unsigned ua[2], na[2];                                                                             \
+        ua[0] = lds_base + slot * kUnitBytes + xo[0]; ua[1] = lds_base + slot * kUnitBytes + xo[1];        \
+        na[0] = lds_base + nslot * kUnitBytes + xo[0]; na[1] = lds_base + nslot * kUnitBytes + xo[1];      \
         /* certify unit u + 1 (own pieces, then everyone's); every wave is past unit u - 1: its slot is free */ \
         unsigned long long s0_ = 0, s1_ = 0;                                                               \
         if (VARIANT == 5) s0_ = cycle_stamp();                                                             \
@@ -393,6 +406,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         __builtin_amdgcn_s_barrier();                                                                      \
         asm volatile("" ::: "memory");                                                                     \
         if (VARIANT == 5) { t_vm += s1_ - s0_; t_bar += cycle_stamp() - s1_; }                             \
+        if (VARIANT == 6) __builtin_amdgcn_s_sleep(4);   /* ~256 idle cycles per unit: elasticity of time to cycles */ \
         const bool do_issue = issue_u < nu && !kNoDma;                                                     \
         const unsigned char* isrc = tile_src + issue_ui * (kUnitK * 2);                                    \
         const unsigned idst = lds0 + issue_slot * kUnitBytes;                                              \
@@ -455,7 +469,8 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
 #undef TS16_STEP
 #undef TS16_MMA
 #undef TS16_MMAF
-#undef TS16_MMA_ORDER
+#undef TS16_LOAD
+#undef TS16_PIECE
 #undef TS16_ISSUED
     if (kStaged) {
         // the tile loop is over (no DMA in flight that a counted wait still watches): staged candidates -> shared lists

@@ -967,6 +967,7 @@ static int launch_mfma16(bool full_pass, int variant, int grid, hipStream_t st, 
             HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         }
         attr_done.fetch_or(bit, std::memory_order_release);
     }
@@ -980,6 +981,7 @@ static int launch_mfma16(bool full_pass, int variant, int grid, hipStream_t st, 
             else if (variant == 4) mfma16_topk_kernel<D, NB, 4, false><<<grid, kMfmaThreads, lds, st>>>(a);
             else if (variant == 7) mfma16_topk_kernel<D, NB, 7, false><<<grid, kMfmaThreads, lds, st>>>(a);
             else if (variant == 5) mfma16_topk_kernel<D, NB, 5, false><<<grid, kMfmaThreads, lds, st>>>(a);
+            else if (variant == 6) mfma16_topk_kernel<D, NB, 6, false><<<grid, kMfmaThreads, lds, st>>>(a);
             else mfma16_topk_kernel<D, NB, 0, false><<<grid, kMfmaThreads, lds, st>>>(a);
         }
     } else {

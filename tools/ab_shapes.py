@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--variant", action="append", default=[], help="name:KNOB=value[,KNOB=value]")
     ap.add_argument("--out", default="")
+    ap.add_argument("--data", default="normal", choices=["normal", "zeros", "same"],
+                    help="corpus content: the synthetic normal rows; all-zero rows; one normal row repeated (timing of the "
+                         "matrix pipe's data-dependent power: use with a timing-only variant, TS_MFMA_VARIANT=1)")
     args = ap.parse_args()
     import torch
     import synthetic
@@ -38,6 +41,10 @@ def main():
 
     def make(c):
         data = synthetic.synth_chunk(c, ch, args.dim, bf16=bf16)
+        if args.data == "zeros":
+            data = np.zeros_like(data)
+        elif args.data == "same":
+            data = np.ascontiguousarray(np.broadcast_to(data[:1], data.shape))
         ix.upload(data[: min(args.rows, (c + 1) * ch) - c * ch], c * ch)
 
     with ThreadPoolExecutor(16) as ex:
