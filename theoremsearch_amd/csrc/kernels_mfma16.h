@@ -77,6 +77,17 @@ __device__ __forceinline__ void lds_read16(bf16x8& dst, unsigned addr) {
     static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
 }
+// Every outstanding fragment read has landed; names the whole ring, so that no copy of a ring register the compiler may
+// need where control flow merges (end of a tile, steady / general branch) is placed above it.
+template <int N>
+__device__ __forceinline__ void lds_ring_landed(bf16x8 (&af)[N]) {
+    static_assert(N == 6 || N == 8, "ring of 3 or 4 k-steps, two row blocks");
+    if constexpr (N == 6)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]));
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]),
+                     "+v"(af[6]), "+v"(af[7]));
+}
 // wait states between the last MFMA writing an accumulator and its first VALU reader (hipcc pads nothing for asm)
 template <int NB>
 __device__ __forceinline__ void mfma16_settle(f32x4 (&acc)[2][NB]) {
@@ -282,7 +293,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     asm volatile("" ::: "memory");
 
     // A-fragment ring: af[2 (s % kA) + rb]; k-steps 0 .. kA - 2 of the first unit are fetched here
-    bf16x8 af[2 * kA];
+    bf16x8 af[2 * kA] = {};
     {
         const unsigned p0 = lds_base + xo[0], p1 = lds_base + xo[1];
         lds_read16<0>(af[0], p0);
@@ -295,6 +306,8 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         }
         static_assert(kA == 3 || kA == 4, "prologue written for rings of 3 or 4 k-steps");
     }
+    // (ring registers not fetched yet are named too: they hold nothing anyone reads before their first fetch)
+    lds_ring_landed(af);
 
     f32x4 acc[2][NB];
     u32 cnt[NB];
@@ -392,6 +405,32 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         if constexpr (kNoMma) TS16_PIECE(S_);                                                              \
     } while (0)
 
+    // A unit of the steady part of the tile loop: the unit kSlots - 1 ahead is still to be issued (so every piece goes out,
+    // no branch), exactly kSlots - 3 units stay in flight behind the counted wait (an immediate, no ladder), the unit in
+    // the tile that is issued is a compile-time constant, and the ring positions are three running byte offsets
+    // (this unit's slot, the next one's, the one unit u - 1 has left = the issue slot).
+#define TS16_UNIT_S(UI)                                                                                    \
+    do {                                                                                                   \
+        constexpr int cui_ = ((UI) + kSlots - 1) % kUnits;                                                 \
+        const unsigned noff = (soff + kUnitBytes == (unsigned)dims::kLds) ? 0u : soff + kUnitBytes;        \
+        unsigned ua[2], na[2];                                                                             \
+        ua[0] = lds_base + soff + xo[0]; ua[1] = lds_base + soff + xo[1];                                  \
+        na[0] = lds_base + noff + xo[0]; na[1] = lds_base + noff + xo[1];                                  \
+        if constexpr (!kNoDma) wait_vmcnt<(kSlots - 3) * kPieces>();   /* own pieces of unit u + 1 */       \
+        __builtin_amdgcn_s_barrier();                                   /* ... and everyone's */            \
+        asm volatile("" ::: "memory");                                                                     \
+        if (VARIANT == 6) __builtin_amdgcn_s_sleep(4);                                                     \
+        constexpr bool do_issue = !kNoDma;                                                                 \
+        const unsigned char* isrc = tile_src + cui_ * (kUnitK * 2);                                        \
+        const unsigned idst = lds0 + poff;                                                                 \
+        TS16_STEP(UI, 0); TS16_STEP(UI, 1); TS16_STEP(UI, 2); TS16_STEP(UI, 3);                            \
+        TS16_STEP(UI, 4); TS16_STEP(UI, 5); TS16_STEP(UI, 6); TS16_STEP(UI, 7);                            \
+        if constexpr (kUnitSteps > 8) { TS16_STEP(UI, 8 % kUnitSteps); TS16_STEP(UI, 9 % kUnitSteps); TS16_STEP(UI, 10 % kUnitSteps); TS16_STEP(UI, 11 % kUnitSteps); } \
+        if constexpr (cui_ == kUnits - 1 && !kNoDma) tile_src += steady_jump;                              \
+        poff = soff;                                                                                       \
+        soff = noff;                                                                                       \
+    } while (0)
+
 #define TS16_UNIT(UI)                                                                                      \
     do {                                                                                                   \
         const int nslot = (slot + 1 == kSlots) ? 0 : slot + 1;                                             \
@@ -419,18 +458,50 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     } while (0)
 
     static_assert(kUnitSteps == 8 || kUnitSteps == 12, "unit = 8 or 12 k-steps of 32");
+    static_assert(kSlots >= 3, "the steady part keeps kSlots - 3 units in flight behind its wait");
+    // Steady tiles: every unit of the tile still has a unit to issue kSlots - 1 ahead.  (Runs of tiles, a shallower
+    // ring and the stamped build go through the general units below.)
+    const int nt_steady = (a.run == 1 && ahead == kSlots - 1 && VARIANT != 5 && nu > ahead) ? (nu - ahead) / kUnits : 0;
+    const int64_t steady_jump = tile_bytes * a.tile_stride;
+    unsigned soff = 0, poff = (unsigned)(kSlots - 1) * kUnitBytes;
     for (int t = 0; t < nt; ++t) {
-        TS16_UNIT(0);
-        TS16_UNIT(1);
-        if constexpr (kUnits >= 4) {
-            TS16_UNIT(2 % kUnits);
-            TS16_UNIT(3 % kUnits);
-        }
-        if constexpr (kUnits == 8) {
-            TS16_UNIT(4 % kUnits);
-            TS16_UNIT(5 % kUnits);
-            TS16_UNIT(6 % kUnits);
-            TS16_UNIT(7 % kUnits);
+        if (t < nt_steady) {
+            TS16_UNIT_S(0);
+            TS16_UNIT_S(1);
+            if constexpr (kUnits >= 4) {
+                TS16_UNIT_S(2 % kUnits);
+                TS16_UNIT_S(3 % kUnits);
+            }
+            if constexpr (kUnits == 8) {
+                TS16_UNIT_S(4 % kUnits);
+                TS16_UNIT_S(5 % kUnits);
+                TS16_UNIT_S(6 % kUnits);
+                TS16_UNIT_S(7 % kUnits);
+            }
+            if constexpr (!kNoMma) lds_ring_landed(af);      // before any branch: see lds_ring_landed
+            if (t + 1 == nt_steady) {
+                // hand over to the general units: the same ring, counted in units
+                u = kUnits * nt_steady;
+                slot = u % kSlots;
+                issue_u = u + ahead;
+                issue_ui = issue_u % kUnits;
+                issue_slot = issue_u % kSlots;
+                issue_run_pos = 0;
+            }
+        } else {
+            TS16_UNIT(0);
+            TS16_UNIT(1);
+            if constexpr (kUnits >= 4) {
+                TS16_UNIT(2 % kUnits);
+                TS16_UNIT(3 % kUnits);
+            }
+            if constexpr (kUnits == 8) {
+                TS16_UNIT(4 % kUnits);
+                TS16_UNIT(5 % kUnits);
+                TS16_UNIT(6 % kUnits);
+                TS16_UNIT(7 % kUnits);
+            }
+            if constexpr (!kNoMma) lds_ring_landed(af);
         }
         if constexpr (kNoMma) continue;
         // The last k-step issued its MFMAs in block order, so with NB = 4 the results of block b are at least 6 MFMAs
@@ -466,6 +537,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         }
     }
 #undef TS16_UNIT
+#undef TS16_UNIT_S
 #undef TS16_STEP
 #undef TS16_MMA
 #undef TS16_MMAF
