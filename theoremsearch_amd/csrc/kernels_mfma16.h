@@ -30,6 +30,8 @@
 namespace ts {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+// a corpus fragment in flight (one ds_read_b128): four dwords, so that copies of it are four plain register moves
+typedef __attribute__((ext_vector_type(4))) unsigned frag16;
 
 constexpr int kMfma16PrivCap = 16;   // entries of a lane-private candidate list (4 * gridDim.x writers per query)
 // Full pass: candidates are staged in LDS (16 bytes each: key, query) and written to the queries' shared lists when the
@@ -45,16 +47,16 @@ constexpr int kMfma16StageBytes = 4 * kMfma16StageCap * 16 + 16;     // + one co
 // ("v" forms) or an AGPR ("a" forms) quadruple.  No pads inside: the A fragment comes straight from a ds_read (the
 // compiler's lgkmcnt wait covers it), the query fragments are written once before the loop, accumulators chain
 // MFMA -> MFMA; the only non-MFMA reader of an accumulator is the epilogue, behind mfma16_settle().
-__device__ __forceinline__ void mfma16_v_first(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+__device__ __forceinline__ void mfma16_v_first(f32x4& acc, const frag16& a, const bf16x8& b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
 }
-__device__ __forceinline__ void mfma16_v(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+__device__ __forceinline__ void mfma16_v(f32x4& acc, const frag16& a, const bf16x8& b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
-__device__ __forceinline__ void mfma16_a_first(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+__device__ __forceinline__ void mfma16_a_first(f32x4& acc, const frag16& a, const bf16x8& b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b));
 }
-__device__ __forceinline__ void mfma16_a(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+__device__ __forceinline__ void mfma16_a(f32x4& acc, const frag16& a, const bf16x8& b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
 }
 // fp32 rows (F32): v_mfma_f32_16x16x4_f32, one float of the corpus chunk x one float of the query chunk per instruction
@@ -73,14 +75,31 @@ __device__ __forceinline__ void mfma16f_a_first(f32x4& acc, float a, float b) {
 // A-fragment read with a fixed place in the instruction stream (asm volatile statements keep their order among themselves):
 // the compiler does not know the result is asynchronous - every consumer sits behind an explicit s_waitcnt lgkmcnt below.
 template <int OFF>
-__device__ __forceinline__ void lds_read16(bf16x8& dst, unsigned addr) {
+__device__ __forceinline__ void lds_read16(frag16& dst, unsigned addr) {
     static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+// LDS-DMA piece with a wave-uniform base in SGPRs, a 32-bit per-lane offset and an immediate: no vector arithmetic per
+// piece.  The immediate is added to the global AND to the LDS address (LDS address = M0 + immediate + 16 * lane), so the
+// caller passes lds_dst - IMM.
+#ifndef TS16_DMA_IMM_LDS
+#define TS16_DMA_IMM_LDS 1
+#endif
+template <int IMM>
+__device__ __forceinline__ void lds_dma16s(unsigned voff, const void* sbase, unsigned lds_dst) {
+    static_assert(IMM >= 0 && IMM < 4096, "13-bit signed immediate");
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %1 offset:%3" TS_DMA_POLICY
+        :
+        : "v"(voff), "s"(sbase), "s"(lds_dst), "n"(IMM)
+        : "memory");
 }
 // Every outstanding fragment read has landed; names the whole ring, so that no copy of a ring register the compiler may
 // need where control flow merges (end of a tile, steady / general branch) is placed above it.
 template <int N>
-__device__ __forceinline__ void lds_ring_landed(bf16x8 (&af)[N]) {
+__device__ __forceinline__ void lds_ring_landed(frag16 (&af)[N]) {
     static_assert(N == 6 || N == 8, "ring of 3 or 4 k-steps, two row blocks");
     if constexpr (N == 6)
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]));
@@ -293,7 +312,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     asm volatile("" ::: "memory");
 
     // A-fragment ring: af[2 (s % kA) + rb]; k-steps 0 .. kA - 2 of the first unit are fetched here
-    bf16x8 af[2 * kA] = {};
+    frag16 af[2 * kA] = {};
     {
         const unsigned p0 = lds_base + xo[0], p1 = lds_base + xo[1];
         lds_read16<0>(af[0], p0);
@@ -360,9 +379,11 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     do {                                                                                                   \
         if constexpr ((S_) % kPieceEvery == kPieceEvery - 1)                                               \
             if (do_issue) {                                                                                \
+                constexpr int j_ = (S_) / kPieceEvery;                                                     \
                 unsigned long long d0_ = 0;                                                                \
                 if (VARIANT == 5) d0_ = cycle_stamp();                                                     \
-                lds_dma16(isrc + ((S_) / kPieceEvery) * 128, idst + ((S_) / kPieceEvery) * 4096);          \
+                if constexpr (steady_) lds_dma16s<j_ * 128>(dma_voff, ssrc, idst + j_ * (4096 - 128 * TS16_DMA_IMM_LDS)); \
+                else lds_dma16(isrc + j_ * 128, idst + j_ * 4096);                                         \
                 if (VARIANT == 5) t_dma += cycle_stamp() - d0_;                                            \
             }                                                                                              \
     } while (0)
@@ -421,12 +442,14 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         asm volatile("" ::: "memory");                                                                     \
         if (VARIANT == 6) __builtin_amdgcn_s_sleep(4);                                                     \
         constexpr bool do_issue = !kNoDma;                                                                 \
-        const unsigned char* isrc = tile_src + cui_ * (kUnitK * 2);                                        \
+        constexpr bool steady_ = true;                                                                     \
+        const unsigned char* isrc = nullptr;                                                               \
+        const unsigned char* ssrc = s_tile + cui_ * (kUnitK * 2);       /* wave-uniform: SGPRs */           \
         const unsigned idst = lds0 + poff;                                                                 \
         TS16_STEP(UI, 0); TS16_STEP(UI, 1); TS16_STEP(UI, 2); TS16_STEP(UI, 3);                            \
         TS16_STEP(UI, 4); TS16_STEP(UI, 5); TS16_STEP(UI, 6); TS16_STEP(UI, 7);                            \
         if constexpr (kUnitSteps > 8) { TS16_STEP(UI, 8 % kUnitSteps); TS16_STEP(UI, 9 % kUnitSteps); TS16_STEP(UI, 10 % kUnitSteps); TS16_STEP(UI, 11 % kUnitSteps); } \
-        if constexpr (cui_ == kUnits - 1 && !kNoDma) tile_src += steady_jump;                              \
+        if constexpr (cui_ == kUnits - 1 && !kNoDma) s_tile += steady_jump;                                \
         poff = soff;                                                                                       \
         soff = noff;                                                                                       \
     } while (0)
@@ -447,7 +470,9 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         if (VARIANT == 5) { t_vm += s1_ - s0_; t_bar += cycle_stamp() - s1_; }                             \
         if (VARIANT == 6) __builtin_amdgcn_s_sleep(4);   /* ~256 idle cycles per unit: elasticity of time to cycles */ \
         const bool do_issue = issue_u < nu && !kNoDma;                                                     \
+        constexpr bool steady_ = false;                                                                    \
         const unsigned char* isrc = tile_src + issue_ui * (kUnitK * 2);                                    \
+        const unsigned char* ssrc = nullptr;                                                               \
         const unsigned idst = lds0 + issue_slot * kUnitBytes;                                              \
         TS16_STEP(UI, 0); TS16_STEP(UI, 1); TS16_STEP(UI, 2); TS16_STEP(UI, 3);                            \
         TS16_STEP(UI, 4); TS16_STEP(UI, 5); TS16_STEP(UI, 6); TS16_STEP(UI, 7);                            \
@@ -464,6 +489,10 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     const int nt_steady = (a.run == 1 && ahead == kSlots - 1 && VARIANT != 5 && nu > ahead) ? (nu - ahead) / kUnits : 0;
     const int64_t steady_jump = tile_bytes * a.tile_stride;
     unsigned soff = 0, poff = (unsigned)(kSlots - 1) * kUnitBytes;
+    // the steady part addresses the stream as (uniform tile base in SGPRs) + (this lane's offset inside a tile); the
+    // prologue has issued `ahead` units: the next one lies in visited tile t0 + ahead / kUnits
+    const unsigned dma_voff = (unsigned)(drow * (Deq * 2) + dchunk * 16);
+    const unsigned char* s_tile = (const unsigned char*)a.corpus + (t0 + ahead / kUnits) * steady_jump;
     for (int t = 0; t < nt; ++t) {
         if (t < nt_steady) {
             TS16_UNIT_S(0);
@@ -487,6 +516,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
                 issue_ui = issue_u % kUnits;
                 issue_slot = issue_u % kSlots;
                 issue_run_pos = 0;
+                tile_src = s_tile + dma_voff;
             }
         } else {
             TS16_UNIT(0);
