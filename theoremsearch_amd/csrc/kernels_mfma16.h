@@ -23,6 +23,12 @@
 // The LDS image, the DMA ring, its counted waits and the barrier protocol are those of kernels_mfma.h (the 16-row
 // operand read of this shape is conflict-free on the same swizzled image: lane (r, q) reads chunk 4 (s & 1) + q of row r).
 //
+// Instruction stream of a k-step (measured): a 16x16x32 MFMA holds the SIMD's vector issue for 8
+// of its 16 cycles, so fillers hide two per MFMA gap and not in a cluster.  The fragment reads are asm statements with
+// fixed places between the MFMAs, behind explicit lgkmcnt waits (tools/audit_ring.py checks the compiled ISA); the
+// steady part of the tile loop has no branches, an immediate vmcnt wait and DMA pieces addressed by a scalar base + a
+// lane offset + an immediate.  2,419 -> 1,865 cycles per unit of 96 MFMAs per wave (1,536 MFMA cycles).
+//
 // Algorithmic traffic: rows * 2 d bytes per launch; flops 2 * queries * rows * d.
 #pragma once
 #include "kernels_mfma.h"
@@ -44,8 +50,8 @@ constexpr int kMfma16StageCap = 192;                                 // entries 
 constexpr int kMfma16StageBytes = 4 * kMfma16StageCap * 16 + 16;     // + one counter per wave
 
 // MFMA statements with pinned register classes: accumulator and corpus fragment in VGPRs, query fragment in a VGPR
-// ("v" forms) or an AGPR ("a" forms) quadruple.  No pads inside: the A fragment comes straight from a ds_read (the
-// compiler's lgkmcnt wait covers it), the query fragments are written once before the loop, accumulators chain
+// ("v" forms) or an AGPR ("a" forms) quadruple.  No pads inside: the A fragment comes from a ds_read behind the k-step's
+// explicit lgkmcnt wait (lds_read16 below), the query fragments are written once before the loop, accumulators chain
 // MFMA -> MFMA; the only non-MFMA reader of an accumulator is the epilogue, behind mfma16_settle().
 __device__ __forceinline__ void mfma16_v_first(f32x4& acc, const frag16& a, const bf16x8& b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
@@ -192,7 +198,8 @@ __device__ __forceinline__ void mfma16_append_block(const f32x4& a0, const f32x4
 // corpus chunk by float i of the matching query chunk, i.e. k = 16 s + 4 (lane >> 4) + i - a fixed permutation of k in the
 // fp32 sum.  The four MFMAs of a chunk go to the accumulators in turn (i-major), so that no accumulator is used twice in a
 // row (16x16x4: 32-cycle issue, 40-cycle dependent latency).  d = 1024: one block of 16 queries per wave (256 registers),
-// 64 queries per launch - the Qwen-sized fp32 tables; d = 768 fp32 has its own kernel (kernels_mfma_f32.h, 128 per launch).
+// 64 queries per launch - the Qwen-sized fp32 tables; d = 768: one or two blocks, 64 or 128 queries per launch (the
+// 32x32x2 kernel of kernels_mfma_f32.h stays selectable: TS_MFMA_F32=32).
 template <int D, int NB, int VARIANT, bool SPARSE, bool F32 = false>
 __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a) {
     constexpr int Deq = F32 ? 2 * D : D;                 // row length in 2-byte elements
