@@ -394,6 +394,31 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
                 if (VARIANT == 5) t_dma += cycle_stamp() - d0_;                                            \
             }                                                                                              \
     } while (0)
+#ifndef TS16_ORDER_A
+#define TS16_BF16_ORDER(KS_, R0_, N_, S_)                                                                  \
+    do {                                                                                                   \
+        TS16_MMA(0, 0, KS_, af[R0_]); TS16_LOAD(0, N_);                                                    \
+        TS16_MMA(1, 0, KS_, af[R0_ + 1]); TS16_LOAD(1, N_);                                                \
+        if constexpr (NB > 1) { TS16_MMA(0, 1, KS_, af[R0_]); TS16_MMA(1, 1, KS_, af[R0_ + 1]); }          \
+        TS16_PIECE(S_);                                                                                    \
+        if constexpr (NB > 2) { TS16_MMA(0, 2, KS_, af[R0_]); TS16_MMA(1, 2, KS_, af[R0_ + 1]); }          \
+        if constexpr (NB > 3) { TS16_MMA(0, 3, KS_, af[R0_]); TS16_MMA(1, 3, KS_, af[R0_ + 1]); }          \
+    } while (0)
+#else   /* A/B build: row-block major - the corpus fragment stays put for NB consecutive MFMAs */
+#define TS16_BF16_ORDER(KS_, R0_, N_, S_)                                                                  \
+    do {                                                                                                   \
+        TS16_MMA(0, 0, KS_, af[R0_]); TS16_LOAD(0, N_);                                                    \
+        if constexpr (NB > 1) { TS16_MMA(0, 1, KS_, af[R0_]); }                                            \
+        TS16_LOAD(1, N_);                                                                                  \
+        if constexpr (NB > 2) { TS16_MMA(0, 2, KS_, af[R0_]); }                                            \
+        if constexpr (NB > 3) { TS16_MMA(0, 3, KS_, af[R0_]); }                                            \
+        TS16_PIECE(S_);                                                                                    \
+        TS16_MMA(1, 0, KS_, af[R0_ + 1]);                                                                  \
+        if constexpr (NB > 1) { TS16_MMA(1, 1, KS_, af[R0_ + 1]); }                                        \
+        if constexpr (NB > 2) { TS16_MMA(1, 2, KS_, af[R0_ + 1]); }                                        \
+        if constexpr (NB > 3) { TS16_MMA(1, 3, KS_, af[R0_ + 1]); }                                        \
+    } while (0)
+#endif
     // One k-step.  The fillers have fixed places between the MFMAs (a 16x16x32 MFMA leaves 8 of its 16 cycles of vector
     // issue free: two simple instructions per gap hide, a cluster behind the last MFMA does not): the wait for this
     // k-step's fragments, MFMA, read, MFMA, read, two MFMAs, the DMA piece when one is due, the remaining MFMAs.
@@ -423,12 +448,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         }                                                                                                  \
         if constexpr (!kNoMma && !F32) {                                                                   \
             /* query-block major (consecutive MFMAs share the query fragment; the epilogue's block order relies on it) */ \
-            TS16_MMA(0, 0, ks_, af[r0_]); TS16_LOAD(0, n_);                                                \
-            TS16_MMA(1, 0, ks_, af[r0_ + 1]); TS16_LOAD(1, n_);                                            \
-            if constexpr (NB > 1) { TS16_MMA(0, 1, ks_, af[r0_]); TS16_MMA(1, 1, ks_, af[r0_ + 1]); }      \
-            TS16_PIECE(S_);                                                                                \
-            if constexpr (NB > 2) { TS16_MMA(0, 2, ks_, af[r0_]); TS16_MMA(1, 2, ks_, af[r0_ + 1]); }      \
-            if constexpr (NB > 3) { TS16_MMA(0, 3, ks_, af[r0_]); TS16_MMA(1, 3, ks_, af[r0_ + 1]); }      \
+            TS16_BF16_ORDER(ks_, r0_, n_, S_);                                                             \
         }                                                                                                  \
         if constexpr (kNoMma) TS16_PIECE(S_);                                                              \
     } while (0)
@@ -543,7 +563,11 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         if constexpr (kNoMma) continue;
         // The last k-step issued its MFMAs in block order, so with NB = 4 the results of block b are at least 6 MFMAs
         // old when its test (5 VALU instructions per block, in order) reads them; fewer blocks need explicit wait states.
+#ifdef TS16_ORDER_A
+        mfma16_settle<NB>(acc);
+#else
         if constexpr (NB < 4 || kNoEpi) mfma16_settle<NB>(acc);
+#endif
         if constexpr (kNoEpi) {
 #pragma unroll
             for (int b = 0; b < NB; ++b) asm volatile("" ::"v"(acc[0][b]), "v"(acc[1][b]));
@@ -579,6 +603,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
 #undef TS16_MMA
 #undef TS16_MMAF
 #undef TS16_LOAD
+#undef TS16_BF16_ORDER
 #undef TS16_PIECE
 #undef TS16_ISSUED
     if (kStaged) {
