@@ -812,14 +812,14 @@ static int run_select_rounds(ts_index* ix, int slots, int m, int k, float* out_s
 }
 
 static int scan_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* out_idx, const int* qlist, const int* qcount,
-                       hipStream_t st) {
+                       hipStream_t st, const float* qbuf = nullptr) {
     const int grid = ix->cu_count * kScanGridPerCU;
     ScanArgs a;
     memset(&a, 0, sizeof(a));
     a.corpus = ix->rows;
     a.ld = ix->ld;
     a.n = ix->n;
-    a.qbuf = ix->qf32;
+    a.qbuf = qbuf ? qbuf : ix->qf32;
     a.qlist = qlist;
     a.qcount = qcount;
     a.nq = nq;
@@ -1321,6 +1321,21 @@ static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_
     for (int q0 = 0; q0 < nq; q0 += block) {
         const int nb = std::min(block, nq - q0);
         const void* qsrc = (const char*)queries + (size_t)q0 * ix->d * q_elem;
+        float* os = dscores + (size_t)q0 * k;
+        int64_t* oi = didx + (size_t)q0 * k;
+        // One fp32 query against an fp32 inner-product index whose rows are not padded (the single query of the apps,
+        // streamlit_app.py:173, app_showcase_model.py:92; configs[1]): nothing to normalise, round or pad - the scan
+        // reads the query where it is (device) or where the copy puts it (host).  No preparation launch.
+        if (use == TS_ALGO_SCAN && nb == 1 && nq == 1 && q_dtype == TS_F32 && ix->dtype == TS_F32 &&
+            ix->metric == TS_METRIC_IP && ix->ld == ix->d) {
+            const float* qb = (const float*)qsrc;
+            if (!q_on_device) {
+                HIP_TRY(hipMemcpyAsync(ix->qf32, qsrc, (size_t)ix->d * 4, hipMemcpyHostToDevice, st));
+                qb = ix->qf32;
+            }
+            TS_TRY(scan_search(ix, 1, k, os, oi, nullptr, nullptr, st, qb));
+            continue;
+        }
         if (!q_on_device) {
             HIP_TRY(hipMemcpyAsync(ix->stage, qsrc, (size_t)nb * ix->d * q_elem, hipMemcpyHostToDevice, st));
             qsrc = ix->stage;
@@ -1328,8 +1343,6 @@ static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_
         // normalise (COS), round to the storage type, zero-pad to 256 rows x ld; fp32 copy for the scan
         TS_TRY(prep_dispatch(q_dtype, ix->dtype, ix->metric == TS_METRIC_COS, qsrc, ix->d, ix->qstore, ix->qf32, ix->ld, ix->d,
                              nb, kQBlock, st));
-        float* os = dscores + (size_t)q0 * k;
-        int64_t* oi = didx + (size_t)q0 * k;
         if (use == TS_ALGO_MFMA) TS_TRY(mfma_search(ix, nb, k, os, oi, st, stats));
         else TS_TRY(scan_search(ix, nb, k, os, oi, nullptr, nullptr, st));
     }
