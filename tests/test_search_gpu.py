@@ -163,6 +163,25 @@ def test_mfma_and_scan_agree_and_levels_run(ts):
         assert (st4["algo"], st5["algo"]) == (1, 2)
 
 
+@pytest.mark.parametrize("knobs", [{"TS_MFMA_AHEAD": 2}, {"TS_MFMA_RUN": 4, "TS_MFMA_STAT": 0}, {"TS_MFMA_GRID": 64},
+                                   {"TS_MFMA_GRID": 200, "TS_MFMA_AHEAD": 1}, {"TS_MFMA_SHAPE": 32, "TS_MFMA_AHEAD": 1}])
+@pytest.mark.parametrize("n,d,nq", [(310_000, 768, 256), (120_000, 1024, 150)])
+def test_general_units_of_the_tile_loop_give_the_same_answer(ts, knobs, n, d, nq):
+    """The tile loop of the 16x16 kernel has a branch-free steady part (default ring depth, single-tile runs) and general
+    units for the rest: a shallower DMA ring, sampled runs of tiles and other grids (tiles per workgroup) drive the
+    general units and the hand-over between the two at other places; the answers may not change."""
+    q, c = oracle.golden_inputs(n, nq, d, 4242 + nq, "ip")
+    with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as ix:
+        s0, i0, st0 = ix.search(q, 10, algo="mfma", return_stats=True)
+        assert st0["fallback_queries"] == 0, st0
+        check(q, c, "ip", "bf16", 10, s0, i0)
+        for k_, v_ in knobs.items():
+            ix.set_option(k_, v_)
+        s1, i1, st1 = ix.search(q, 10, algo="mfma", return_stats=True)
+        assert st1["fallback_queries"] == 0, st1
+        assert np.array_equal(i1, i0) and np.array_equal(s1, s0)
+
+
 def test_mfma_d1024_and_query_blocks(ts):
     # Qwen-sized rows (vector(1024), rds_schema.sql:50-56): 128 queries per launch, so 300 queries = 3 blocks
     q, c = oracle.golden_inputs(50_000, 300, 1024, 33, "ip")

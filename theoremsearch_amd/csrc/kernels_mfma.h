@@ -87,7 +87,7 @@ struct MfmaArgs {
     u32* count;                    // [256]
     int cap;
     const u32* row_mask;           // optional filter: bit (row & 31) of word row >> 5 set = the row may be returned
-    int ahead;                     // units kept in flight by the DMA ring (1 .. kSlots - 1)
+    int ahead;                     // units kept in flight by the DMA ring (2 .. kSlots - 1; anything else = kSlots - 1)
     int nq;                        // real queries of this launch: waves / groups holding only padding skip the matrix work
     unsigned long long* dbg;       // VARIANT 3 only: per-wave cycle sums
     // first level of a search: thresholds are not read but set here (-inf for the nq_real real queries, +inf for padding)
@@ -310,7 +310,9 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma_topk_kernel(MfmaArgs a) 
     } while (0)
 
     // prologue: kSlots - 1 units in flight; unit 0 must have landed before its fragments are read
-    const int ahead = (a.ahead >= 1 && a.ahead < kSlots) ? a.ahead : kSlots - 1;
+    // at least two: the fragment reads at the end of unit u already fetch the head of unit u + 1, which is certified at the
+    // start of unit u only if it was issued a unit earlier
+    const int ahead = (a.ahead >= 2 && a.ahead < kSlots) ? a.ahead : kSlots - 1;
     for (int i = 0; i < ahead && issue_u < nu && !kNoDma; ++i) {
         const unsigned char* src = tile_src + issue_ui * (kUnitK * 2);
 #pragma unroll

@@ -126,7 +126,9 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma_f32_topk_kernel(MfmaArgs
         issue_slot = (issue_slot + 1 == kSlots) ? 0 : issue_slot + 1;                 \
     } while (0)
 
-    const int ahead = (a.ahead >= 1 && a.ahead < kSlots) ? a.ahead : kSlots - 1;
+    // at least two: the fragment reads at the end of unit u already fetch the head of unit u + 1, which is certified at the
+    // start of unit u only if it was issued a unit earlier
+    const int ahead = (a.ahead >= 2 && a.ahead < kSlots) ? a.ahead : kSlots - 1;
     for (int i = 0; i < ahead && issue_u < nu; ++i) {
         const unsigned char* src = tile_src + issue_ui * dims::kUnitRowBytes;
 #pragma unroll
