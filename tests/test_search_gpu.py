@@ -610,8 +610,12 @@ def test_fp32_batches_at_d1024_run_on_the_fp32_mfma_path(ts, n, nq, k, metric):
 def test_small_fp32_batches_stay_on_the_scan(ts):
     q, c = oracle.golden_inputs(50_000, 12, 768, 77, "cos")
     with ts.TheoremIndex.from_embeddings(c, dtype="f32", metric="cos") as ix:
-        _, _, st = ix.search(q, 10, return_stats=True)
+        s4, i4, st = ix.search(q[:4], 10, return_stats=True)          # one scan pass serves four queries
         assert st["algo"] == 1
+        s5, i5, st = ix.search(q[:5], 10, return_stats=True)          # five would need two: the matrix kernel is cheaper
+        assert st["algo"] == 2
+        check(q[:5], c, "cos", "f32", 10, s5, i5)
+        assert np.array_equal(i5[:4], i4)
         ix.set_option("TS_MFMA_F32", 0)
         _, _, st = ix.search(np.tile(q, (3, 1)), 10, return_stats=True)
         assert st["algo"] == 1

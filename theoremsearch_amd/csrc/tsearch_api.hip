@@ -1234,12 +1234,13 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
     return TS_OK;
 }
 
-// Largest batch the streaming scan still serves faster than the MFMA path.  bf16: the MFMA pass is ~1.5x a scan pass of 4
-// queries.  fp32: the exact-fp32 matrix pass is bound by the matrix pipe (~3x a scan pass of 4 queries at 128 queries
-// per launch), so it pays from ~13 queries on.  Large k (4 keys per lane in the scan) moves both down to 1.
+// Largest batch the streaming scan still serves faster than the MFMA path: one scan pass serves 4 queries at the HBM
+// rate, and one launch of the matrix kernels (64 queries or more) costs less than two scan passes on both storage types
+// (1M x 768 fp32, 5-8 queries: 0.99 ms through the scan, 0.74 ms through the 16x16x4 kernel; 10M x 768 bf16: 4.44 against
+// 2.21 ms).  Large k (4 keys per lane in the scan) moves it down to 1.
 static int scan_max_queries(const ts_index* ix, int k) {
     if (k > 64) return 1;
-    return ix->knobs.get(K_SCAN_MAX_QUERIES, ix->dtype == TS_F32 ? 12 : 4);
+    return ix->knobs.get(K_SCAN_MAX_QUERIES, 4);
 }
 
 static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_device, int32_t nq, int32_t k,
