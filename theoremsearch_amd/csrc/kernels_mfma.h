@@ -96,6 +96,10 @@ struct MfmaArgs {
     int nq_real;
     int* fb_count;
     unsigned long long* stat;
+    // full pass of the 16x16 kernel: tile ranges of the workgroups from a table instead of equal shares (part[w] .. part[w+1]),
+    // and the time each workgroup took (100 MHz ticks) - the final select moves the boundaries for the next search
+    const int64_t* part;
+    unsigned* wg_ticks;
 };
 
 __device__ __forceinline__ float mfma_level_thr(const MfmaArgs& a, int qid) {

@@ -239,9 +239,13 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     uint4* stage = (uint4*)(smem + dims::kLds) + wave * kMfma16StageCap;          // this wave's staged candidates
     u32* stage_cnt = (u32*)(smem + dims::kLds + 4 * kMfma16StageCap * 16) + wave;
     if (kStaged && lane == 0) *stage_cnt = 0;
-    const int64_t t0 = (a.ntiles * (int64_t)blockIdx.x) / G;
-    const int nt = (int)((a.ntiles * (int64_t)(blockIdx.x + 1)) / G - t0);
+    // Tile range of this workgroup: equal shares, or the table the previous search's final select left (the XCDs of one
+    // device run this pass at rates 3-4 % apart; the launch ends with its slowest workgroup)
+    const unsigned long long wg_start = (!SPARSE && a.wg_ticks) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const int64_t t0 = (!SPARSE && a.part) ? a.part[blockIdx.x] : (a.ntiles * (int64_t)blockIdx.x) / G;
+    const int nt = (int)(((!SPARSE && a.part) ? a.part[blockIdx.x + 1] : (a.ntiles * (int64_t)(blockIdx.x + 1)) / G) - t0);
     if (nt <= 0) {
+        if (!SPARSE && a.wg_ticks && threadIdx.x == 0) a.wg_ticks[blockIdx.x] = 0;
         if (!kStaged) {
 #pragma unroll
             for (int b = 0; b < NB; ++b) a.pcount[(int64_t)qid[b] * nwriters + writer] = 0;
@@ -620,6 +624,8 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
 #pragma unroll
         for (int b = 0; b < NB; ++b) a.pcount[(int64_t)qid[b] * nwriters + writer] = cnt[b];
     }
+    if (!SPARSE && a.wg_ticks && threadIdx.x == 0)
+        a.wg_ticks[blockIdx.x] = (unsigned)(__builtin_amdgcn_s_memrealtime() - wg_start);
     if (VARIANT == 5 && a.dbg && lane == 0) {
         unsigned long long* d = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 4;
         d[0] = cycle_stamp() - t_all0;

@@ -59,13 +59,13 @@ static int fail(int code, const char* fmt, ...) {
 enum Knob {
     K_MFMA_MIN_RANK, K_MFMA_VARIANT, K_MFMA_GROUPS, K_MFMA_GRID, K_MFMA_STAT, K_MFMA_STAT_CANDS, K_MFMA_TAIL_FIT,
     K_MFMA_NO_IDLE, K_MFMA_AHEAD, K_MFMA_TARGET_CANDS, K_MFMA_FIRST_ROWS, K_MFMA_TARGET_SPARSE, K_MFMA_RUN,
-    K_MFMA_MIN_ROWS, K_MFMA_SHAPE, K_MFMA_F32, K_SCAN_GENERIC, K_SCAN_MAX_QUERIES, K_COUNT
+    K_MFMA_MIN_ROWS, K_MFMA_SHAPE, K_MFMA_F32, K_SCAN_GENERIC, K_SCAN_MAX_QUERIES, K_MFMA_BALANCE, K_COUNT
 };
 static const char* const kKnobNames[K_COUNT] = {
     "TS_MFMA_MIN_RANK", "TS_MFMA_VARIANT", "TS_MFMA_GROUPS", "TS_MFMA_GRID", "TS_MFMA_STAT", "TS_MFMA_STAT_CANDS",
     "TS_MFMA_TAIL_FIT", "TS_MFMA_NO_IDLE", "TS_MFMA_AHEAD", "TS_MFMA_TARGET_CANDS", "TS_MFMA_FIRST_ROWS",
     "TS_MFMA_TARGET_SPARSE", "TS_MFMA_RUN", "TS_MFMA_MIN_ROWS", "TS_MFMA_SHAPE", "TS_MFMA_F32", "TS_SCAN_GENERIC",
-    "TS_SCAN_MAX_QUERIES"};
+    "TS_SCAN_MAX_QUERIES", "TS_MFMA_BALANCE"};
 struct Knobs {
     int v[K_COUNT];
     bool set[K_COUNT];
@@ -117,6 +117,8 @@ struct ts_index {
     Knobs knobs;                                             // env at creation, then ts_index_set_option
     hipStream_t last_stream = nullptr;                       // stream of the previous call that used the scratch buffers
     hipEvent_t order_ev = nullptr;                           // orders a call on another stream behind it
+    int64_t* part = nullptr;    unsigned* wg_ticks = nullptr;    // full pass of the 16x16 kernel: tile boundaries per workgroup, their times
+    int part_g = 0;             int64_t part_ntiles = -1;        // ... the grid and tile count the table was made for
     unsigned long long* dbg = nullptr;                       // TS_MFMA_VARIANT=3: per-wave cycle sums / clock probe
     double probe_ghz = 0.0, probe_cycles_per_unit = 0.0, probe_units = 0.0;   // last clock probe (16x16 shape, VARIANT 3)
     // optional event brackets around the dominant kernel (ts_index_profile_*)
@@ -314,7 +316,7 @@ extern "C" int ts_index_destroy(ts_index* ix) {
     }
     if (ix->attached) ix->rows = nullptr;
     void* ptrs[] = {ix->rows,  ix->stage,   ix->qstore,   ix->qf32,     ix->cand,       ix->count,  ix->thr, ix->priv, ix->pcount, ix->mask_dev, ix->rank_buf, ix->id_map,
-                    ix->fb_list, ix->fb_count, ix->stat, ix->partial, ix->partial2, ix->res_scores, ix->res_idx, ix->dbg};
+                    ix->fb_list, ix->fb_count, ix->stat, ix->partial, ix->partial2, ix->res_scores, ix->res_idx, ix->dbg, ix->part, ix->wg_ticks};
     for (void* p : ptrs)
         if (p) hipFree(p);
     for (hipEvent_t e : ix->ev_pool) hipEventDestroy(e);
@@ -1112,6 +1114,28 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
     const float tail_p = (z_tail > 0.0f && bound_swamps && ix->knobs.get(K_MFMA_TAIL_FIT, 1))
                              ? (float)std::min(0.25, (double)std::max(2048, 8 * kk) / (double)std::max<int64_t>(pop, 1))
                              : 0.0f;
+    // Feedback partition of the full pass (16x16 kernel): the final select moves the workgroups' tile boundaries towards
+    // equal finishing times for the next search (kernels_select.h, rebalance_tiles).  The table starts as equal shares and
+    // is re-made whenever the grid or the number of tiles changes.
+    const int64_t full_tiles = lv.back().ntiles;
+    const bool balance = shape16 && ix->knobs.get(K_MFMA_BALANCE, 1) != 0 && grid >= 8 && grid <= kLevelThreads && lv.back().stride == 1 &&
+                         lv.back().run == 1 && full_tiles >= 32 * (int64_t)grid && (variant == 0 || variant == 3);
+    if (balance && (ix->part_g != grid || ix->part_ntiles != full_tiles)) {
+        if (ix->part_g != grid) {
+            if (ix->part) HIP_TRY(hipFree(ix->part));
+            if (ix->wg_ticks) HIP_TRY(hipFree(ix->wg_ticks));
+            ix->part = nullptr; ix->wg_ticks = nullptr; ix->part_g = 0; ix->part_ntiles = -1;
+            HIP_TRY(hipMalloc((void**)&ix->part, (size_t)(grid + 1) * 8));
+            HIP_TRY(hipMalloc((void**)&ix->wg_ticks, (size_t)grid * 4));
+            ix->part_g = grid;
+        }
+        std::vector<int64_t> equal((size_t)grid + 1);
+        for (int w = 0; w <= grid; ++w) equal[w] = full_tiles * (int64_t)w / grid;
+        HIP_TRY(hipMemcpyAsync(ix->part, equal.data(), equal.size() * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(ix->wg_ticks, 0, (size_t)grid * 4, st));
+        HIP_TRY(hipStreamSynchronize(st));          // `equal` is a local; this happens once per (grid, size)
+        ix->part_ntiles = full_tiles;
+    }
     for (size_t i = 0; i < lv.size(); ++i) {
         const bool full_pass = (i + 1 == lv.size());
         MfmaArgs a;
@@ -1134,6 +1158,8 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         a.nq_real = nq;
         a.fb_count = ix->fb_count;
         a.stat = ix->stat;
+        a.part = (balance && full_pass) ? ix->part : nullptr;
+        a.wg_ticks = (balance && full_pass) ? ix->wg_ticks : nullptr;
         a.dbg = nullptr;
         if (variant >= 3) {
             if (!ix->dbg) HIP_TRY(hipMalloc((void**)&ix->dbg, 2048 * 4 * 4 * 8));
@@ -1224,8 +1250,13 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         l.fb_list = ix->fb_list;
         l.fb_count = ix->fb_count;
         l.stat_candidates = ix->stat;
-        if (kk <= 64) level_select_kernel<1><<<nq, kLevelThreads, kLevelLds, st>>>(l);
-        else level_select_kernel<4><<<nq, kLevelThreads, kLevelLds, st>>>(l);
+        const bool move = balance && full_pass;      // one more workgroup: it moves the boundaries for the next search
+        l.part = move ? ix->part : nullptr;
+        l.wg_ticks = ix->wg_ticks;
+        l.part_g = grid;
+        l.nq = nq;
+        if (kk <= 64) level_select_kernel<1><<<nq + (move ? 1 : 0), kLevelThreads, kLevelLds, st>>>(l);
+        else level_select_kernel<4><<<nq + (move ? 1 : 0), kLevelThreads, kLevelLds, st>>>(l);
         HIP_TRY(hipGetLastError());
     }
     // exact fall-back for queries that lost candidates (device-side count; no-op when 0)
