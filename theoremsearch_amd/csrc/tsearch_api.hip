@@ -1203,6 +1203,23 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
                 ix->probe_ghz = ghz[ghz.size() / 2];
                 ix->probe_cycles_per_unit = cpu_[cpu_.size() / 2];
                 ix->probe_units = (double)h[2];
+                if (getenv("TS_PROBE_SPREAD")) {
+                    // the launch ends with its slowest workgroup: time inside the tile loop per workgroup (100 MHz ticks),
+                    // and its mean by workgroup id % 8 (the XCD under round-robin dispatch)
+                    std::vector<double> us;
+                    double xm[8] = {0}, xn[8] = {0};
+                    for (int w = 0; w < grid; ++w)
+                        if (h[w * 4 + 1] > 0) {
+                            us.push_back((double)h[w * 4 + 1] * 0.01);
+                            xm[w & 7] += us.back();
+                            xn[w & 7] += 1;
+                        }
+                    std::sort(us.begin(), us.end());
+                    fprintf(stderr, "[tsearch probe] tile loop per workgroup: min %.1f us, median %.1f, max %.1f; mean by id %% 8:", us.front(),
+                            us[us.size() / 2], us.back());
+                    for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f", xm[x] / std::max(1.0, xn[x]));
+                    fprintf(stderr, "\n");
+                }
             }
         } else if (a.dbg && full_pass && shape16 && variant == 5) {
             std::vector<unsigned long long> h((size_t)grid * 16);
