@@ -97,6 +97,7 @@ struct LevelArgs {
     const unsigned* wg_ticks;             // [part_g] time of each workgroup in the pass just finished (100 MHz ticks)
     int part_g;
     int nq;
+    float part_gain;                      // share of the measured imbalance corrected per search
 };
 
 constexpr int kLevelSortMax = 8192;
@@ -285,7 +286,7 @@ __device__ __forceinline__ void rebalance_tiles(const LevelArgs& a, double* tmp)
         if (tx[8 + x] > 0.0) { T += tx[x] / tx[8 + x]; ++nx; }
     T /= (double)(nx > 0 ? nx : 1);
     if (w < G) {
-        double f = 1.0 + 0.7 * (T / (tx[w & 7] / tx[8 + (w & 7)]) - 1.0);
+        double f = 1.0 + (double)a.part_gain * (T / (tx[w & 7] / tx[8 + (w & 7)]) - 1.0);
         f = f < 0.9 ? 0.9 : (f > 1.1 ? 1.1 : f);
         const double floor_share = (double)ntiles / (4.0 * G);
         share *= f;

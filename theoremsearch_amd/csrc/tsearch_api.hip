@@ -1272,6 +1272,10 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         l.wg_ticks = ix->wg_ticks;
         l.part_g = grid;
         l.nq = nq;
+        {   // TS_MFMA_BALANCE = n > 1: gain n / 10 (default 0.7)
+            const int b = ix->knobs.get(K_MFMA_BALANCE, 1);
+            l.part_gain = (b >= 2 && b <= 10) ? 0.1f * (float)b : 0.7f;
+        }
         if (kk <= 64) level_select_kernel<1><<<nq + (move ? 1 : 0), kLevelThreads, kLevelLds, st>>>(l);
         else level_select_kernel<4><<<nq + (move ? 1 : 0), kLevelThreads, kLevelLds, st>>>(l);
         HIP_TRY(hipGetLastError());
