@@ -251,3 +251,26 @@ def test_sharded_searcher_device_pipeline_with_changing_queries(ts):
         got[-1][2].synchronize()
         assert np.array_equal(got[-1][1].cpu().numpy(), want[-1][1])
         searcher.close()
+
+
+def test_answers_do_not_move_with_the_tile_shares_of_the_full_pass(ts):
+    """The full pass takes each workgroup's tile range from a table that the final select moves after every search
+    (towards equal finishing times of the XCDs).  Same queries, ten searches in a row: the table moves, the answers may
+    not; an append changes the number of tiles and the table starts again from equal shares."""
+    q, c = oracle.golden_inputs(400_000, 200, 768, 909, "ip")
+    with ts.TheoremIndex(300_000, 768, dtype="bf16", metric="ip") as ix:
+        ix.upload(c[:300_000], 0)
+        s0, i0, st = ix.search(q, 10, algo="mfma", return_stats=True)
+        assert st["fallback_queries"] == 0
+        check(q, c[:300_000], "ip", "bf16", 10, s0, i0)
+        for _ in range(9):
+            s, i = ix.search(q, 10, algo="mfma")
+            assert np.array_equal(i, i0) and np.array_equal(s, s0)
+        ix.set_option("TS_MFMA_BALANCE", 0)                 # equal shares: the same answers
+        s, i = ix.search(q, 10, algo="mfma")
+        assert np.array_equal(i, i0) and np.array_equal(s, s0)
+        ix.set_option("TS_MFMA_BALANCE", None)
+        assert ix.append(c[300_000:]) == 300_000
+        for _ in range(3):
+            s1, i1 = ix.search(q, 10, algo="mfma")
+            check(q, c, "ip", "bf16", 10, s1, i1)
