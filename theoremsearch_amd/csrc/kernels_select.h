@@ -430,6 +430,7 @@ constexpr int kHistSelectMax = 12288;   // 96 KiB of keys: with the short list, 
 constexpr int kHistSelectLds = kHistSelectMax * 8 + kLevelSmall * 8 + (kLevelThreads / 64) * TS_MAX_K_INTERNAL * 8 + kLevelBins * 4 + 64;
 static_assert(kHistSelectLds <= 160 * 1024 && kLevelLds <= 160 * 1024, "select kernels must fit the CU's LDS");
 
+template <int KR>   // 1: k <= 64, 4: k <= 256 (as level_select_kernel)
 __global__ void __launch_bounds__(kLevelThreads) select_hist_kernel(SelectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* keys = (u64*)smem;
@@ -460,7 +461,7 @@ __global__ void __launch_bounds__(kLevelThreads) select_hist_kernel(SelectArgs a
     __syncthreads();
     const int cnt = (int)ctr[0];
     double mean, sd;
-    u64* best = lds_select_top<1>(keys, cnt, a.k_user, small, wlists, hist, ctr, false, mean, sd);
+    u64* best = lds_select_top<KR>(keys, cnt, a.k_user, small, wlists, hist, ctr, false, mean, sd);
     const int qid = a.qlist ? a.qlist[slot] : slot;
     for (int i = threadIdx.x; i < a.k_user; i += blockDim.x) {
         const u64 key = best[i];

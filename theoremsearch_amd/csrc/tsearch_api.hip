@@ -754,30 +754,33 @@ static int run_select_rounds(ts_index* ix, int slots, int m, int k, float* out_s
     u64* scratch[2] = {ix->partial2, ix->partial};
     int which = 0;
     int64_t in_stride = m;
-    if (m > 1024 && m <= kHistSelectMax && k <= 64) {
-        // the usual case (k <= 12 over 1024 workgroups): one launch, histogram cut instead of two rounds of bitonic sorts
-        if (!ix->attr_done_hist) {
-            HIP_TRY(hipFuncSetAttribute((const void*)select_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kHistSelectLds));
-            ix->attr_done_hist = true;
-        }
-        SelectArgs a;
-        memset(&a, 0, sizeof(a));
-        a.in = in;
-        a.in_stride = in_stride;
-        a.m = m;
-        a.kout = k;
-        a.k_user = k;
-        a.row_offset = ix->row_offset;
-        a.id_map = ix->id_map;
-        a.qlist = qlist;
-        a.qcount = qcount;
-        a.out_scores = out_scores;
-        a.out_idx = out_idx;
-        select_hist_kernel<<<slots, kLevelThreads, kHistSelectLds, st>>>(a);
-        HIP_TRY(hipGetLastError());
-        return TS_OK;
-    }
     for (;;) {
+        if (m > 1024 && m <= kHistSelectMax) {
+            // the usual case (k <= 12 over 1024 workgroups, or k up to 256 over the fewer workgroups scan_search uses on a
+            // small corpus): one launch, histogram cut instead of rounds of bitonic sorts
+            if (!ix->attr_done_hist) {
+                HIP_TRY(hipFuncSetAttribute((const void*)select_hist_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistSelectLds));
+                HIP_TRY(hipFuncSetAttribute((const void*)select_hist_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistSelectLds));
+                ix->attr_done_hist = true;
+            }
+            SelectArgs a;
+            memset(&a, 0, sizeof(a));
+            a.in = in;
+            a.in_stride = in_stride;
+            a.m = m;
+            a.kout = k;
+            a.k_user = k;
+            a.row_offset = ix->row_offset;
+            a.id_map = ix->id_map;
+            a.qlist = qlist;
+            a.qcount = qcount;
+            a.out_scores = out_scores;
+            a.out_idx = out_idx;
+            if (k <= 64) select_hist_kernel<1><<<slots, kLevelThreads, kHistSelectLds, st>>>(a);
+            else select_hist_kernel<4><<<slots, kLevelThreads, kHistSelectLds, st>>>(a);
+            HIP_TRY(hipGetLastError());
+            return TS_OK;
+        }
         SelectArgs a;
         memset(&a, 0, sizeof(a));
         a.in = in;
@@ -815,7 +818,11 @@ static int run_select_rounds(ts_index* ix, int slots, int m, int k, float* out_s
 
 static int scan_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* out_idx, const int* qlist, const int* qcount,
                        hipStream_t st, const float* qbuf = nullptr) {
-    const int grid = ix->cu_count * kScanGridPerCU;
+    int grid = ix->cu_count * kScanGridPerCU;
+    // Large k over a small corpus (app_showcase_model.py:96: topk(200) over a few thousand theorems): every workgroup
+    // hands k keys to the select, and 1,024 x 200 of them cost three rounds of sorts (150 us) for a scan of 10 us.  Few
+    // enough workgroups that ONE histogram select takes all their keys.
+    if (k > 64 && ix->n <= 16384) grid = std::min(grid, std::max(8, kHistSelectMax / k));
     ScanArgs a;
     memset(&a, 0, sizeof(a));
     a.corpus = ix->rows;
