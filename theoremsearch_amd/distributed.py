@@ -116,15 +116,26 @@ class ShardedSearcher:
         return cls(group=group, index=ix, exchange=exchange)
 
     def _init_native_comm(self) -> None:
-        """ts_comm_create on every rank; torch.distributed only carries the unique id (start-up, not the search path)."""
+        """ts_comm_create on every rank; torch.distributed only carries the unique id (start-up, not the search path).
+        No rank may skip a collective another rank is waiting in: whether RCCL loads at all is settled first (every rank
+        asks for a unique id - no communication - and the outcomes are all-reduced), only then does rank 0's id travel."""
+        import torch
         from . import _ffi
         _ffi.prefer_torch_rccl()
         lib = _ffi.load()
-        ident = [None]
-        if self.rank == 0:
+        mine, err = None, None
+        try:
             buf = C.create_string_buffer(128)
             _ffi.check(lib.ts_comm_unique_id(buf, 128))
-            ident[0] = bytes(buf.raw)
+            mine = bytes(buf.raw)
+        except Exception as e:                     # noqa: BLE001 - reported below, after every rank has been heard
+            err = e
+        dev = torch.device("cuda", self.index.device) if self.backend == "nccl" else "cpu"
+        flag = torch.tensor([0 if mine is None else 1], device=dev)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) == 0:
+            raise RuntimeError(f"RCCL is not usable on every rank (this rank: {err or 'ok'})")
+        ident = [mine if self.rank == 0 else None]
         self.dist.broadcast_object_list(ident, src=self.dist.get_global_rank(self.group, 0) if self.group else 0,
                                         group=self.group)
         _ffi.check(lib.ts_comm_create(self.index.device, self.world, self.rank, ident[0], 128, C.byref(self._comm)))
