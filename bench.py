@@ -74,6 +74,11 @@ def main():
                          "through host memory (timings meaningless)")
     ap.add_argument("--mask-frac", type=float, default=0.0,
                     help="diagnostic: filtered search with this fraction of rows allowed (device bitmask)")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="searches in flight: the timed loop alternates this many handles on the same rows (the index and "
+                         "views of it, ts_index_view), each on its own stream, so that the small kernels at the head of "
+                         "step i + 1 overlap the tail of step i (independent batches back to back, streamlit_app.py:165-173); "
+                         "1 = one handle, one stream")
     ap.add_argument("--zero-queries", action="store_true", help="diagnostic: all-zero queries (power probe)")
     ap.add_argument("--zero-corpus", action="store_true", help="diagnostic: all-zero corpus (power probe)")
     args = ap.parse_args()
@@ -154,16 +159,23 @@ def main():
     # The timed loop runs on an explicit stream (never on the default stream: the library's stream argument 0 means "the
     # index's own stream").  With N > 1 the step is ShardedSearcher.search_device: local search on `main`, ONE all-gather
     # of the packed per-shard top-k + the merge on a side stream, overlapping the next step's search.
+    P = max(1, args.pipeline)
     main = torch.cuda.Stream()
     q_dev = torch.from_numpy(q_host.view(np.int16) if bf16 else q_host).cuda()
     idx_off = (nq * K * 4 + 7) // 8 * 8
     blk = idx_off + nq * K * 8
-    res = [torch.empty(blk, dtype=torch.uint8, device="cuda") for _ in range(2)]   # N = 1: results of step parity b
+    nres = max(2, P)
+    res = [torch.empty(blk, dtype=torch.uint8, device="cuda") for _ in range(nres)]   # N = 1: results of step i in res[i % nres]
     use_dist = world > 1 or args.force_dist
     searcher = None
+    handles, lanes = [ix], [main]
     if use_dist:
         from theoremsearch_amd.distributed import ShardedSearcher
-        searcher = ShardedSearcher(index=ix, exchange=("torch" if args.share_gpu else args.exchange))
+        searcher = ShardedSearcher(index=ix, exchange=("torch" if args.share_gpu else args.exchange), pipeline=P)
+    else:
+        for _ in range(P - 1):                     # N = 1: the loop itself alternates the handles
+            handles.append(ix.view())
+            lanes.append(torch.cuda.Stream())
         log(rank, f"sharded search: exchange = {searcher.exchange}" + (" (RCCL inside libtsearch)" if searcher.exchange == "native" else f" (torch.distributed, backend {searcher.backend})"))
     encoder = None
     if args.workload == "c5":
@@ -195,19 +207,21 @@ def main():
     def step():
         i = step_no[0]
         step_no[0] += 1
-        b = i & 1
-        with torch.cuda.stream(main):
+        b = i % nres
+        lane = lanes[i % len(lanes)]
+        with torch.cuda.stream(lane):
             if encoder is not None:
-                emb = encode_queries()                        # on `main`: the search below is stream-ordered behind it
-                emb.record_stream(main)
+                emb = encode_queries()                        # on this step's stream: the search below is ordered behind it
+                emb.record_stream(lane)
                 qp, qd = emb.data_ptr(), "f32"
             else:
                 qp, qd = q_dev.data_ptr(), dtype
             if searcher is not None:
-                last_out[0] = searcher.search_device(qp, qd, nq, K, stream=main, algo=args.algo, mask_ptr=mask_ptr)
+                last_out[0] = searcher.search_device(qp, qd, nq, K, stream=lane, algo=args.algo, mask_ptr=mask_ptr)
             else:
                 base = res[b].data_ptr()
-                ix.search_device(qp, qd, nq, K, base, base + idx_off, main.cuda_stream, algo=args.algo, mask_ptr=mask_ptr)
+                handles[i % len(handles)].search_device(qp, qd, nq, K, base, base + idx_off, lane.cuda_stream, algo=args.algo,
+                                                        mask_ptr=mask_ptr)
                 last_out[0] = b
 
     def barrier():
@@ -218,15 +232,24 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ix.profile_enable(True)
+    if searcher is not None and P > 1:
+        searcher._lane(main)                       # the handles exist before profiling is switched on
+    prof_handles = handles if searcher is None else [h for h, _ in (searcher._lanes or [(ix, None)])]
+    for h in prof_handles:
+        h.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    prof = ix.profile_read()
-    ix.profile_enable(False)
+    prof = {"launches": 0, "total_ms": 0.0, "rows_per_launch": 0}
+    for h in prof_handles:
+        p_ = h.profile_read()
+        h.profile_enable(False)
+        prof["launches"] += p_["launches"]
+        prof["total_ms"] += p_["total_ms"]
+        prof["rows_per_launch"] = max(prof["rows_per_launch"], p_["rows_per_launch"])
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -359,7 +382,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"{rows_total}x{D} {dtype} corpus, batch-{nq} queries, top-{K} "
                                    f"(BASELINE.json configs[{ {'c2': 1, 'c2b': 1, 'c3': 2, 'c4': 3, 'c5': 4}[args.workload] }])" + (f", encoder forward in the loop ({args.seq_len} tokens/query, random-init BERT-base shape)" if encoder is not None else ""),
-                       "rows": rows_total, "dim": D, "batch": nq, "k": K,
+                       "rows": rows_total, "dim": D, "batch": nq, "k": K, "searches_in_flight": P,
                        **({"mask_frac": args.mask_frac} if args.mask_frac > 0 else {}),
                        "parallelism": f"corpus row-sharded x{world}" + ((", gloo rehearsal on one GPU" if args.share_gpu else (", ncclAllGather of per-shard top-k inside libtsearch (ts_comm)" if searcher.exchange == "native" else ", torch.distributed all-gather of per-shard top-k (RCCL)")) if use_dist else "")},
             "recall_at_10": recall,
@@ -372,6 +395,8 @@ def main():
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if searcher is not None:
         searcher.close()
+    for h in handles[1:]:
+        h.close()                                  # views go before the index they view
     if world > 1 or args.force_dist:
         dist.destroy_process_group()
 

@@ -274,3 +274,81 @@ def test_answers_do_not_move_with_the_tile_shares_of_the_full_pass(ts):
         for _ in range(3):
             s1, i1 = ix.search(q, 10, algo="mfma")
             check(q, c, "ip", "bf16", 10, s1, i1)
+
+
+# ---- round 3: queries read in place, the one-launch exact re-run, order of calls across streams ---------------------
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_device_queries_in_the_storage_form_are_read_in_place(ts, dtype):
+    """Device queries that already are what the matrix kernels multiply (storage dtype, inner-product index, a whole
+    launch's worth of rows) skip the preparation launch: same answers, bit for bit, as the prepared path - including a
+    query whose candidates overflow and that the exact re-run (one launch: the last workgroup reduces the partial lists)
+    has to serve from the caller's own matrix."""
+    import torch
+    rng = np.random.default_rng(31)
+    n, d, k = 60_000, 768, 10
+    c = rng.standard_normal((n, d), dtype=np.float32) * np.float32(0.05)
+    hot = rng.standard_normal(d).astype(np.float32) * np.float32(0.05)
+    rows = rng.choice(n, size=20_000, replace=False)
+    c[rows] = hot                                            # query 0 = the hot row: 20,000 ties, candidate overflow
+    for nq in (64, 128, 256):
+        q = rng.standard_normal((nq, d), dtype=np.float32) * np.float32(0.05)
+        q[0] = hot
+        q_store = oracle.f32_to_bf16_bits(q) if dtype == "bf16" else q
+        with ts.TheoremIndex.from_embeddings(c, dtype=dtype, metric="ip") as ix:
+            qh = oracle.bf16_bits_to_f32(q_store) if dtype == "bf16" else q
+            want_s, want_i, st = ix.search(qh, k, algo="mfma", return_stats=True)      # host queries: prepared path
+            assert st["fallback_queries"] >= 1
+            qd = torch.from_numpy(q_store.view(np.int16) if dtype == "bf16" else q_store).cuda()
+            out_s = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+            out_i = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            for _ in range(2):                               # twice: the re-run's ticket counter must be left at zero
+                out_i.fill_(-7)
+                torch.cuda.synchronize()
+                ix.search_device(qd.data_ptr(), dtype, nq, k, out_s.data_ptr(), out_i.data_ptr(), 0, algo="mfma")
+                ix.synchronize()
+                assert np.array_equal(out_i.cpu().numpy(), want_i) and np.array_equal(out_s.cpu().numpy(), want_s), (dtype, nq)
+            assert want_i[0].tolist() == sorted(rows.tolist())[:k]
+            check(qh, c, "ip", dtype, k, want_s, want_i)
+
+
+def test_exact_rerun_with_large_k_and_many_queries(ts):
+    """The one-launch re-run with four keys per lane (k > 64) and more failing queries than one scan pass serves."""
+    rng = np.random.default_rng(32)
+    n, d, k = 50_000, 768, 100
+    c = rng.standard_normal((n, d), dtype=np.float32) * np.float32(0.05)
+    hots = rng.standard_normal((6, d)).astype(np.float32) * np.float32(0.05)
+    for j in range(6):
+        c[j * 8000:(j + 1) * 8000 - 500] = hots[j]           # six piles of equal rows: six queries overflow
+    q = np.concatenate([hots, rng.standard_normal((10, d), dtype=np.float32) * np.float32(0.05)])
+    with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as ix:
+        s, i, st = ix.search(q, k, algo="mfma", return_stats=True)
+        assert st["fallback_queries"] >= 6
+        check(q, c, "ip", "bf16", k, s, i)
+        s2, i2 = ix.search(q, k, algo="scan")
+        assert np.array_equal(i[:6], i2[:6])
+
+
+def test_a_callers_stream_may_be_destroyed_after_its_own_sync(ts):
+    """the library must not touch a caller's stream after the call that was given it has returned - the next
+    call (on another stream), ts_index_synchronize and ts_index_destroy only use the order event."""
+    import torch
+    q, c = oracle.golden_inputs(50_000, 64, 768, 41, "ip")
+    qd = torch.from_numpy(q).cuda()
+    with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as ix:
+        want_s, want_i = ix.search(q, 10)
+        out_s = torch.empty((64, 10), dtype=torch.float32, device="cuda")
+        out_i = torch.empty((64, 10), dtype=torch.int64, device="cuda")
+        for _ in range(3):
+            st = torch.cuda.Stream()
+            ix.search_device(qd.data_ptr(), "f32", 64, 10, out_s.data_ptr(), out_i.data_ptr(), st.cuda_stream)
+            st.synchronize()
+            del st                                           # the handle may be recycled by the next Stream()
+            s2, i2 = ix.search(q, 10)                        # own stream: ordered behind the event, not the dead stream
+            assert np.array_equal(i2, want_i) and np.array_equal(out_i.cpu().numpy(), want_i)
+        st = torch.cuda.Stream()
+        ix.search_device(qd.data_ptr(), "f32", 64, 10, out_s.data_ptr(), out_i.data_ptr(), st.cuda_stream)
+        st.synchronize()
+        del st
+        ix.synchronize()
+        assert np.array_equal(out_s.cpu().numpy(), want_s)

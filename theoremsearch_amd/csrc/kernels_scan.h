@@ -19,7 +19,8 @@ struct ScanArgs {
     const void* corpus;   // [n_pad x ld] storage dtype
     int64_t ld;           // elements per row (multiple of 64)
     int64_t n;            // real rows
-    const float* qbuf;    // prepared queries, fp32 [* x ld]
+    const float* qbuf;    // prepared queries, fp32 [* x ld]; NULL = read qb16 instead
+    const unsigned short* qb16;  // the same queries as bf16 bits [* x ld] (the caller's own matrix, used in place)
     const int* qlist;     // optional indirection: query ids to run (fallback list); NULL = 0..nq-1
     const int* qcount;    // optional device count of entries in qlist; NULL = nq
     int nq;
@@ -27,7 +28,18 @@ struct ScanArgs {
     u64* partial;         // [slot][gridDim.x][k] keys, descending
     float* scores;        // EMIT: [nq x n]
     const u32* row_mask;  // optional filter: bit (row & 31) of word row >> 5 set = the row may be returned
+    // one-launch form (the exact re-run of the MFMA path): the workgroup that finishes last reduces the partial lists
+    // and writes the results, instead of a second launch (scan_finish)
+    unsigned* done_ctr;   // NULL = partial lists only; else a zeroed counter, left zeroed
+    float* out_scores;    // [query][k]
+    int64_t* out_idx;
+    int64_t row_offset;
+    const int64_t* id_map;
 };
+
+__device__ __forceinline__ float scan_query_elem(const ScanArgs& a, int64_t off) {
+    return a.qbuf ? a.qbuf[off] : bf16_to_f32(a.qb16[off]);
+}
 
 template <int DT> struct Elem;
 template <> struct Elem<0> { static constexpr int VEC = 4; };
@@ -99,6 +111,57 @@ __device__ __forceinline__ void wg_merge_store(WaveTopK<KR>& tk, int k, u64* lds
     __syncthreads();
 }
 
+// One-launch form: every workgroup publishes its lists (device-scope release), takes a ticket, and the workgroup that
+// draws the last one reduces all of them: per query it streams the gridDim.x * k keys through per-wave running top-k
+// lists and merges those - slower than the histogram select of a second launch, but this path runs only for the rare
+// query the threshold estimate failed for, and what the common case pays is one empty launch instead of two or more.
+template <int KR>
+__device__ __forceinline__ void scan_finish(const ScanArgs& a, int count, u64* lds) {
+    __shared__ int last_block;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last_block = (atomicAdd(a.done_ctr, 1u) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!last_block) return;
+    __threadfence();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int64_t m = (int64_t)gridDim.x * a.k;
+    for (int s = 0; s < count; ++s) {
+        const u64* src = a.partial + (int64_t)s * m;
+        WaveTopK<KR> tk;
+        tk.init();
+        for (int64_t i0 = (int64_t)wave * 64; i0 < m; i0 += (int64_t)nw * 64) {
+            const int64_t i = i0 + lane;
+            const u64 key = (i < m) ? __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            u64 mm = __ballot(key > tk.thr);
+            while (mm) {
+                const int from = __ffsll((long long)mm) - 1;
+                mm &= mm - 1;
+                const u64 K = shfl_u64(key, from);
+                if (K > tk.thr) tk.insert(K, a.k, lane);
+            }
+        }
+        int P = 1;
+        while (P < nw * a.k) P <<= 1;
+        __syncthreads();
+        for (int i = threadIdx.x; i < P; i += blockDim.x) lds[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+            const int sl = r * 64 + lane;
+            if (sl < a.k) lds[wave * a.k + sl] = tk.key[r];
+        }
+        bitonic_sort_desc(lds, P, threadIdx.x, blockDim.x);
+        const int qid = a.qlist ? a.qlist[s] : s;
+        for (int i = threadIdx.x; i < a.k; i += blockDim.x) {
+            const u64 key = lds[i];
+            a.out_scores[(int64_t)qid * a.k + i] = key ? key_score(key) : -INFINITY;
+            a.out_idx[(int64_t)qid * a.k + i] = !key ? -1 : a.id_map ? a.id_map[key_row(key)] : (int64_t)key_row(key) + a.row_offset;
+        }
+    }
+    if (threadIdx.x == 0) *a.done_ctr = 0;
+}
+
 constexpr int kScanRB = 4;  // rows per lane group per iteration
 
 // Specialised: row = CH * G chunks of 16 bytes, queries in registers.
@@ -128,7 +191,7 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanArgs a) {
 #pragma unroll
             for (int c = 0; c < CH; ++c)
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) qv[q][c][e] = a.qbuf[(int64_t)qid[q] * a.ld + (int64_t)(gl + c * G) * VEC + e];
+                for (int e = 0; e < VEC; ++e) qv[q][c][e] = scan_query_elem(a, (int64_t)qid[q] * a.ld + (int64_t)(gl + c * G) * VEC + e);
         }
         WaveTopK<KR> tk[QB];
         if (!EMIT) {
@@ -180,6 +243,8 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanArgs a) {
             }
         }
     }
+    if constexpr (!EMIT)
+        if (a.done_ctr && count > 0) scan_finish<KR>(a, count, lds_keys);
 }
 
 // Generic: any ld (multiple of 64 elements), QB queries per pass staged in LDS (QB = 1 or 4).
@@ -205,7 +270,7 @@ __global__ void __launch_bounds__(256) scan_generic_kernel(ScanArgs a) {
         for (int q = 0; q < QB; ++q) {
             const int slot = (g0 + q < count) ? (g0 + q) : g0;
             qid[q] = a.qlist ? a.qlist[slot] : slot;
-            for (int i = threadIdx.x; i < a.ld; i += blockDim.x) lds_q[(int64_t)q * a.ld + i] = a.qbuf[(int64_t)qid[q] * a.ld + i];
+            for (int i = threadIdx.x; i < a.ld; i += blockDim.x) lds_q[(int64_t)q * a.ld + i] = scan_query_elem(a, (int64_t)qid[q] * a.ld + i);
         }
         __syncthreads();
         WaveTopK<KR> tk[QB];
@@ -258,6 +323,8 @@ __global__ void __launch_bounds__(256) scan_generic_kernel(ScanArgs a) {
                     wg_merge_store<KR>(tk[q], a.k, lds_keys, a.partial + ((int64_t)(g0 + q) * gridDim.x + blockIdx.x) * a.k);
         }
     }
+    if constexpr (!EMIT)
+        if (a.done_ctr && count > 0) scan_finish<KR>(a, count, lds_keys);
 }
 
 // ---- rank of a given row ("rank of gold") -----------------------------------------------------------------

@@ -115,8 +115,9 @@ struct ts_index {
     bool attr_done = false;
     bool attr_done_hist = false;
     Knobs knobs;                                             // env at creation, then ts_index_set_option
-    hipStream_t last_stream = nullptr;                       // stream of the previous call that used the scratch buffers
-    hipEvent_t order_ev = nullptr;                           // orders a call on another stream behind it
+    hipStream_t last_stream = nullptr;                       // stream the previous call ran on: compared, never used (it may be gone)
+    hipEvent_t order_ev = nullptr;                           // recorded at the end of every call on that call's stream: orders the
+    bool ordered = false;                                    //   next call behind it (`ordered`: recorded at least once)
     int64_t* part = nullptr;    unsigned* wg_ticks = nullptr;    // full pass of the 16x16 kernel: tile boundaries per workgroup, their times
     int part_g = 0;             int64_t part_ntiles = -1;        // ... the grid and tile count the table was made for
     unsigned long long* dbg = nullptr;                       // TS_MFMA_VARIANT=3: per-wave cycle sums / clock probe
@@ -166,19 +167,34 @@ static void prof_end(hipEvent_t stop, hipStream_t st) {
     if (stop) hipEventRecord(stop, st);
 }
 
-// Stream of this call (NULL = the index's own).  The per-handle scratch buffers are shared by all calls: when the
-// previous call was enqueued on ANOTHER stream, this one is ordered behind it (event record + wait), so that a
-// second call never overwrites scratch the first one still reads.  Called under ix->mu.
+// Stream of this call (NULL = the index's own).  The per-handle scratch buffers are shared by all calls: a call that
+// arrives on ANOTHER stream than the previous one is ordered behind it, so that it never overwrites scratch the first
+// one still reads.  The order event is recorded at the END of every entry point, on the stream of that call, while that
+// stream is known to be alive (StreamScope's destructor, on every return path); the next call only waits on the event,
+// and ts_index_synchronize / ts_index_destroy only synchronise on it: a caller's stream handle is never touched after
+// the call that was given it has returned, so the caller may destroy the stream whenever its own work on it is done.
+// Called under ix->mu.
 // The index's own stream is a BLOCKING stream: it orders with the legacy null stream, which is what a torch
 // default stream's handle (0 = NULL here) means - encoder kernels before an upload / search, torch ops after it.
-static int enter_stream(ts_index* ix, void* stream, hipStream_t* out) {
-    hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
-    if (ix->last_stream && ix->last_stream != st) {
-        if (!ix->order_ev) HIP_TRY(hipEventCreateWithFlags(&ix->order_ev, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(ix->order_ev, ix->last_stream));
-        HIP_TRY(hipStreamWaitEvent(st, ix->order_ev, 0));
+struct StreamScope {
+    ts_index* ix = nullptr;
+    hipStream_t st = nullptr;
+    ~StreamScope() {
+        if (!ix || !ix->order_ev) return;
+        if (hipEventRecord(ix->order_ev, st) == hipSuccess) {
+            ix->last_stream = st;
+            ix->ordered = true;
+        } else {
+            (void)hipGetLastError();
+        }
     }
-    ix->last_stream = st;
+};
+static int enter_stream(ts_index* ix, void* stream, hipStream_t* out, StreamScope* scope) {
+    hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
+    if (!ix->order_ev) HIP_TRY(hipEventCreateWithFlags(&ix->order_ev, hipEventDisableTiming));
+    if (ix->ordered && ix->last_stream != st) HIP_TRY(hipStreamWaitEvent(st, ix->order_ev, 0));
+    scope->ix = ix;
+    scope->st = st;
     *out = st;
     return TS_OK;
 }
@@ -307,7 +323,7 @@ extern "C" int ts_index_destroy(ts_index* ix) {
     if (ix->nviews.load() > 0)
         return fail(TS_ERR_UNSUPPORTED, "the index has %d live views: destroy them first (they read its rows)", ix->nviews.load());
     hipSetDevice(ix->device);
-    if (ix->last_stream && ix->last_stream != ix->stream) hipStreamSynchronize(ix->last_stream);   // scratch still in use there
+    if (ix->ordered && ix->order_ev) hipEventSynchronize(ix->order_ev);   // scratch still in use by a call on a caller's stream
     if (ix->stream) hipStreamSynchronize(ix->stream);
     if (ix->borrowed) {
         ix->rows = nullptr;
@@ -373,7 +389,8 @@ extern "C" int ts_index_subset(ts_index* src, const int64_t* rows, int64_t nrows
     }
     std::lock_guard<std::mutex> lock(src->mu);
     hipStream_t src_own;
-    if (enter_stream(src, nullptr, &src_own) != TS_OK) {   // uploads enqueued on the source's own or a caller's stream
+    StreamScope src_scope;
+    if (enter_stream(src, nullptr, &src_own, &src_scope) != TS_OK) {   // uploads enqueued on the source's own or a caller's stream
         ts_index_destroy(ix);
         return TS_ERR_HIP;
     }
@@ -399,9 +416,10 @@ extern "C" int ts_index_synchronize(ts_index* ix) {
     if (!ix) return fail(TS_ERR_INVALID, "index is NULL");
     std::lock_guard<std::mutex> lock(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));
-    if (ix->last_stream && ix->last_stream != ix->stream) HIP_TRY(hipStreamSynchronize(ix->last_stream));
+    if (ix->ordered && ix->order_ev) HIP_TRY(hipEventSynchronize(ix->order_ev));   // the end of the last call, whatever stream it ran on
     HIP_TRY(hipStreamSynchronize(ix->stream));
-    ix->last_stream = nullptr;      // nothing in flight: the caller may destroy that stream now, the next call orders behind nothing
+    ix->ordered = false;            // nothing in flight: the next call orders behind nothing
+    ix->last_stream = nullptr;
     return TS_OK;
 }
 
@@ -468,7 +486,8 @@ static int upload_device_locked(ts_index* ix, const void* dev_rows, int src_dtyp
     if (nrows == 0) return TS_OK;
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st;
-    TS_TRY(enter_stream(ix, stream, &st));
+    StreamScope scope;
+    TS_TRY(enter_stream(ix, stream, &st, &scope));
     char* dst = (char*)ix->rows + (size_t)row0 * ix->ld * ix->elem();
     return prep_dispatch(src_dtype, ix->dtype, ix->metric == TS_METRIC_COS, dev_rows, src_ld, dst, nullptr, ix->ld, ix->d,
                          nrows, nrows, st);
@@ -481,7 +500,8 @@ static int upload_host_locked(ts_index* ix, const void* host_rows, int src_dtype
     const size_t src_elem = src_dtype == TS_BF16 ? 2 : 4;
     const size_t src_row = (size_t)ix->d * src_elem;
     hipStream_t own;
-    TS_TRY(enter_stream(ix, nullptr, &own));   // rows / the stage buffer may still feed a call enqueued on a caller's stream
+    StreamScope scope;
+    TS_TRY(enter_stream(ix, nullptr, &own, &scope));   // rows / the stage buffer may still feed a call enqueued on a caller's stream
     if (src_dtype == ix->dtype && ix->metric == TS_METRIC_IP && ix->ld == ix->d) {
         // stored as given: straight copy into place
         HIP_TRY(hipMemcpyAsync((char*)ix->rows + (size_t)row0 * src_row, host_rows, (size_t)nrows * src_row, hipMemcpyHostToDevice, own));
@@ -532,7 +552,8 @@ static int grow_locked(ts_index* ix, int64_t want_rows) {
     hipError_t e = hipMalloc(&fresh, new_bytes);
     if (e != hipSuccess) return fail(TS_ERR_NOMEM, "hipMalloc of %zu bytes for the grown index failed: %s", new_bytes, hipGetErrorString(e));
     hipStream_t own;
-    int rc = enter_stream(ix, nullptr, &own);
+    StreamScope scope;
+    int rc = enter_stream(ix, nullptr, &own, &scope);
     if (rc == TS_OK) {
         e = hipMemcpyAsync(fresh, ix->rows, old_bytes, hipMemcpyDeviceToDevice, own);
         if (e == hipSuccess) e = hipMemsetAsync((char*)fresh + old_bytes, 0, new_bytes - old_bytes, own);
@@ -572,7 +593,8 @@ extern "C" int ts_index_attach_device(ts_index* ix, void* dev_rows, int64_t capa
         return fail(TS_ERR_INVALID, "attached rows are not device memory of device %d", ix->device);
     }
     hipStream_t own;
-    TS_TRY(enter_stream(ix, nullptr, &own));
+    StreamScope scope;
+    TS_TRY(enter_stream(ix, nullptr, &own, &scope));
     HIP_TRY(hipStreamSynchronize(own));
     if (!ix->attached && ix->rows) HIP_TRY(hipFree(ix->rows));
     ix->rows = dev_rows;
@@ -627,7 +649,8 @@ extern "C" int ts_index_download(ts_index* ix, void* host_rows, int64_t row0, in
     const size_t row_bytes = (size_t)ix->d * ix->elem();
     TS_TRY(ensure(&ix->stage, &ix->stage_bytes, kStageBytes));
     hipStream_t own;
-    TS_TRY(enter_stream(ix, nullptr, &own));
+    StreamScope scope;
+    TS_TRY(enter_stream(ix, nullptr, &own, &scope));
     const int64_t rows_per = std::max<int64_t>(1, (int64_t)(kStageBytes / row_bytes));
     for (int64_t r = 0; r < nrows; r += rows_per) {
         const int64_t cnt = std::min(rows_per, nrows - r);
@@ -816,8 +839,9 @@ static int run_select_rounds(ts_index* ix, int slots, int m, int k, float* out_s
     }
 }
 
+// `qbuf`: fp32 queries to read instead of the prepared copy; `qb16`: bf16 queries to read in place (the caller's matrix).
 static int scan_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* out_idx, const int* qlist, const int* qcount,
-                       hipStream_t st, const float* qbuf = nullptr) {
+                       hipStream_t st, const float* qbuf = nullptr, const unsigned short* qb16 = nullptr) {
     int grid = ix->cu_count * kScanGridPerCU;
     // Large k over a small corpus (app_showcase_model.py:96: topk(200) over a few thousand theorems): every workgroup
     // hands k keys to the select, and 1,024 x 200 of them cost three rounds of sorts (150 us) for a scan of 10 us.  Few
@@ -828,13 +852,25 @@ static int scan_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
     a.corpus = ix->rows;
     a.ld = ix->ld;
     a.n = ix->n;
-    a.qbuf = qbuf ? qbuf : ix->qf32;
+    a.qbuf = qb16 ? nullptr : (qbuf ? qbuf : ix->qf32);
+    a.qb16 = qb16;
     a.qlist = qlist;
     a.qcount = qcount;
     a.nq = nq;
     a.k = k;
     a.partial = ix->partial;
     a.row_mask = ix->active_mask;
+    // The exact re-run of the MFMA path (device-side query count, almost always zero) is ONE launch: the workgroup that
+    // finishes last reduces the partial lists itself (scan_finish), so the common case pays one empty launch, not one per
+    // select round as well.
+    const bool one_launch = qcount != nullptr;
+    if (one_launch) {
+        a.done_ctr = (unsigned*)ix->fb_count + 2;     // zeroed with the block, left zeroed by the kernel
+        a.out_scores = out_scores;
+        a.out_idx = out_idx;
+        a.row_offset = ix->row_offset;
+        a.id_map = ix->id_map;
+    }
     // k > 64 keeps 4 keys per lane and query: on bf16 x 768 four queries at once need all 256 VGPRs, one wave per SIMD
     // (measured 0.18 of the HBM rate against 0.8 for one query per pass); the other shapes keep two waves
     const bool wide_k_one_wave = k > 64 && ix->dtype == TS_BF16 && (ix->ld == 768 || ix->ld == 384);
@@ -843,6 +879,7 @@ static int scan_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
     launch_scan<false>(ix, a, qb, st, grid);
     prof_end(stop, st);
     HIP_TRY(hipGetLastError());
+    if (one_launch) return TS_OK;
     return run_select_rounds(ix, nq, grid * k, k, out_scores, out_idx, qlist, qcount, st);
 }
 
@@ -1069,7 +1106,10 @@ static int mfma_block_queries(const ts_index* ix, int nq) {
     return nq <= 128 && ix->knobs.get(K_MFMA_GROUPS, 0) != 2 ? 128 : 256;
 }
 
-static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* out_idx, hipStream_t st, ts_search_stats* stats) {
+// `qmat`: the queries as the kernels multiply them (storage dtype, row stride d = ld, a whole launch's worth of rows):
+// the prepared copy, or the caller's own device matrix when it already has that form (`in_place`).
+static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* out_idx, hipStream_t st, ts_search_stats* stats,
+                       const void* qmat, bool in_place) {
     // threshold rank: the k-th best of a sample is already a valid lower bound of the final k-th best; private
     // lists + spill absorb the run-to-run spread of the candidate count, so no safety margin in the rank
     const int kk = std::max(k, ix->knobs.get(K_MFMA_MIN_RANK, 1));
@@ -1151,7 +1191,7 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         a.ntiles = lv[i].ntiles;
         a.tile_stride = lv[i].stride;
         a.run = lv[i].run;
-        a.q = (const unsigned short*)ix->qstore;
+        a.q = (const unsigned short*)qmat;
         a.thr = ix->thr;
         a.nq = ix->knobs.get(K_MFMA_NO_IDLE, 0) ? 256 : nq;
         a.row_mask = ix->active_mask;
@@ -1287,8 +1327,10 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         else level_select_kernel<4><<<nq + (move ? 1 : 0), kLevelThreads, kLevelLds, st>>>(l);
         HIP_TRY(hipGetLastError());
     }
-    // exact fall-back for queries that lost candidates (device-side count; no-op when 0)
-    TS_TRY(scan_search(ix, nq, k, out_scores, out_idx, ix->fb_list, ix->fb_count, st));
+    // exact fall-back for queries that lost candidates (device-side count; one empty launch when 0)
+    if (!in_place) TS_TRY(scan_search(ix, nq, k, out_scores, out_idx, ix->fb_list, ix->fb_count, st));
+    else if (ix->dtype == TS_F32) TS_TRY(scan_search(ix, nq, k, out_scores, out_idx, ix->fb_list, ix->fb_count, st, (const float*)qmat));
+    else TS_TRY(scan_search(ix, nq, k, out_scores, out_idx, ix->fb_list, ix->fb_count, st, nullptr, (const unsigned short*)qmat));
     if (stats) stats->levels = (int)lv.size();
     return TS_OK;
 }
@@ -1318,7 +1360,8 @@ static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_
     std::lock_guard<std::mutex> lock(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st;
-    TS_TRY(enter_stream(ix, stream, &st));
+    StreamScope scope;
+    TS_TRY(enter_stream(ix, stream, &st, &scope));
     TS_TRY(ensure_search_scratch(ix, k));
     struct MaskScope {  // the bitmask is a property of this call only
         ts_index* ix;
@@ -1396,6 +1439,15 @@ static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_
             TS_TRY(scan_search(ix, 1, k, os, oi, nullptr, nullptr, st, qb));
             continue;
         }
+        // Device queries that already are what the matrix kernels multiply - the index's storage type, an inner-product
+        // index (nothing to normalise), rows not padded, a whole launch's worth of them, 16-byte aligned - are read where
+        // they lie: no preparation launch (the encoder's fused pooling writes this form, ts_pool_normalize with
+        // out_dtype = the index's; bench.py's resident query batch).  They must stay unchanged until the search has run.
+        if (use == TS_ALGO_MFMA && q_on_device && q_dtype == ix->dtype && ix->metric == TS_METRIC_IP && ix->ld == ix->d &&
+            nb == block && ((uintptr_t)qsrc & 15) == 0) {
+            TS_TRY(mfma_search(ix, nb, k, os, oi, st, stats, qsrc, true));
+            continue;
+        }
         if (!q_on_device) {
             HIP_TRY(hipMemcpyAsync(ix->stage, qsrc, (size_t)nb * ix->d * q_elem, hipMemcpyHostToDevice, st));
             qsrc = ix->stage;
@@ -1403,7 +1455,7 @@ static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_
         // normalise (COS), round to the storage type, zero-pad to 256 rows x ld; fp32 copy for the scan
         TS_TRY(prep_dispatch(q_dtype, ix->dtype, ix->metric == TS_METRIC_COS, qsrc, ix->d, ix->qstore, ix->qf32, ix->ld, ix->d,
                              nb, kQBlock, st));
-        if (use == TS_ALGO_MFMA) TS_TRY(mfma_search(ix, nb, k, os, oi, st, stats));
+        if (use == TS_ALGO_MFMA) TS_TRY(mfma_search(ix, nb, k, os, oi, st, stats, ix->qstore, false));
         else TS_TRY(scan_search(ix, nb, k, os, oi, nullptr, nullptr, st));
     }
     if (!out_on_device) {
@@ -1545,7 +1597,8 @@ static int rank_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_de
     std::lock_guard<std::mutex> lock(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st;
-    TS_TRY(enter_stream(ix, stream, &st));
+    StreamScope scope;
+    TS_TRY(enter_stream(ix, stream, &st, &scope));
     TS_TRY(ensure_search_scratch(ix, 1));
     constexpr size_t kPer = 8 + 8 + 4;
     TS_TRY(ensure(&ix->rank_buf, &ix->rank_bytes, (size_t)kQBlock * kPer));
@@ -1633,7 +1686,8 @@ extern "C" int ts_scores(ts_index* ix, const void* queries, int q_dtype, int q_o
     std::lock_guard<std::mutex> lock(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st;
-    TS_TRY(enter_stream(ix, stream, &st));
+    StreamScope scope;
+    TS_TRY(enter_stream(ix, stream, &st, &scope));
     TS_TRY(ensure_search_scratch(ix, 1));
     float* dout = out;
     DevBuf tmp;

@@ -65,7 +65,13 @@ class ShardedSearcher:
 
     def __init__(self, local_search: Optional[Callable[[np.ndarray, int], Tuple[np.ndarray, np.ndarray]]] = None,
                  merge: Optional[Callable[[np.ndarray, np.ndarray, int], Tuple[np.ndarray, np.ndarray]]] = None,
-                 group=None, index=None, exchange: str = "auto"):
+                 group=None, index=None, exchange: str = "auto", pipeline: int = 2):
+        """``exchange``: ``"torch"`` = ``dist.all_gather_into_tensor`` (RCCL under the nccl backend), ``"native"`` =
+        ``ncclAllGather`` inside libtsearch (``ts_comm_*``); ``"auto"`` = ``"torch"``: the native communicator has only ever
+        run with one rank on the boxes this was developed on, so it is opt-in until a run on two or more GPUs is on record.
+        ``pipeline``: local searches in flight in `search_device` (1 = every search on the caller's stream; 2 = consecutive
+        searches alternate between the index and a view of it, each on its own stream, so that the small kernels at the
+        head of search i + 1 overlap the tail of search i)."""
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -77,28 +83,22 @@ class ShardedSearcher:
         self._comm = C.c_void_p()
         self._bufs = {}
         self._step = 0
+        self._side = None
+        self._lanes = None
+        self.pipeline = max(1, int(pipeline))
         backend = dist.get_backend(group) if dist.is_initialized() else None
         if exchange == "auto":
-            exchange = "native" if (index is not None and backend == "nccl") else "torch"
+            exchange = "torch"
         if exchange not in ("native", "torch"):
             raise ValueError(f"exchange must be 'auto', 'native' or 'torch', got {exchange!r}")
         self.exchange = exchange
         self.backend = backend
         if exchange == "native" and self.world > 1:
-            try:
-                self._init_native_comm()
-            except Exception as e:            # RCCL not loadable / communicator refused: the same block goes over torch.distributed
+            ok, why = self._init_native_comm()      # every rank comes back with the same answer
+            if not ok:
                 import warnings
-                warnings.warn(f"native RCCL exchange unavailable ({e}); falling back to torch.distributed")
-                ok = False
-            else:
-                ok = True
-            # every rank must take the same path: one all-reduce of the outcome (start-up, not the search path)
-            import torch
-            flag = torch.tensor([1 if ok else 0], device=torch.device("cuda", index.device) if backend == "nccl" else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-            if int(flag.item()) == 0:
-                self.close()
+                warnings.warn(f"native RCCL exchange unavailable ({why}); using torch.distributed for the same block")
+                self.close_comm()
                 self.exchange = "torch"
 
     # -- construction ---------------------------------------------------------------------------------------------
@@ -115,36 +115,60 @@ class ShardedSearcher:
         assert ix.n == hi - lo, f"rank {rank} expected {hi - lo} rows, got {ix.n}"
         return cls(group=group, index=ix, exchange=exchange)
 
-    def _init_native_comm(self) -> None:
-        """ts_comm_create on every rank; torch.distributed only carries the unique id (start-up, not the search path).
-        No rank may skip a collective another rank is waiting in: whether RCCL loads at all is settled first (every rank
-        asks for a unique id - no communication - and the outcomes are all-reduced), only then does rank 0's id travel."""
+    def _agree(self, ok: bool) -> bool:
+        """One all-reduce (min) of a start-up outcome: every rank learns whether EVERY rank succeeded."""
         import torch
+        dev = torch.device("cuda", self.index.device) if self.backend == "nccl" else "cpu"
+        flag = torch.tensor([1 if ok else 0], device=dev)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.group)
+        return int(flag.item()) == 1
+
+    def _init_native_comm(self):
+        """ts_comm_create on every rank; torch.distributed only carries the unique id (start-up, not the search path).
+        Returns ``(ok, reason)``, the same ``ok`` on every rank.  Every rank walks through the same three collectives
+        whatever happens locally (library missing, RCCL not loadable, id refused): nothing local is allowed to raise
+        before its outcome has been all-reduced, so no rank can be left waiting in a collective another rank skipped.
+        What cannot be recovered: ``ncclCommInitRank`` is itself a collective, and a rank that dies INSIDE it leaves the
+        others blocked there - such a job must be ended from outside (the launcher's timeout) and exits non-zero."""
         from . import _ffi
-        _ffi.prefer_torch_rccl()
-        lib = _ffi.load()
-        mine, err = None, None
+        lib, mine, err = None, None, None
         try:
+            _ffi.prefer_torch_rccl()
+            lib = _ffi.load()
             buf = C.create_string_buffer(128)
             _ffi.check(lib.ts_comm_unique_id(buf, 128))
             mine = bytes(buf.raw)
-        except Exception as e:                     # noqa: BLE001 - reported below, after every rank has been heard
+        except Exception as e:                     # noqa: BLE001 - reported after every rank has been heard
             err = e
-        dev = torch.device("cuda", self.index.device) if self.backend == "nccl" else "cpu"
-        flag = torch.tensor([0 if mine is None else 1], device=dev)
-        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.group)
-        if int(flag.item()) == 0:
-            raise RuntimeError(f"RCCL is not usable on every rank (this rank: {err or 'ok'})")
+        if not self._agree(mine is not None):                                   # collective 1
+            return False, f"RCCL is not usable on every rank (this rank: {err or 'ok'})"
         ident = [mine if self.rank == 0 else None]
         self.dist.broadcast_object_list(ident, src=self.dist.get_global_rank(self.group, 0) if self.group else 0,
-                                        group=self.group)
-        _ffi.check(lib.ts_comm_create(self.index.device, self.world, self.rank, ident[0], 128, C.byref(self._comm)))
+                                        group=self.group)                       # collective 2
+        try:
+            _ffi.check(lib.ts_comm_create(self.index.device, self.world, self.rank, ident[0], 128, C.byref(self._comm)))
+        except Exception as e:                     # noqa: BLE001 - a refusal that returned (bad id, no device ...)
+            err = e
+        if not self._agree(bool(self._comm.value)):                             # collective 3
+            return False, f"ts_comm_create failed on some rank (this rank: {err or 'ok'})"
+        return True, ""
 
-    def close(self) -> None:
+    def close_comm(self) -> None:
         if self._comm.value:
             from . import _ffi
             _ffi.load().ts_comm_destroy(self._comm)
             self._comm = C.c_void_p()
+
+    def close(self) -> None:
+        self.close_comm()
+        lanes, self._lanes = self._lanes, None
+        for ix, _ in (lanes or [])[1:]:           # the views; lane 0 is the caller's index
+            try:
+                ix.synchronize()
+                ix.close()
+            except Exception:
+                pass
+        self._bufs = {}
 
     def __del__(self):
         try:
@@ -153,31 +177,55 @@ class ShardedSearcher:
             pass
 
     # -- the device pipeline (what bench.py times) -----------------------------------------------------------------
+    _MAX_SHAPES = 4      # (nq, k) shapes whose exchange buffers are kept (least recently used goes first)
+
     def _device_buffers(self, nq: int, k: int):
         import torch
         key = (nq, k)
-        b = self._bufs.get(key)
+        b = self._bufs.pop(key, None)
         if b is None:
             dev = torch.device("cuda", self.index.device)
             blk = packed_bytes(nq, k)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)        # ONE side stream per searcher, whatever the shapes
+            while len(self._bufs) >= self._MAX_SHAPES:
+                old = self._bufs.pop(next(iter(self._bufs)))
+                for e, used in zip(old["done"], old["used"]):
+                    if used:
+                        e.synchronize()                           # its buffers may still be read by an exchange in flight
             b = {
                 "mine": [torch.empty(blk, dtype=torch.uint8, device=dev) for _ in range(2)],
                 "all": [torch.empty(self.world * blk, dtype=torch.uint8, device=dev) for _ in range(2)],
                 "fin_s": [torch.empty((nq, k), dtype=torch.float32, device=dev) for _ in range(2)],
                 "fin_i": [torch.empty((nq, k), dtype=torch.int64, device=dev) for _ in range(2)],
+                "ready": [torch.cuda.Event() for _ in range(2)],
                 "searched": [torch.cuda.Event() for _ in range(2)],
                 "done": [torch.cuda.Event() for _ in range(2)],
                 "used": [False, False],
-                "side": torch.cuda.Stream(device=dev),
             }
-            self._bufs[key] = b
+        self._bufs[key] = b                                       # most recently used last
         return b
+
+    def _lane(self, main):
+        """(index handle, stream) of the next local search: the caller's index on the caller's stream, or - pipeline > 1 -
+        the index and views of it in turn, each on a stream of its own."""
+        import torch
+        if self.pipeline <= 1:
+            return self.index, main, False
+        if self._lanes is None:
+            dev = torch.device("cuda", self.index.device)
+            self._lanes = [(self.index, torch.cuda.Stream(device=dev))]
+            for _ in range(self.pipeline - 1):
+                self._lanes.append((self.index.view(), torch.cuda.Stream(device=dev)))
+        ix, st = self._lanes[self._step % len(self._lanes)]
+        return ix, st, True
 
     def search_device(self, q_ptr: int, q_dtype: str, nq: int, k: int, stream=None, algo: str = "auto", mask_ptr: int = 0,
                       overlap: bool = True):
-        """Enqueue one sharded search of ``nq`` device-resident queries: local search on ``stream`` (a
-        ``torch.cuda.Stream``; default: the current one), then the exchange + merge on a side stream, so that they
-        overlap the next call's search (``overlap=False``: everything on ``stream``).  Returns
+        """Enqueue one sharded search of ``nq`` device-resident queries, ordered behind ``stream`` (a
+        ``torch.cuda.Stream``; default: the current one - the queries must be ready there): the local search (on that
+        stream, or with ``pipeline`` > 1 on the stream of the handle whose turn it is), then the exchange + merge on a
+        side stream, so that they overlap the next call's search (``overlap=False``: everything on ``stream``).  Returns
         ``(scores, idx, done)``: merged global results as device tensors ``[nq x k]`` (double-buffered: valid until
         the second-next call) and the ``torch.cuda.Event`` that marks them complete."""
         import torch
@@ -185,16 +233,20 @@ class ShardedSearcher:
         lib = _ffi.load()
         main = stream or torch.cuda.current_stream(self.index.device)
         b = self._device_buffers(nq, k)
+        ix, lane, own_stream = self._lane(main) if overlap else (self.index, main, False)
         p = self._step & 1
         self._step += 1
+        if own_stream:
+            b["ready"][p].record(main)                 # the queries are complete on the caller's stream
+            lane.wait_event(b["ready"][p])
         if b["used"][p]:
-            main.wait_event(b["done"][p])              # the exchange of the call before last has consumed mine[p]
+            lane.wait_event(b["done"][p])              # the exchange of the call before last has consumed mine[p]
         blk, off = packed_bytes(nq, k), packed_idx_off(nq, k)
         base = b["mine"][p].data_ptr()
-        self.index.search_device(q_ptr, q_dtype, nq, k, base, base + off, main.cuda_stream, algo=algo, mask_ptr=mask_ptr)
-        side = b["side"] if overlap else main
+        ix.search_device(q_ptr, q_dtype, nq, k, base, base + off, lane.cuda_stream, algo=algo, mask_ptr=mask_ptr)
+        side = self._side if overlap else main
         if overlap:
-            b["searched"][p].record(main)
+            b["searched"][p].record(lane)
             side.wait_event(b["searched"][p])
         if self.world == 1:
             src = b["mine"][p]
