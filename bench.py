@@ -172,11 +172,11 @@ def main():
     if use_dist:
         from theoremsearch_amd.distributed import ShardedSearcher
         searcher = ShardedSearcher(index=ix, exchange=("torch" if args.share_gpu else args.exchange), pipeline=P)
+        log(rank, f"sharded search: exchange = {searcher.exchange}" + (" (RCCL inside libtsearch)" if searcher.exchange == "native" else f" (torch.distributed, backend {searcher.backend})"))
     else:
         for _ in range(P - 1):                     # N = 1: the loop itself alternates the handles
             handles.append(ix.view())
             lanes.append(torch.cuda.Stream())
-        log(rank, f"sharded search: exchange = {searcher.exchange}" + (" (RCCL inside libtsearch)" if searcher.exchange == "native" else f" (torch.distributed, backend {searcher.backend})"))
     encoder = None
     if args.workload == "c5":
         # BASELINE.json configs[4]: encoder forward (PyTorch-ROCm, random-init BERT-base-shaped stand-in: no weights

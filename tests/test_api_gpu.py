@@ -315,11 +315,11 @@ def test_device_queries_in_the_storage_form_are_read_in_place(ts, dtype):
 def test_exact_rerun_with_large_k_and_many_queries(ts):
     """The one-launch re-run with four keys per lane (k > 64) and more failing queries than one scan pass serves."""
     rng = np.random.default_rng(32)
-    n, d, k = 50_000, 768, 100
+    n, d, k = 80_000, 768, 100
     c = rng.standard_normal((n, d), dtype=np.float32) * np.float32(0.05)
     hots = rng.standard_normal((6, d)).astype(np.float32) * np.float32(0.05)
     for j in range(6):
-        c[j * 8000:(j + 1) * 8000 - 500] = hots[j]           # six piles of equal rows: six queries overflow
+        c[j * 13000:(j + 1) * 13000 - 1000] = hots[j]        # six piles of 12,000 equal rows: six queries overflow
     q = np.concatenate([hots, rng.standard_normal((10, d), dtype=np.float32) * np.float32(0.05)])
     with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as ix:
         s, i, st = ix.search(q, k, algo="mfma", return_stats=True)
@@ -352,3 +352,19 @@ def test_a_callers_stream_may_be_destroyed_after_its_own_sync(ts):
         del st
         ix.synchronize()
         assert np.array_equal(out_s.cpu().numpy(), want_s)
+
+
+def test_the_product_library_refuses_timing_only_kernel_variants(ts):
+    """VERDICT r2 / ADVICE: kernels that return wrong answers (TS_MFMA_VARIANT != 0) are not in libtsearch.so - only in the
+    diagnostic build (make diag -> libtsearch_diag.so, selected with TS_LIB)."""
+    import os
+    from theoremsearch_amd import _ffi
+    if os.path.basename(_ffi.lib_path()) != "libtsearch.so":
+        pytest.skip("a diagnostic build is loaded (TS_LIB)")
+    with ts.TheoremIndex(1000, 768, dtype="bf16", metric="ip") as ix:
+        for v in (1, 2, 3, 5, 7):
+            with pytest.raises(_ffi.TSearchError) as e:
+                ix.set_option("TS_MFMA_VARIANT", v)
+            assert e.value.code == -5
+        ix.set_option("TS_MFMA_VARIANT", 0)
+        ix.set_option("TS_MFMA_VARIANT", None)

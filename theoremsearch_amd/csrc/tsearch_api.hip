@@ -59,13 +59,13 @@ static int fail(int code, const char* fmt, ...) {
 enum Knob {
     K_MFMA_MIN_RANK, K_MFMA_VARIANT, K_MFMA_GROUPS, K_MFMA_GRID, K_MFMA_STAT, K_MFMA_STAT_CANDS, K_MFMA_TAIL_FIT,
     K_MFMA_NO_IDLE, K_MFMA_AHEAD, K_MFMA_TARGET_CANDS, K_MFMA_FIRST_ROWS, K_MFMA_TARGET_SPARSE, K_MFMA_RUN,
-    K_MFMA_MIN_ROWS, K_MFMA_SHAPE, K_MFMA_F32, K_SCAN_GENERIC, K_SCAN_MAX_QUERIES, K_MFMA_BALANCE, K_COUNT
+    K_MFMA_MIN_ROWS, K_MFMA_SHAPE, K_MFMA_F32, K_SCAN_GENERIC, K_SCAN_MAX_QUERIES, K_MFMA_BALANCE, K_PROBE_SPREAD, K_COUNT
 };
 static const char* const kKnobNames[K_COUNT] = {
     "TS_MFMA_MIN_RANK", "TS_MFMA_VARIANT", "TS_MFMA_GROUPS", "TS_MFMA_GRID", "TS_MFMA_STAT", "TS_MFMA_STAT_CANDS",
     "TS_MFMA_TAIL_FIT", "TS_MFMA_NO_IDLE", "TS_MFMA_AHEAD", "TS_MFMA_TARGET_CANDS", "TS_MFMA_FIRST_ROWS",
     "TS_MFMA_TARGET_SPARSE", "TS_MFMA_RUN", "TS_MFMA_MIN_ROWS", "TS_MFMA_SHAPE", "TS_MFMA_F32", "TS_SCAN_GENERIC",
-    "TS_SCAN_MAX_QUERIES", "TS_MFMA_BALANCE"};
+    "TS_SCAN_MAX_QUERIES", "TS_MFMA_BALANCE", "TS_PROBE_SPREAD"};
 struct Knobs {
     int v[K_COUNT];
     bool set[K_COUNT];
@@ -75,6 +75,10 @@ struct Knobs {
             set[i] = e && *e;
             v[i] = set[i] ? atoi(e) : 0;
         }
+#ifndef TS_DIAG
+        set[K_MFMA_VARIANT] = false;      // the timing-only kernel variants exist in the diagnostic build only (make diag)
+        v[K_MFMA_VARIANT] = 0;
+#endif
     }
     int get(Knob k, int dflt) const { return set[k] ? v[k] : dflt; }
 };
@@ -352,6 +356,11 @@ extern "C" int ts_index_set_option(ts_index* ix, const char* name, int32_t value
     if (!ix || !name) return fail(TS_ERR_INVALID, "NULL argument");
     for (int i = 0; i < K_COUNT; ++i)
         if (!strcmp(name, kKnobNames[i])) {
+#ifndef TS_DIAG
+            if (i == K_MFMA_VARIANT && value != 0)
+                return fail(TS_ERR_UNSUPPORTED, "TS_MFMA_VARIANT = %d: the timing-only kernel variants are compiled into the "
+                            "diagnostic build only (make -C theoremsearch_amd/csrc diag; TS_LIB selects it)", value);
+#endif
             std::lock_guard<std::mutex> lock(ix->mu);
             ix->knobs.v[i] = value;
             ix->knobs.set[i] = true;
@@ -972,6 +981,7 @@ static int launch_mfma(bool full_pass, int variant, int grid, hipStream_t st, co
     if (!(attr_done.load(std::memory_order_acquire) & bit)) {
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<D, GROUPS, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<D, GROUPS, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+#ifdef TS_DIAG
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<D, GROUPS, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<D, GROUPS, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<D, GROUPS, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -979,9 +989,11 @@ static int launch_mfma(bool full_pass, int variant, int grid, hipStream_t st, co
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<D, GROUPS, 5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<D, GROUPS, 6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_topk_kernel<D, GROUPS, 7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+#endif
         attr_done.fetch_or(bit, std::memory_order_release);
     }
     if (!full_pass) mfma_topk_kernel<D, GROUPS, 0, true><<<grid, kMfmaThreads, lds, st>>>(a);
+#ifdef TS_DIAG
     else if (variant == 1) mfma_topk_kernel<D, GROUPS, 1, false><<<grid, kMfmaThreads, lds, st>>>(a);
     else if (variant == 2) mfma_topk_kernel<D, GROUPS, 2, false><<<grid, kMfmaThreads, lds, st>>>(a);
     else if (variant == 3) mfma_topk_kernel<D, GROUPS, 3, false><<<grid, kMfmaThreads, lds, st>>>(a);
@@ -989,7 +1001,9 @@ static int launch_mfma(bool full_pass, int variant, int grid, hipStream_t st, co
     else if (variant == 5) mfma_topk_kernel<D, GROUPS, 5, false><<<grid, kMfmaThreads, lds, st>>>(a);
     else if (variant == 6) mfma_topk_kernel<D, GROUPS, 6, false><<<grid, kMfmaThreads, lds, st>>>(a);
     else if (variant == 7) mfma_topk_kernel<D, GROUPS, 7, false><<<grid, kMfmaThreads, lds, st>>>(a);
+#endif
     else mfma_topk_kernel<D, GROUPS, 0, false><<<grid, kMfmaThreads, lds, st>>>(a);
+    (void)variant;
     HIP_TRY(hipGetLastError());
     return TS_OK;
 }
@@ -998,7 +1012,11 @@ template <int D, int NB>
 static int launch_mfma16(bool full_pass, int variant, int grid, hipStream_t st, const MfmaArgs& a) {
     constexpr int lds = MfmaDims<D>::kLds + kMfma16StageBytes;
     static_assert(lds <= 160 * 1024, "DMA ring + staged candidates must fit the CU's LDS");
+#ifdef TS_DIAG
     constexpr bool kDiag = (D == 768 && NB == 4);     // the timing-only variants exist for the headline shape only
+#else
+    constexpr bool kDiag = false;                     // ... and in the diagnostic build only (make diag)
+#endif
     static std::atomic<unsigned long long> attr_done{0};
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
@@ -1046,12 +1064,17 @@ static int launch_mfma_f32(bool full_pass, int variant, int grid, hipStream_t st
     if (!(attr_done.load(std::memory_order_acquire) & bit)) {
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_f32_topk_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_f32_topk_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+#ifdef TS_DIAG
         HIP_TRY(hipFuncSetAttribute((const void*)mfma_f32_topk_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+#endif
         attr_done.fetch_or(bit, std::memory_order_release);
     }
     if (!full_pass) mfma_f32_topk_kernel<0, true><<<grid, kMfmaThreads, lds, st>>>(a);
+#ifdef TS_DIAG
     else if (variant == 1) mfma_f32_topk_kernel<1, false><<<grid, kMfmaThreads, lds, st>>>(a);
+#endif
     else mfma_f32_topk_kernel<0, false><<<grid, kMfmaThreads, lds, st>>>(a);
+    (void)variant;
     HIP_TRY(hipGetLastError());
     return TS_OK;
 }
@@ -1208,10 +1231,12 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         a.part = (balance && full_pass) ? ix->part : nullptr;
         a.wg_ticks = (balance && full_pass) ? ix->wg_ticks : nullptr;
         a.dbg = nullptr;
+#ifdef TS_DIAG
         if (variant >= 3) {
             if (!ix->dbg) HIP_TRY(hipMalloc((void**)&ix->dbg, 2048 * 4 * 4 * 8));
             a.dbg = ix->dbg;
         }
+#endif
         hipEvent_t stop = full_pass ? prof_begin(ix, st, ix->n) : nullptr;  // only the full pass is bracketed
         int rc;
         if (ix->dtype == TS_F32 && ix->d == 1024) rc = launch_mfma16_f32<1024, 1>(full_pass, grid, st, a);
@@ -1232,6 +1257,7 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         else rc = launch_mfma<768, 2>(full_pass, variant, grid, st, a);
         prof_end(stop, st);
         TS_TRY(rc);
+#ifdef TS_DIAG
         if (a.dbg && full_pass && shape16 && variant == 3) {
             // clock probe (MI355X_MICROARCH.md "DVFS give-back" item 6): shader cycles / 100 MHz ticks around the tile loop,
             // median over workgroups
@@ -1250,7 +1276,7 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
                 ix->probe_ghz = ghz[ghz.size() / 2];
                 ix->probe_cycles_per_unit = cpu_[cpu_.size() / 2];
                 ix->probe_units = (double)h[2];
-                if (getenv("TS_PROBE_SPREAD")) {
+                if (ix->knobs.get(K_PROBE_SPREAD, 0)) {
                     // the launch ends with its slowest workgroup: time inside the tile loop per workgroup (100 MHz ticks),
                     // and its mean by workgroup id % 8 (the XCD under round-robin dispatch)
                     std::vector<double> us;
@@ -1290,6 +1316,7 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
                         wv, tot / units, vm / units, bar / units, units / grid);
             }
         }
+#endif
         LevelArgs l;
         memset(&l, 0, sizeof(l));
         l.priv = ix->priv;

@@ -13,6 +13,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# the timing-only kernel variants live in the diagnostic build of the library (make -C theoremsearch_amd/csrc diag)
+_DIAG = os.path.join(ROOT, "theoremsearch_amd", "libtsearch_diag.so")
+if os.path.exists(_DIAG):
+    os.environ.setdefault("TS_LIB", _DIAG)
 
 
 def main():
