@@ -68,17 +68,24 @@ def main():
                     help="N > 1: collective of the per-shard top-k: native = ncclAllGather inside libtsearch (ts_comm_*), "
                          "torch = torch.distributed.all_gather_into_tensor; auto = native on the nccl backend")
     ap.add_argument("--cpu-baseline-full", action="store_true",
-                    help="time the CPU baseline over the WHOLE corpus, 16 queries at a time (minutes; default: a 1M-row sample)")
+                    help="time the CPU baseline for EVERY query of the batch over the whole corpus, 16 queries at a time (minutes; "
+                         "default: the whole corpus, as many 16-query chunks as fit in --cpu-baseline-seconds)")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0, help="host time the default CPU baseline may take")
+    ap.add_argument("--sustained-steps", type=int, default=300,
+                    help="steps of the sustained leg behind the timed region (0 = skip); reported as `sustained`")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the measured-ceiling legs (tools/microbench)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal of the N > 1 path on a one-GPU box: every rank uses device 0, exchange over gloo "
                          "through host memory (timings meaningless)")
     ap.add_argument("--mask-frac", type=float, default=0.0,
                     help="diagnostic: filtered search with this fraction of rows allowed (device bitmask)")
-    ap.add_argument("--pipeline", type=int, default=2,
+    ap.add_argument("--pipeline", type=int, default=1,
                     help="searches in flight: the timed loop alternates this many handles on the same rows (the index and "
                          "views of it, ts_index_view), each on its own stream, so that the small kernels at the head of "
                          "step i + 1 overlap the tail of step i (independent batches back to back, streamlit_app.py:165-173); "
-                         "1 = one handle, one stream")
+                         "1 = one handle, one stream (default: measured on one box, two in flight gain 0.0 % on the 10M corpus and "
+                         "2 % on an eighth of it - the full pass holds every CU, so the small kernels of the other search "
+                         "only move, they do not hide - and the event brackets of overlapping passes stop being kernel time)")
     ap.add_argument("--zero-queries", action="store_true", help="diagnostic: all-zero queries (power probe)")
     ap.add_argument("--zero-corpus", action="store_true", help="diagnostic: all-zero corpus (power probe)")
     args = ap.parse_args()
@@ -257,6 +264,33 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     qps = nq * args.steps / dt
 
+    # ---- sustained: the same step, `--sustained-steps` more of them back to back (the timed region above is the
+    # contract's K steps - 63 ms at the default; a second of back-to-back passes lets the clock settle) -----------------
+    sustained = None
+    if args.sustained_steps > 0 and args.workload != "c1":
+        barrier()
+        for h in prof_handles:
+            h.profile_enable(True)
+        t1 = time.perf_counter()
+        for _ in range(args.sustained_steps):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        dt_s = time.perf_counter() - t1
+        sp = {"launches": 0, "total_ms": 0.0}
+        for h in prof_handles:
+            p_ = h.profile_read()
+            h.profile_enable(False)
+            sp["launches"] += p_["launches"]
+            sp["total_ms"] += p_["total_ms"]
+        if world > 1:
+            t = torch.tensor([dt_s], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_s = float(t.item())
+        sustained = {"steps": args.sustained_steps, "queries_per_s": round(nq * args.sustained_steps / dt_s, 1),
+                     "ms_per_step": round(dt_s / args.sustained_steps * 1e3, 4),
+                     "kernel_ms": round(sp["total_ms"] / max(1, sp["launches"]), 4), "seconds": round(dt_s, 3)}
+
     # ---- how the search ran (one extra search outside the timed region): algorithm, levels, candidates ----------------
     search_stats, stats_algo = None, None
     if not mask_ptr and encoder is None:
@@ -294,13 +328,40 @@ def main():
                    "scan": "scan_kernel"}.get(stats_algo or ("scan" if mask_ptr and nq <= 4 else None), "unknown")
     if stats_algo is None and encoder is not None:
         kernel_name = "mfma16_topk_kernel" if D == 768 else "mfma_topk_kernel"
+    # ---- the ceiling of this pass on THIS device, measured on the resident corpus right here (tools/microbench/
+    # mfma_stream_ceiling.hip: the product's tile loop without epilogue / candidates, its DMA stream alone, its matrix work
+    # alone, and the same MFMA count with operands in registers = the random-data matrix rate under this device's power cap)
+    ceiling = None
+    if (rank == 0 and world == 1 and not args.no_ceiling and bf16 and D == 768 and nq == 256 and encoder is None
+            and not mask_ptr and n_local >= 64 * 512):
+        try:
+            import ctypes as C
+            cl = C.CDLL(os.path.join(ROOT, "tools", "microbench", "build", "libts_ceiling.so"))
+            cl.ts_ceiling_run.restype = C.c_int
+            cl.ts_ceiling_run.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p]
+            ms4 = (C.c_double * 4)()
+            torch.cuda.synchronize()
+            rows_c = n_local // 32 * 32
+            if cl.ts_ceiling_run(local_rank, C.c_void_p(ix.info()["rows_ptr"]), rows_c, C.c_void_p(q_dev.data_ptr()), 3, 5, ms4, None) == 0:
+                fl = 2.0 * 256 * rows_c * D
+                ceiling = {"stream_plus_mfma_ms": round(ms4[0], 4), "stream_only_ms": round(ms4[1], 4),
+                           "mfma_lds_only_ms": round(ms4[2], 4), "bare_mfma_ms": round(ms4[3], 4),
+                           "measured_gemm_tflops": round(fl / (ms4[3] * 1e-3) / 1e12, 1),
+                           "stream_plus_mfma_hbm_frac": round(rows_c * D * 2 / (ms4[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "kernel_over_stream_plus_mfma": round(kern_ms / ms4[0], 4) if ms4[0] > 0 else None,
+                           "how": "same run, same device, the resident corpus: 3 interleaved rounds x 5 launches per leg of "
+                                  "tools/microbench/mfma_stream_ceiling.hip"}
+        except OSError as e:
+            log(rank, f"ceiling legs skipped: {e}")
     by_mfma = mfma_frac > hbm_frac
     roofline = {"bound": "mfma" if by_mfma else "hbm", "kernel": kernel_name,
                 "achieved": round(tflops if by_mfma else achieved, 1), "peak": mfma_peak if by_mfma else HBM_PEAK_GBS,
                 "unit": "TFLOP/s" if by_mfma else "GB/s", "frac": round(mfma_frac if by_mfma else hbm_frac, 4),
                 "hbm_achieved_gbs": round(achieved, 1), "hbm_peak_gbs": HBM_PEAK_GBS, "hbm_frac": round(hbm_frac, 4),
                 "mfma_achieved_tflops": round(tflops, 1), "mfma_peak_tflops": mfma_peak, "mfma_frac": round(mfma_frac, 4),
-                "mfma_frac_of_measured_gemm_rate": round(tflops / MFMA_RANDOM_DATA_GEMM_TFLOPS, 4) if bf16 else None,
+                "mfma_frac_of_measured_gemm_rate": (round(tflops / ceiling["measured_gemm_tflops"], 4) if ceiling else None),
+                "mfma_frac_of_guide_gemm_rate": round(tflops / MFMA_RANDOM_DATA_GEMM_TFLOPS, 4) if bf16 else None,
+                "ceiling": ceiling,
                 "traffic": traffic,
                 "kernel_ms": round(kern_ms, 4), "launches_per_step": launches_per_step,
                 "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_flops_per_launch": alg_flops}
@@ -353,25 +414,40 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         q_s = oracle.bf16_bits_to_f32(q_host) if bf16 else q_host
-        if args.cpu_baseline_full and len(cache) == len(chunks):
+        mem_avail = 0
+        try:
+            for ln in open("/proc/meminfo"):
+                if ln.startswith("MemAvailable:"):
+                    mem_avail = int(ln.split()[1]) * 1024
+        except OSError:
+            pass
+        fp32_corpus = rows_total * D * 4
+        nq_timed = nq
+        if len(cache) == len(chunks) and (not bf16 or mem_avail >= 3 * fp32_corpus) and rows_total * 16 * 12 < mem_avail:
+            # the workload's own N: the [nq x N] fp32 matrix + its int64 argsort do not fit at once for N = 10M, so
+            # 16 queries per call; every call re-normalises the corpus, as util.cos_sim does.  By default as many calls as
+            # fit in --cpu-baseline-seconds (at least one), --cpu-baseline-full: all of them
             c_s = np.concatenate([oracle.bf16_bits_to_f32(cache[c]) if bf16 else cache[c] for c in sorted(cache)], axis=0)[:rows_total]
-            t_cpu = 0.0
-            for q0 in range(0, nq, 16):                    # the [nq x N] fp32 matrix + int64 argsort do not fit at once
+            t_cpu, nq_timed = 0.0, 0
+            for q0 in range(0, nq, 16):
                 _, t_ = oracle.cpu_reference_topk(q_s[q0:q0 + 16], c_s, K, threads=ncpu)
                 t_cpu += t_
-            how = "query-chunked (16 at a time) over the whole corpus"
+                nq_timed += len(q_s[q0:q0 + 16])
+                if not args.cpu_baseline_full and t_cpu >= args.cpu_baseline_seconds:
+                    break
+            how = f"{nq_timed} of the batch's {nq} queries, 16 per call, over the whole corpus"
         else:
             nch = [c for c in sorted(cache) if c < 4]                     # up to 1M rows: ~10 s of host work at batch 256
             rows_s = np.concatenate([cache[c] for c in nch], axis=0)[: min(len(nch) * CH, rows_total)] if nch else cache[0]
             c_s = oracle.bf16_bits_to_f32(rows_s) if bf16 else rows_s
             # the oracle's port of the reference formulation: util.cos_sim + np.argsort(-S)[:, :10], all host cores
             _, t_cpu = oracle.cpu_reference_topk(q_s, c_s, K, threads=ncpu)
-            how = "one call"
-        cpu = {"value": round(nq / t_cpu, 3), "unit": "queries/s", "cores": ncpu, "kind": "port",
-               "rows": int(c_s.shape[0]),
-               "sample": f"MEASURED on {c_s.shape[0]} rows (of the workload's {rows_total}) x {nq} queries, {how}: fp32 torch-CPU "
+            how = f"all {nq} queries in one call (host memory did not allow the whole corpus: MemAvailable {mem_avail >> 30} GiB)"
+        cpu = {"value": round(nq_timed / t_cpu, 3), "unit": "queries/s", "cores": ncpu, "kind": "port",
+               "rows": int(c_s.shape[0]), "queries": int(nq_timed),
+               "sample": f"MEASURED on {c_s.shape[0]} rows (of the workload's {rows_total}), {how}: fp32 torch-CPU "
                          f"cos_sim (F.normalize both sides + mm) + np.argsort(-S)[:, :10] in {t_cpu:.2f}s on {ncpu} host cores; "
-                         f"not scaled to the full corpus"}
+                         f"nothing scaled"}
         del c_s
 
     if rank == 0:
@@ -388,6 +464,7 @@ def main():
             "recall_at_10": recall,
             "parity": parity,
             "search_stats": search_stats,
+            "sustained": sustained,
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

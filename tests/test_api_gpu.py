@@ -223,10 +223,11 @@ def test_comm_of_one_rank_runs_the_rccl_exchange(ts):
         lib.ts_comm_destroy(comm)
 
 
-def test_sharded_searcher_device_pipeline_with_changing_queries(ts):
+@pytest.mark.parametrize("pipeline", [1, 2])
+def test_sharded_searcher_device_pipeline_with_changing_queries(ts, pipeline):
     """ShardedSearcher.search_device - the loop bench.py times - with DIFFERENT queries every step (identical queries
-    would mask a result block that is read while it is rewritten): search on one stream, exchange + merge on the side
-    stream, double-buffered results."""
+    would mask a result block that is read while it is rewritten): search on one stream (pipeline 2: on the streams of
+    two handles in turn), exchange + merge on the side stream, double-buffered results."""
     import torch
     from theoremsearch_amd.distributed import ShardedSearcher
     n, nq, k = 150_000, 64, 10
@@ -235,7 +236,7 @@ def test_sharded_searcher_device_pipeline_with_changing_queries(ts):
     batches = [rng.standard_normal((nq, 768)).astype(np.float32) for _ in range(6)]
     with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as ix:
         want = [ix.search(b, k) for b in batches]
-        searcher = ShardedSearcher(index=ix)
+        searcher = ShardedSearcher(index=ix, pipeline=pipeline)
         dev = [torch.from_numpy(b).cuda() for b in batches]
         torch.cuda.synchronize()
         main = torch.cuda.Stream()

@@ -28,6 +28,10 @@ struct ScanArgs {
     u64* partial;         // [slot][gridDim.x][k] keys, descending
     float* scores;        // EMIT: [nq x n]
     const u32* row_mask;  // optional filter: bit (row & 31) of word row >> 5 set = the row may be returned
+    // optional additive per-row term (similarity + w * ln(citations), streamlit_app.py:351-358):
+    // a row is ranked by fmaf(bias_w, bias[row], score); the keys - and so the results - carry that biased score
+    const float* bias;
+    float bias_w;
     // one-launch form (the exact re-run of the MFMA path): the workgroup that finishes last reduces the partial lists
     // and writes the results, instead of a second launch (scan_finish)
     unsigned* done_ctr;   // NULL = partial lists only; else a zeroed counter, left zeroed
@@ -118,12 +122,24 @@ __device__ __forceinline__ void wg_merge_store(WaveTopK<KR>& tk, int k, u64* lds
 template <int KR>
 __device__ __forceinline__ void scan_finish(const ScanArgs& a, int count, u64* lds) {
     __shared__ int last_block;
-    __threadfence();
+    // hand-off between workgroups (MI355X_MICROARCH.md "inter-workgroup visibility"): every storing wave drains its
+    // stores, the workgroup meets, ONE lane releases at agent scope (L2 write-back; the explicit vmcnt wait keeps the
+    // ticket behind it - hipcc may drop its own), takes the ticket with an agent-scope atomic, and the lane that drew
+    // the last ticket acquires; the keys themselves are then read with agent-scope (L1-bypassing) loads
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) last_block = (atomicAdd(a.done_ctr, 1u) == gridDim.x - 1) ? 1 : 0;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned ticket = __hip_atomic_fetch_add(a.done_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_block = (ticket == gridDim.x - 1) ? 1 : 0;
+        if (last_block) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
     __syncthreads();
     if (!last_block) return;
-    __threadfence();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int64_t m = (int64_t)gridDim.x * a.k;
     for (int s = 0; s < count; ++s) {
@@ -220,10 +236,11 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanArgs a) {
                     for (int c = 0; c < CH; ++c) s = chunk_dot<DT>(v[r][c], qv[q][c], s);
                     acc[r] = s;
                 }
-                const float s = reduce4<G>(acc[0], acc[1], acc[2], acc[3], lane);
+                float s = reduce4<G>(acc[0], acc[1], acc[2], acc[3], lane);
                 if (EMIT) {
                     if (rep && row < a.n && g0 + q < count) a.scores[(int64_t)qid[q] * a.n + row] = s;
                 } else {
+                    if (a.bias && rep && row < a.n) s = fmaf(a.bias_w, a.bias[row], s);
                     const u64 key = (rep && row < a.n && s == s && allowed) ? make_key(s, (u32)row) : 0ull;
                     u64 m = __ballot(key > tk[q].thr);
                     while (m) {
@@ -301,10 +318,11 @@ __global__ void __launch_bounds__(256) scan_generic_kernel(ScanArgs a) {
             const bool allowed = !a.row_mask || (rep && row < a.n && ((a.row_mask[row >> 5] >> (row & 31)) & 1u));
 #pragma unroll
             for (int q = 0; q < QB; ++q) {
-                const float s = reduce4<64>(acc[q][0], acc[q][1], acc[q][2], acc[q][3], lane);
+                float s = reduce4<64>(acc[q][0], acc[q][1], acc[q][2], acc[q][3], lane);
                 if (EMIT) {
                     if (rep && row < a.n && g0 + q < count) a.scores[(int64_t)qid[q] * a.n + row] = s;
                 } else {
+                    if (a.bias && rep && row < a.n) s = fmaf(a.bias_w, a.bias[row], s);
                     const u64 key = (rep && row < a.n && s == s && allowed) ? make_key(s, (u32)row) : 0ull;
                     u64 m = __ballot(key > tk[q].thr);
                     while (m) {
@@ -325,6 +343,15 @@ __global__ void __launch_bounds__(256) scan_generic_kernel(ScanArgs a) {
     }
     if constexpr (!EMIT)
         if (a.done_ctr && count > 0) scan_finish<KR>(a, count, lds_keys);
+}
+
+// Raw similarity of biased results: sim = biased - w * bias[row] (one rounding away from the score the scan computed).
+__global__ void unbias_kernel(const float* scores, const int64_t* idx, const float* bias, float w, int64_t row_offset, float* sims,
+                              int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int64_t id = idx[i];
+    sims[i] = id < 0 ? -INFINITY : fmaf(-w, bias[id - row_offset], scores[i]);
 }
 
 // ---- rank of a given row ("rank of gold") -----------------------------------------------------------------

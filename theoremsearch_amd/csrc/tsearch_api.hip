@@ -108,6 +108,8 @@ struct ts_index {
     u64* partial = nullptr;     u64* partial2 = nullptr;     size_t partial_bytes = 0;
     float* res_scores = nullptr; int64_t* res_idx = nullptr; size_t res_cap = 0;  // device result buffers (entries)
     u32* mask_dev = nullptr;    size_t mask_bytes = 0;       // filtered search: device copy of a host bitmask
+    float* bias_dev = nullptr;  size_t bias_bytes = 0;       // biased search: device copy of a host bias array
+    const float* active_bias = nullptr; float active_bias_w = 0.f;   // per-row additive term of the search in progress (under `mu`)
     int64_t* id_map = nullptr;                               // subset index: local row -> global id
     bool borrowed = false;                                   // a view: rows / id_map belong to another handle
     bool attached = false;                                   // rows adopted from the caller (ts_index_attach_device): never freed here
@@ -335,7 +337,7 @@ extern "C" int ts_index_destroy(ts_index* ix) {
         if (ix->parent) ix->parent->nviews.fetch_sub(1);
     }
     if (ix->attached) ix->rows = nullptr;
-    void* ptrs[] = {ix->rows,  ix->stage,   ix->qstore,   ix->qf32,     ix->cand,       ix->count,  ix->thr, ix->priv, ix->pcount, ix->mask_dev, ix->rank_buf, ix->id_map,
+    void* ptrs[] = {ix->rows,  ix->stage,   ix->qstore,   ix->qf32,     ix->cand,       ix->count,  ix->thr, ix->priv, ix->pcount, ix->mask_dev, ix->bias_dev, ix->rank_buf, ix->id_map,
                     ix->fb_list, ix->fb_count, ix->stat, ix->partial, ix->partial2, ix->res_scores, ix->res_idx, ix->dbg, ix->part, ix->wg_ticks};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -869,6 +871,8 @@ static int scan_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
     a.k = k;
     a.partial = ix->partial;
     a.row_mask = ix->active_mask;
+    a.bias = ix->active_bias;
+    a.bias_w = ix->active_bias_w;
     // The exact re-run of the MFMA path (device-side query count, almost always zero) is ONE launch: the workgroup that
     // finishes last reduces the partial lists itself (scan_finish), so the common case pays one empty launch, not one per
     // select round as well.
@@ -1371,9 +1375,17 @@ static int scan_max_queries(const ts_index* ix, int k) {
     return ix->knobs.get(K_SCAN_MAX_QUERIES, 4);
 }
 
+struct BiasSpec {       // ts_search_biased: rank by score + weight * bias[row]
+    const float* bias = nullptr;
+    int on_device = 0;
+    float weight = 0.f;
+    float* out_sims = nullptr;   // optional: raw similarities of the results, where the scores go
+};
+
 static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_device, int32_t nq, int32_t k,
                        float* out_scores, int64_t* out_idx, int out_on_device, void* stream, int algo,
-                       ts_search_stats* stats, const uint32_t* row_mask = nullptr, int mask_on_device = 0) {
+                       ts_search_stats* stats, const uint32_t* row_mask = nullptr, int mask_on_device = 0,
+                       const BiasSpec* bias = nullptr) {
     if (stats) memset(stats, 0, sizeof(*stats));
     if (!ix || !queries || !out_scores || !out_idx) return fail(TS_ERR_INVALID, "NULL argument");
     if (q_dtype != TS_F32 && q_dtype != TS_BF16) return fail(TS_ERR_INVALID, "q_dtype %d", q_dtype);
@@ -1390,10 +1402,26 @@ static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_
     StreamScope scope;
     TS_TRY(enter_stream(ix, stream, &st, &scope));
     TS_TRY(ensure_search_scratch(ix, k));
-    struct MaskScope {  // the bitmask is a property of this call only
+    struct MaskScope {  // the bitmask and the bias are properties of this call only
         ts_index* ix;
-        ~MaskScope() { ix->active_mask = nullptr; }
+        ~MaskScope() { ix->active_mask = nullptr; ix->active_bias = nullptr; }
     } mask_scope{ix};
+    if (bias) {
+        // the additive term is applied where the row is known and the key is made: the scan kernel (four queries per pass at
+        // the HBM rate).  The matrix kernels test a whole accumulator tile against one threshold per query; a per-row term
+        // of the size of w * ln(citations) (several standard deviations of the scores) leaves no threshold that prunes.
+        if (ix->id_map) return fail(TS_ERR_UNSUPPORTED, "biased search on a subset index");
+        if (algo == TS_ALGO_MFMA) return fail(TS_ERR_UNSUPPORTED, "the biased search runs on the scan kernel");
+        algo = TS_ALGO_SCAN;
+        if (bias->on_device) {
+            ix->active_bias = bias->bias;
+        } else {
+            TS_TRY(ensure((void**)&ix->bias_dev, &ix->bias_bytes, std::max<size_t>((size_t)ix->n * 4, 4)));
+            HIP_TRY(hipMemcpyAsync(ix->bias_dev, bias->bias, (size_t)ix->n * 4, hipMemcpyHostToDevice, st));
+            ix->active_bias = ix->bias_dev;
+        }
+        ix->active_bias_w = bias->weight;
+    }
     if (row_mask) {
         const size_t words = (size_t)((ix->n + 31) / 32);
         if (mask_on_device) {
@@ -1457,7 +1485,7 @@ static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_
         // streamlit_app.py:173, app_showcase_model.py:92; configs[1]): nothing to normalise, round or pad - the scan
         // reads the query where it is (device) or where the copy puts it (host).  No preparation launch.
         if (use == TS_ALGO_SCAN && nb == 1 && nq == 1 && q_dtype == TS_F32 && ix->dtype == TS_F32 &&
-            ix->metric == TS_METRIC_IP && ix->ld == ix->d) {
+            ix->metric == TS_METRIC_IP && ix->ld == ix->d && ((uintptr_t)qsrc & 3) == 0) {
             const float* qb = (const float*)qsrc;
             if (!q_on_device) {
                 HIP_TRY(hipMemcpyAsync(ix->qf32, qsrc, (size_t)ix->d * 4, hipMemcpyHostToDevice, st));
@@ -1484,6 +1512,18 @@ static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_
                              nb, kQBlock, st));
         if (use == TS_ALGO_MFMA) TS_TRY(mfma_search(ix, nb, k, os, oi, st, stats, ix->qstore, false));
         else TS_TRY(scan_search(ix, nb, k, os, oi, nullptr, nullptr, st));
+    }
+    DevBuf sims_tmp;
+    if (bias && bias->out_sims) {
+        float* dsims = bias->out_sims;
+        const int64_t cnt = (int64_t)nq * k;
+        if (!out_on_device) {
+            HIP_TRY(sims_tmp.alloc((size_t)cnt * 4));
+            dsims = sims_tmp.as<float>();
+        }
+        unbias_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, st>>>(dscores, didx, ix->active_bias, ix->active_bias_w, ix->row_offset, dsims, cnt);
+        HIP_TRY(hipGetLastError());
+        if (!out_on_device) HIP_TRY(hipMemcpyAsync(bias->out_sims, dsims, (size_t)cnt * 4, hipMemcpyDeviceToHost, st));
     }
     if (!out_on_device) {
         HIP_TRY(hipMemcpyAsync(out_scores, dscores, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
@@ -1531,6 +1571,20 @@ extern "C" int ts_search_filtered_ex(ts_index* ix, const void* queries, int q_dt
     if (!row_mask) return fail(TS_ERR_INVALID, "row_mask is NULL");
     return search_impl(ix, queries, q_dtype, q_on_device, nq, k, out_scores, out_idx, out_on_device, stream, algo, stats,
                        row_mask, mask_on_device);
+}
+
+extern "C" int ts_search_biased(ts_index* ix, const void* queries, int q_dtype, int q_on_device, int32_t nq, int32_t k,
+                                const float* bias, int bias_on_device, float weight, const uint32_t* row_mask, int mask_on_device,
+                                float* out_scores, float* out_sims, int64_t* out_idx, int out_on_device, void* stream) {
+    if (!bias) return fail(TS_ERR_INVALID, "bias is NULL");
+    if (!(weight == weight) || std::isinf(weight)) return fail(TS_ERR_INVALID, "weight must be finite");
+    BiasSpec b;
+    b.bias = bias;
+    b.on_device = bias_on_device;
+    b.weight = weight;
+    b.out_sims = out_sims;
+    return search_impl(ix, queries, q_dtype, q_on_device, nq, k, out_scores, out_idx, out_on_device, stream, TS_ALGO_AUTO, nullptr,
+                       row_mask, mask_on_device, &b);
 }
 
 template <int DT, int CH, int G>

@@ -169,6 +169,17 @@ class TheoremIndex:
     def handle(self) -> C.c_void_p:
         return self._h
 
+    def info(self) -> dict:
+        """Shape and placement of the rows as the kernels see them (``ts_index_info``): ``ld`` = row stride in
+        elements, ``rows_ptr`` = device address of row 0."""
+        n, ld, off = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        d, dt, me = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        rows = C.c_void_p()
+        _ffi.check(self._lib.ts_index_info(self._h, C.byref(n), C.byref(d), C.byref(dt), C.byref(me), C.byref(ld), C.byref(off),
+                                           C.byref(rows)))
+        return {"n": n.value, "d": d.value, "dtype": dt.value, "metric": me.value, "ld": ld.value, "row_offset": off.value,
+                "rows_ptr": rows.value or 0}
+
     # -- search -----------------------------------------------------------------------------
     def search(self, queries, k: int, algo: str = "auto", return_stats: bool = False, mask=None):
         """Exact top-k.  Returns ``(scores [nq x k] float32, indices [nq x k] int64)`` ordered by
