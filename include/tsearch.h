@@ -24,8 +24,10 @@
  *     that lives on the default stream of the caller (torch.cuda.current_stream().cuda_stream is 0
  *     there).  A call that arrives on a different stream than the previous call on the same handle
  *     is ordered behind that call by the library (the handle's scratch buffers are shared); for
- *     that the library records an event on the previous call's stream, so a caller-owned stream
- *     must stay alive until the next call on the handle or until ts_index_synchronize has returned.
+ *     that the library records an event at the END of every call on the stream of that call and never touches
+ *     that stream again: a caller-owned stream may be destroyed as soon as the caller's own work on it is done.
+ *   - device queries may be read in place (no copy is made when they already have the form the kernels multiply):
+ *     they must stay unchanged until the work the call enqueued has run.
  *   - one handle may be used from several threads (the Streamlit apps share one model and one
  *     library across session threads, streamlit_app.py:52); calls on one handle are serialised
  *     inside, different handles are independent.
@@ -95,6 +97,10 @@ int ts_index_destroy(ts_index *ix);
 int ts_index_set_row_offset(ts_index *ix, int64_t row_offset);
 /* The index's own HIP stream (hipStream_t as void*): what stream = NULL means in the calls below. */
 int ts_index_stream(const ts_index *ix, void **stream);
+/* Makes `stream` (hipStream_t as void*, not NULL) wait for the end of the LAST call on this handle, whatever stream that
+ * call ran on (stream-ordered, no host wait): a side stream that consumes a search's device results - the exchange + merge
+ * of the sharded search - needs no event of its own on the search's stream. */
+int ts_index_wait_order(ts_index *ix, void *stream);
 /* Waits until everything this handle has enqueued (on its own stream and on the stream of its last call) is done. */
 int ts_index_synchronize(ts_index *ix);
 int ts_index_info(const ts_index *ix, int64_t *n, int32_t *d, int32_t *dtype, int32_t *metric,
@@ -188,6 +194,20 @@ int ts_search_filtered(ts_index *ix, const void *queries, int q_dtype, int q_on_
 int ts_search_filtered_ex(ts_index *ix, const void *queries, int q_dtype, int q_on_device, int32_t nq, int32_t k,
                           const uint32_t *row_mask, int mask_on_device, float *out_scores, int64_t *out_idx,
                           int out_on_device, void *stream, int algo, ts_search_stats *stats);
+
+/* Top-k of  score(row) + weight * bias[row]  over ALL rows of the index (or all rows row_mask allows; row_mask may be NULL):
+ * the citation-weighted ranking of streamlit_app.py:348-364 -
+ *     weighted_score = similarity + w * CASE WHEN citations > 0 THEN ln(citations) ELSE 0 END   ORDER BY weighted_score DESC
+ * - computed over the whole corpus instead of over the max(50, 10 k) nearest rows the SQL ranks (streamlit_app.py:317): the
+ * pool form misses a heavily cited theorem that is not among the 10 k nearest; this one cannot (SURVEY.md section 8f rank 4:
+ * "score + w * ln(citations) as a fused per-row bias, one fp32 side array").  bias: float[n] in host or device memory, one
+ * value per row of THIS index (the caller puts ln(citations) or 0 there); the term is added in fp32 where the key of a row
+ * is made (fmaf(weight, bias[row], score)), so the order is weighted score descending, then row ascending.  out_scores
+ * receives the weighted scores, out_sims (optional, same shape and place) the raw similarities.  Runs on the scan kernel
+ * (four queries per pass at the HBM rate; n * 4 more bytes per pass); not on subset indexes. */
+int ts_search_biased(ts_index *ix, const void *queries, int q_dtype, int q_on_device, int32_t nq, int32_t k,
+                     const float *bias, int bias_on_device, float weight, const uint32_t *row_mask, int mask_on_device,
+                     float *out_scores, float *out_sims, int64_t *out_idx, int out_on_device, void *stream);
 
 /* Rank of one given row per query in the canonical order of that query's scores over the whole index (0 = best):
  * the number of rows whose (score, -row) beats the target's.  One streaming pass that counts; replaces ranking the

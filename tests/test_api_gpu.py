@@ -369,3 +369,73 @@ def test_the_product_library_refuses_timing_only_kernel_variants(ts):
             assert e.value.code == -5
         ix.set_option("TS_MFMA_VARIANT", 0)
         ix.set_option("TS_MFMA_VARIANT", None)
+
+
+# ---- citation-weighted ranking on the device ------------------------------------------------
+@pytest.mark.parametrize("dtype,d", [("f32", 1024), ("bf16", 768), ("f32", 200)])
+def test_biased_search_is_the_citation_weighted_ranking_over_all_rows(ts, dtype, d):
+    """ts_search_biased against the oracle's restatement of streamlit_app.py:348-364 with the pool widened to the whole
+    corpus: weighted = similarity + w * ln(citations) (0 for NULL / <= 0), ORDER BY weighted DESC, similarity DESC.
+    Citation counts: None, 0, 1, small, and a few enormous ones that lift far-away rows into the answer (rows the
+    reference's max(50, 10 k) pool never sees)."""
+    from theoremsearch_amd import pgvector
+    n, nq, k, w = 20_000, 6, 10, 0.02
+    q, c = oracle.golden_inputs(n, nq, d, 300 + d, "ip")
+    rng = np.random.default_rng(9)
+    cites = [None if u < 0.1 else (0 if u < 0.2 else int(v)) for u, v in zip(rng.random(n), rng.integers(1, 400, n))]
+    for r in rng.choice(n, 12, replace=False):
+        cites[int(r)] = int(10 ** rng.integers(6, 9))          # w * ln(1e8) = 0.37: ten standard deviations of the scores
+    bias = pgvector.citation_bias(cites)
+    qp, cp = oracle.prepared_inputs(q, c, "ip", dtype)
+    sim64 = oracle.scores_fp64(qp, cp)                           # fp64 similarities of what the index multiplies
+    with ts.TheoremIndex.from_embeddings(c, dtype=dtype, metric="ip") as ix:
+        ws, sims, idx = ix.search_biased(q, k, bias, w)
+        assert idx.min() >= 0
+        for b in range(nq):
+            weighted64 = sim64[b] + w * bias.astype(np.float64)
+            want_i, want_sim, want_w = oracle.citation_weighted_rerank(np.arange(n), sim64[b], cites, w, k)
+            got_w = weighted64[idx[b]]
+            # pinned ranks (fp64 gap > 1e-6 on both sides) must match exactly, the rest as sets; scores within 1e-5
+            gaps = want_w[:-1] - want_w[1:]
+            for r in range(k):
+                lo = gaps[r - 1] if r else np.inf
+                hi = gaps[r] if r < k - 1 else np.inf
+                if lo > 1e-6 and hi > 1e-6 and r < k - 1:
+                    assert idx[b, r] == want_i[r], (dtype, b, r)
+            assert np.all(got_w >= want_w[-1] - 1e-6)
+            assert np.allclose(ws[b], want_w, atol=1e-5) and np.allclose(sims[b], sim64[b][idx[b]], atol=1e-5)
+        assert np.intersect1d(idx[0], np.flatnonzero(bias > 10)).size > 0       # the heavily cited rows made it
+        # w = 0 is the plain search
+        z_s, z_sim, z_i = ix.search_biased(q, k, bias, 0.0)
+        p_s, p_i = ix.search(q, k, algo="scan")
+        assert np.array_equal(z_i, p_i) and np.array_equal(z_s, p_s) and np.array_equal(z_sim, p_s)
+        # with a WHERE-clause mask: the k best allowed rows by weighted score
+        mask = rng.random(n) < 0.4
+        m_s, m_sim, m_i = ix.search_biased(q, k, bias, w, mask=mask)
+        assert mask[m_i].all()
+        keep = np.flatnonzero(mask)
+        for b in range(nq):
+            weighted64 = sim64[b] + w * bias.astype(np.float64)
+            best = np.sort(weighted64[keep])[::-1][:k]
+            assert np.allclose(m_s[b], best, atol=1e-5)
+
+
+def test_pgvector_adapter_exact_form_equals_the_pool_form_when_the_pool_holds_the_answer(ts):
+    """pgvector.search(..., exact=True) (the kernel over all rows) returns what the reference's pool form returns whenever
+    the max(50, 10 k) nearest rows contain the weighted top-k - small citation counts - and differs, correctly, when a
+    heavily cited theorem lies outside the pool."""
+    from theoremsearch_amd import pgvector
+    n, d, k = 8_000, 768, 5
+    q, c = oracle.golden_inputs(n, 1, d, 77, "ip")
+    rng = np.random.default_rng(3)
+    cites = [int(v) for v in rng.integers(1, 4, n)]              # ln <= 1.1: with w = 0.001 a nudge among near neighbours
+    with ts.TheoremIndex.from_embeddings(c, dtype="f32", metric="ip") as ix:
+        pool = pgvector.search(ix, q[0], k, citation_weight=0.001, citations=cites)
+        exact = pgvector.search(ix, q[0], k, citation_weight=0.001, citations=cites, exact=True)
+        assert [r["row"] for r in exact] == [r["row"] for r in pool]
+        assert np.allclose([r["score"] for r in exact], [r["score"] for r in pool], atol=1e-5)
+        far = int(np.argsort(oracle.scores_fp64(*oracle.prepared_inputs(q, c, "ip", "f32"))[0])[n // 2])   # a median row
+        cites[far] = 10 ** 9
+        pool = pgvector.search(ix, q[0], k, citation_weight=0.05, citations=cites)
+        exact = pgvector.search(ix, q[0], k, citation_weight=0.05, citations=cites, exact=True)
+        assert exact[0]["row"] == far and far not in [r["row"] for r in pool]

@@ -46,6 +46,7 @@ _SIGNATURES = {
     "ts_index_destroy": (C.c_int, [C.c_void_p]),
     "ts_index_set_row_offset": (C.c_int, [C.c_void_p, C.c_int64]),
     "ts_index_synchronize": (C.c_int, [C.c_void_p]),
+    "ts_index_wait_order": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ts_index_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "ts_index_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                 C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
@@ -72,6 +73,8 @@ _SIGNATURES = {
                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ts_search_filtered_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(SearchStats)]),
+    "ts_search_biased": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_int, C.c_float,
+                                   C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ts_rank_of": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p]),
     "ts_count_above": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -434,6 +434,16 @@ extern "C" int ts_index_synchronize(ts_index* ix) {
     return TS_OK;
 }
 
+// `stream` waits for the end of the last call on this handle (its order event): how a caller's side stream picks up the
+// results of a search without recording an event of its own on the search's stream (one marker packet less per step).
+extern "C" int ts_index_wait_order(ts_index* ix, void* stream) {
+    if (!ix) return fail(TS_ERR_INVALID, "index is NULL");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    if (ix->ordered && ix->order_ev && ix->last_stream != (hipStream_t)stream) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ix->order_ev, 0));
+    return TS_OK;
+}
+
 extern "C" int ts_index_stream(const ts_index* ix, void** stream) {
     if (!ix || !stream) return fail(TS_ERR_INVALID, "NULL argument");
     *stream = (void*)ix->stream;

@@ -179,6 +179,7 @@ class ShardedSearcher:
 
     # -- the device pipeline (what bench.py times) -----------------------------------------------------------------
     _MAX_SHAPES = 4      # (nq, k) shapes whose exchange buffers are kept (least recently used goes first)
+    _NBUF = 4            # result blocks in rotation: a search rewrites the block the exchange of four calls ago has read
 
     def _device_buffers(self, nq: int, k: int):
         import torch
@@ -194,15 +195,15 @@ class ShardedSearcher:
                 for e, used in zip(old["done"], old["used"]):
                     if used:
                         e.synchronize()                           # its buffers may still be read by an exchange in flight
+            nb = self._NBUF
             b = {
-                "mine": [torch.empty(blk, dtype=torch.uint8, device=dev) for _ in range(2)],
-                "all": [torch.empty(self.world * blk, dtype=torch.uint8, device=dev) for _ in range(2)],
-                "fin_s": [torch.empty((nq, k), dtype=torch.float32, device=dev) for _ in range(2)],
-                "fin_i": [torch.empty((nq, k), dtype=torch.int64, device=dev) for _ in range(2)],
-                "ready": [torch.cuda.Event() for _ in range(2)],
-                "searched": [torch.cuda.Event() for _ in range(2)],
-                "done": [torch.cuda.Event() for _ in range(2)],
-                "used": [False, False],
+                "mine": [torch.empty(blk, dtype=torch.uint8, device=dev) for _ in range(nb)],
+                "all": [torch.empty(self.world * blk, dtype=torch.uint8, device=dev) for _ in range(nb)],
+                "fin_s": [torch.empty((nq, k), dtype=torch.float32, device=dev) for _ in range(nb)],
+                "fin_i": [torch.empty((nq, k), dtype=torch.int64, device=dev) for _ in range(nb)],
+                "ready": [torch.cuda.Event() for _ in range(nb)],
+                "done": [torch.cuda.Event() for _ in range(nb)],
+                "used": [False] * nb,
             }
         self._bufs[key] = b                                       # most recently used last
         return b
@@ -227,28 +228,31 @@ class ShardedSearcher:
         ``torch.cuda.Stream``; default: the current one - the queries must be ready there): the local search (on that
         stream, or with ``pipeline`` > 1 on the stream of the handle whose turn it is), then the exchange + merge on a
         side stream, so that they overlap the next call's search (``overlap=False``: everything on ``stream``).  Returns
-        ``(scores, idx, done)``: merged global results as device tensors ``[nq x k]`` (double-buffered: valid until
-        the second-next call) and the ``torch.cuda.Event`` that marks them complete."""
+        ``(scores, idx, done)``: merged global results as device tensors ``[nq x k]`` (four blocks in rotation: valid
+        until the fourth-next call) and the ``torch.cuda.Event`` that marks them complete.
+        Marker packets cost the search's stream a few microseconds each (a 1.25M-row shard's step is 0.5 ms), so the
+        search's stream carries none of this class's: the side stream waits on the library's own end-of-call event
+        (``ts_index_wait_order``), and the wait for the block's previous reader is skipped when that reader is known
+        to be done (``Event.query``)."""
         import torch
         from . import _ffi
         lib = _ffi.load()
         main = stream or torch.cuda.current_stream(self.index.device)
         b = self._device_buffers(nq, k)
         ix, lane, own_stream = self._lane(main) if overlap else (self.index, main, False)
-        p = self._step & 1
+        p = self._step % self._NBUF
         self._step += 1
         if own_stream:
             b["ready"][p].record(main)                 # the queries are complete on the caller's stream
             lane.wait_event(b["ready"][p])
-        if b["used"][p]:
-            lane.wait_event(b["done"][p])              # the exchange of the call before last has consumed mine[p]
+        if b["used"][p] and not b["done"][p].query():
+            lane.wait_event(b["done"][p])              # the exchange of four calls ago has not consumed mine[p] yet
         blk, off = packed_bytes(nq, k), packed_idx_off(nq, k)
         base = b["mine"][p].data_ptr()
         ix.search_device(q_ptr, q_dtype, nq, k, base, base + off, lane.cuda_stream, algo=algo, mask_ptr=mask_ptr)
         side = self._side if overlap else main
         if overlap:
-            b["searched"][p].record(lane)
-            side.wait_event(b["searched"][p])
+            _ffi.check(lib.ts_index_wait_order(ix.handle, C.c_void_p(side.cuda_stream)))   # behind the search just enqueued
         if self.world == 1:
             src = b["mine"][p]
         else:

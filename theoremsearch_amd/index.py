@@ -230,6 +230,33 @@ class TheoremIndex:
                                           C.c_void_p(out_scores_ptr), C.c_void_p(out_idx_ptr), 1,
                                           C.c_void_p(stream), _ALGOS[algo], None))
 
+    def search_biased(self, queries, k: int, bias, weight: float, mask=None):
+        """Top-k of ``score + weight * bias[row]`` over all rows (all rows ``mask`` allows): the citation-weighted
+        ranking of streamlit_app.py:348-364 without its candidate pool.  ``bias``: float32 per row of this index.
+        Returns ``(weighted scores, raw similarities, indices)``, each ``[nq x k]``."""
+        q = _host_rows(queries)
+        if q.shape[1] != self.d:
+            raise ValueError(f"queries have d={q.shape[1]}, index has d={self.d}")
+        b = np.ascontiguousarray(np.asarray(bias, dtype=np.float32).reshape(-1))
+        if b.shape[0] != self.n:
+            raise ValueError(f"bias has {b.shape[0]} entries, index has {self.n} rows")
+        nq, k = q.shape[0], int(k)
+        scores = np.empty((nq, k), dtype=np.float32)
+        sims = np.empty((nq, k), dtype=np.float32)
+        idx = np.empty((nq, k), dtype=np.int64)
+        words = None
+        if mask is not None:
+            m = np.asarray(mask, dtype=bool).reshape(-1)
+            if m.shape[0] != self.n:
+                raise ValueError(f"mask has {m.shape[0]} entries, index has {self.n} rows")
+            bits = np.packbits(m, bitorder="little")
+            words = np.zeros((self.n + 31) // 32 * 4, dtype=np.uint8)
+            words[: bits.shape[0]] = bits
+        _ffi.check(self._lib.ts_search_biased(self._h, _ffi.as_ptr(q), _ffi.np_dtype_code(q), 0, nq, k, _ffi.as_ptr(b), 0,
+                                              float(weight), _ffi.as_ptr(words) if words is not None else None, 0,
+                                              _ffi.as_ptr(scores), _ffi.as_ptr(sims), _ffi.as_ptr(idx), 0, None))
+        return scores, sims, idx
+
     def rank_of(self, queries, rows) -> Tuple[np.ndarray, np.ndarray]:
         """0-based rank of ``rows[i]`` among all index rows for query ``i`` (score descending, index ascending)
         and its score: what ``np.flatnonzero(np.argsort(-sim[i]) == rows[i])`` yields on the full score matrix

@@ -79,17 +79,41 @@ def pool_size(top_k: int) -> int:
     return max(50, int(top_k) * 10)  # streamlit_app.py:317
 
 
+def citation_bias(citations: Sequence[Optional[int]]) -> np.ndarray:
+    """``CASE WHEN citations IS NOT NULL AND citations > 0 THEN ln(citations::float) ELSE 0 END`` per row
+    (streamlit_app.py:353-357) as the fp32 side array `TheoremIndex.search_biased` takes."""
+    return np.array([math.log(float(c)) if (c is not None and c > 0) else 0.0 for c in citations], dtype=np.float32)
+
+
 def search(index: TheoremIndex, query_vec, top_k: int, citation_weight: float = 0.0,
-           citations: Optional[Sequence[Optional[int]]] = None, mask=None):
+           citations: Optional[Sequence[Optional[int]]] = None, mask=None, exact: bool = False, bias=None):
     """Returns a list of dicts ``{"row", "similarity", "score"}`` ordered like the SQL result.  ``mask`` (bool per row,
-    e.g. `filters.sql_filter_mask`) plays the WHERE clause: only those rows are ranked."""
+    e.g. `filters.sql_filter_mask`) plays the WHERE clause: only those rows are ranked.
+    ``exact=False`` (default) is the reference's form: the ``max(50, 10 k)`` nearest rows re-ranked by the weighted score.
+    ``exact=True`` ranks EVERY (allowed) row by the weighted score on the device (``ts_search_biased``): the same answer
+    whenever the pool holds it, and the right one when a heavily cited theorem sits outside the pool; ``bias`` may carry
+    a ready-made `citation_bias` array for repeated searches."""
     q = np.asarray(query_vec, dtype=np.float32).reshape(1, -1)
     if citation_weight == 0.0:
         scores, idx = index.search(q, int(top_k), mask=mask)
         return [{"row": int(i), "similarity": 1.0 + float(s), "score": 1.0 + float(s)}
                 for s, i in zip(scores[0], idx[0]) if i >= 0]
-    if citations is None:
+    if citations is None and bias is None:
         raise ValueError("citation-weighted search needs the per-row citation counts")
+    if exact:
+        b = citation_bias(citations) if bias is None else np.asarray(bias, dtype=np.float32)
+        _, sims, idx = index.search_biased(q, int(top_k), b, float(citation_weight), mask=mask)
+        rows = []
+        for s, i in zip(sims[0], idx[0]):
+            if i < 0:
+                continue
+            sim = 1.0 + float(s)
+            rows.append({"row": int(i), "similarity": sim,
+                         "score": sim + citation_weight * float(b[int(i) - index.row_offset])})
+        rows.sort(key=lambda r: (-r["score"], -r["similarity"]))
+        return rows
+    if citations is None:
+        raise ValueError("the pool form re-ranks by the citation counts themselves")
     pool = pool_size(top_k)                      # max(50, 10 k): the reference's slider stops at k = 20 -> 200
     if pool > _ffi.TS_MAX_K:
         raise ValueError(f"citation pool of {pool} rows (top_k = {top_k}) exceeds the library's k limit of {_ffi.TS_MAX_K}; "
