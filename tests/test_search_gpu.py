@@ -619,3 +619,28 @@ def test_small_fp32_batches_stay_on_the_scan(ts):
         ix.set_option("TS_MFMA_F32", 0)
         _, _, st = ix.search(np.tile(q, (3, 1)), 10, return_stats=True)
         assert st["algo"] == 1
+
+
+@pytest.mark.parametrize("dtype,d,n,nq,k", [("bf16", 768, 300_000, 256, 10), ("bf16", 1024, 150_000, 100, 50), ("bf16", 384, 90_000, 70, 10),
+                                           ("f32", 768, 120_000, 128, 10), ("f32", 1024, 80_000, 33, 200)])
+def test_dense_threshold_sample_and_the_list_form_give_the_same_answers(ts, dtype, d, n, nq, k):
+    """Round 3: the threshold sample is a dense score matrix from a kernel of its own (kernels_sample.h) + one select per
+    query; round 2's form (the full-pass kernel over the sample, candidates gathered from lane-private lists) stays
+    selectable (TS_MFMA_SAMPLE=0).  Both feed the same estimates; the answers are exact and identical either way, also
+    behind a row mask (the sample sees the allowed rows only)."""
+    q, c = oracle.golden_inputs(n, nq, d, 500 + d + nq, "ip")
+    mask = np.random.default_rng(8).random(n) < 0.5
+    with ts.TheoremIndex.from_embeddings(c, dtype=dtype, metric="ip") as ix:
+        s1, i1, st1 = ix.search(q, k, algo="mfma", return_stats=True)
+        m1 = ix.search(q, k, algo="mfma", mask=mask)
+        ix.set_option("TS_MFMA_SAMPLE", 0)
+        s0, i0, st0 = ix.search(q, k, algo="mfma", return_stats=True)
+        m0 = ix.search(q, k, algo="mfma", mask=mask)
+        ix.set_option("TS_MFMA_SAMPLE", None)
+        assert st1["algo"] == st0["algo"] == 2 and st1["levels"] == st0["levels"]
+        assert st1["fallback_queries"] == 0 and st0["fallback_queries"] == 0
+        assert np.array_equal(i1, i0) and np.array_equal(s1, s0)
+        assert np.array_equal(m1[1], m0[1]) and np.array_equal(m1[0], m0[0]) and mask[m1[1]].all()
+        # the two samples see the same rows: candidate counts of the full pass agree to within the estimates' noise
+        assert 0.5 < st1["candidates"] / max(1, st0["candidates"]) < 2.0, (st1, st0)
+        check(q, c, "ip", dtype, k, s1, i1)

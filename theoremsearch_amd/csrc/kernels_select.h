@@ -306,6 +306,48 @@ __device__ __forceinline__ void rebalance_tiles(const LevelArgs& a, double* tmp)
     }
 }
 
+// Pass threshold of the next level from the kl best keys of a sample (`best`, sorted descending; cnt keys were sampled;
+// mean / sd of all sampled scores).  Shared by level_select_kernel (candidate lists of a sample level) and
+// sample_select_kernel (the dense sample matrix).
+__device__ __forceinline__ float level_threshold(const LevelArgs& a, const u64* best, int cnt, int kk, bool tail_fit, double mean,
+                                                 double sd) {
+    constexpr int kTailM = 32;
+    // the kk-th best of a sample is a lower bound of the final kk-th best: a guaranteed threshold (any subset
+    // of the candidates still gives a valid bound, so lost candidates are harmless here)
+    const u64 kth = best[kk - 1];
+    float thr = kth ? key_score(kth) : -INFINITY;
+    // Heavier-than-Gaussian tails (clusters of near-duplicates: real corpora) make the Gaussian estimate far too
+    // low and the full pass would drown in candidates.  Second estimate, from the sample's order statistics 8..32
+    // (the top 7 are left out: outliers must not set the slope): an exponential tail fitted to their spacings
+    // (E[x_j - x_32] = e * sum_{i=j}^{31} 1/i) and extrapolated to the exceedance probability tail_p, which the
+    // host sets for ~2048 expected candidates - a quarter of the buffer, far above k - and only for corpora so large
+    // that the guaranteed bound alone would swamp the buffer.  It is used only where the sample SHOWS a heavy tail:
+    // its 32nd best lies more than half a standard deviation above where a Gaussian with the sample's mean and
+    // variance puts it.  On Gaussian-like scores the fit is therefore never consulted - extrapolated over
+    // ln(N / sample) it is noisier than the Gaussian estimate, and at 50M rows its overshoots sent one query per
+    // batch to the exact re-run (an 11 ms scan pass per step, measured).  Like the Gaussian estimate it is only an
+    // estimate that the final level verifies.
+    float thr_tail = -INFINITY, x_m = -INFINITY;
+    if (tail_fit && cnt >= 1024 && best[kTailM - 1] != 0ull) {
+        x_m = key_score(best[kTailM - 1]);
+        float spacing = 0.0f;
+        for (int j = 8; j < kTailM; ++j) spacing += key_score(best[j - 1]) - x_m;
+        const float e = spacing * (1.0f / 13.95928363f);
+        const float ratio = ((float)kTailM / (float)cnt) / a.tail_p;  // how far beyond the sample's 32nd best
+        if (ratio > 1.0f && e > 0.0f) thr_tail = x_m + e * __logf(ratio);
+    }
+    if (a.z_tail > 0.0f && cnt >= 256) {
+        // ... and usually far too low for the next level when that level is much bigger.  The scores of one
+        // query over the corpus are close to Gaussian (normalised, high-dimensional rows), so the sample's
+        // mean + z * std estimates the score that only the wanted number of rows exceed.  NOT a bound: the
+        // final level checks that at least min_fill candidates came back and re-runs the query exactly if not.
+        thr = fmaxf(thr, (float)(mean + (double)a.z_tail * sd));
+        const bool heavy_tail = (double)x_m > mean + ((double)a.tail_z + 0.5) * sd;
+        if (heavy_tail) thr = fmaxf(thr, thr_tail);
+    }
+    return thr;
+}
+
 template <int KR>
 __global__ void __launch_bounds__(kLevelThreads) level_select_kernel(LevelArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -374,39 +416,7 @@ __global__ void __launch_bounds__(kLevelThreads) level_select_kernel(LevelArgs a
 
     if (threadIdx.x == 0) a.count[q] = 0;
     if (!a.final_level) {
-        // the kk-th best of a sample is a lower bound of the final kk-th best: a guaranteed threshold (any subset
-        // of the candidates still gives a valid bound, so `lost` is harmless here)
-        const u64 kth = best[kk - 1];
-        float thr = kth ? key_score(kth) : -INFINITY;
-        // Heavier-than-Gaussian tails (clusters of near-duplicates: real corpora) make the Gaussian estimate far too
-        // low and the full pass would drown in candidates.  Second estimate, from the sample's order statistics 8..32
-        // (the top 7 are left out: outliers must not set the slope): an exponential tail fitted to their spacings
-        // (E[x_j - x_32] = e * sum_{i=j}^{31} 1/i) and extrapolated to the exceedance probability tail_p, which the
-        // host sets for ~2048 expected candidates - a quarter of the buffer, far above k - and only for corpora so large
-        // that the guaranteed bound alone would swamp the buffer.  It is used only where the sample SHOWS a heavy tail:
-        // its 32nd best lies more than half a standard deviation above where a Gaussian with the sample's mean and
-        // variance puts it.  On Gaussian-like scores the fit is therefore never consulted - extrapolated over
-        // ln(N / sample) it is noisier than the Gaussian estimate, and at 50M rows its overshoots sent one query per
-        // batch to the exact re-run (an 11 ms scan pass per step, measured).  Like the Gaussian estimate it is only an
-        // estimate that the final level verifies.
-        float thr_tail = -INFINITY, x_m = -INFINITY;
-        if (tail_fit && cnt >= 1024 && best[kTailM - 1] != 0ull) {
-            x_m = key_score(best[kTailM - 1]);
-            float spacing = 0.0f;
-            for (int j = 8; j < kTailM; ++j) spacing += key_score(best[j - 1]) - x_m;
-            const float e = spacing * (1.0f / 13.95928363f);
-            const float ratio = ((float)kTailM / (float)cnt) / a.tail_p;  // how far beyond the sample's 32nd best
-            if (ratio > 1.0f && e > 0.0f) thr_tail = x_m + e * __logf(ratio);
-        }
-        if (a.z_tail > 0.0f && cnt >= 256) {
-            // ... and usually far too low for the next level when that level is much bigger.  The scores of one
-            // query over the corpus are close to Gaussian (normalised, high-dimensional rows), so the sample's
-            // mean + z * std estimates the score that only the wanted number of rows exceed.  NOT a bound: the
-            // final level checks that at least min_fill candidates came back and re-runs the query exactly if not.
-            thr = fmaxf(thr, (float)(mean + (double)a.z_tail * sd));
-            const bool heavy_tail = (double)x_m > mean + ((double)a.tail_z + 0.5) * sd;
-            if (heavy_tail) thr = fmaxf(thr, thr_tail);
-        }
+        const float thr = level_threshold(a, best, cnt, kk, tail_fit, mean, sd);
         if (threadIdx.x == 0) a.thr[q] = thr;
         return;
     }
@@ -420,6 +430,51 @@ __global__ void __launch_bounds__(kLevelThreads) level_select_kernel(LevelArgs a
         a.out_scores[(int64_t)q * a.k_user + i] = key ? key_score(key) : -INFINITY;
         a.out_idx[(int64_t)q * a.k_user + i] = !key ? -1 : a.id_map ? a.id_map[key_row(key)] : (int64_t)key_row(key) + a.row_offset;
     }
+}
+
+// Sample level of the batched search, dense form (kernels_sample.h): one workgroup per query reads that query's row of the
+// sample score matrix (coalesced; -inf = no such row / filtered out, NaN never keyed), keys them by sample position and
+// sets thr[q] exactly as level_select_kernel does for a sample level - the same selection and the same estimates, without
+// the gather from a thousand lane-private lists.
+template <int KR>
+__global__ void __launch_bounds__(kLevelThreads) sample_select_kernel(LevelArgs a, const float* scores, int row_stride, int npos) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* keys = (u64*)smem;
+    u64* small = (u64*)(smem + kLevelSortMax * 8);
+    u64* wlists = small + kLevelSmall;
+    u32* hist = (u32*)(wlists + (kLevelThreads / 64) * TS_MAX_K_INTERNAL);
+    u32* ctr = hist + kLevelBins;
+    const int q = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) {
+        ctr[0] = 0;
+        ctr[3] = 0;
+        a.count[q] = 0;                       // the shared list of the full pass starts empty
+    }
+    for (int i = threadIdx.x; i < kLevelBins; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const float* src = scores + (int64_t)q * row_stride;
+    const int m = min(npos, kLevelSortMax);
+    for (int i0 = (threadIdx.x & ~63); i0 < m; i0 += blockDim.x) {
+        const int i = i0 + lane;
+        const float sc = (i < m) ? src[i] : -INFINITY;
+        const bool live = sc == sc && sc > -INFINITY;
+        const u64 mask = __ballot(live);
+        u32 base = 0;
+        if (lane == 0 && mask) base = atomicAdd(&ctr[0], (u32)__popcll(mask));
+        base = (u32)__shfl((int)base, 0, 64);
+        if (live) keys[base + __popcll(mask & ((1ull << lane) - 1ull))] = make_key(sc, (u32)i);
+    }
+    __syncthreads();
+    const int cnt = (int)ctr[0];
+    const int kk = a.kk;
+    constexpr int kTailM = 32;
+    const bool tail_fit = a.tail_p > 0.0f;
+    const int kl = tail_fit ? max(kk, kTailM) : kk;
+    double mean = 0.0, sd = 0.0;
+    u64* best = lds_select_top<KR>(keys, cnt, kl, small, wlists, hist, ctr, a.z_tail > 0.0f && cnt >= 256, mean, sd);
+    const float thr = level_threshold(a, best, cnt, kk, tail_fit, mean, sd);
+    if (threadIdx.x == 0) a.thr[q] = thr;
 }
 
 // One-launch reduction of the scan's partial lists (up to kHistSelectMax keys per query: 1024 workgroups x k <= 12) to the

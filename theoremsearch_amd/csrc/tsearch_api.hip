@@ -22,6 +22,7 @@
 #include "kernels_mfma16.h"
 #include "kernels_mfma_f32.h"
 #include "kernels_prep.h"
+#include "kernels_sample.h"
 #include "kernels_scan.h"
 #include "kernels_select.h"
 
@@ -59,13 +60,14 @@ static int fail(int code, const char* fmt, ...) {
 enum Knob {
     K_MFMA_MIN_RANK, K_MFMA_VARIANT, K_MFMA_GROUPS, K_MFMA_GRID, K_MFMA_STAT, K_MFMA_STAT_CANDS, K_MFMA_TAIL_FIT,
     K_MFMA_NO_IDLE, K_MFMA_AHEAD, K_MFMA_TARGET_CANDS, K_MFMA_FIRST_ROWS, K_MFMA_TARGET_SPARSE, K_MFMA_RUN,
-    K_MFMA_MIN_ROWS, K_MFMA_SHAPE, K_MFMA_F32, K_SCAN_GENERIC, K_SCAN_MAX_QUERIES, K_MFMA_BALANCE, K_PROBE_SPREAD, K_COUNT
+    K_MFMA_MIN_ROWS, K_MFMA_SHAPE, K_MFMA_F32, K_SCAN_GENERIC, K_SCAN_MAX_QUERIES, K_MFMA_BALANCE, K_PROBE_SPREAD, K_MFMA_SAMPLE,
+    K_COUNT
 };
 static const char* const kKnobNames[K_COUNT] = {
     "TS_MFMA_MIN_RANK", "TS_MFMA_VARIANT", "TS_MFMA_GROUPS", "TS_MFMA_GRID", "TS_MFMA_STAT", "TS_MFMA_STAT_CANDS",
     "TS_MFMA_TAIL_FIT", "TS_MFMA_NO_IDLE", "TS_MFMA_AHEAD", "TS_MFMA_TARGET_CANDS", "TS_MFMA_FIRST_ROWS",
     "TS_MFMA_TARGET_SPARSE", "TS_MFMA_RUN", "TS_MFMA_MIN_ROWS", "TS_MFMA_SHAPE", "TS_MFMA_F32", "TS_SCAN_GENERIC",
-    "TS_SCAN_MAX_QUERIES", "TS_MFMA_BALANCE", "TS_PROBE_SPREAD"};
+    "TS_SCAN_MAX_QUERIES", "TS_MFMA_BALANCE", "TS_PROBE_SPREAD", "TS_MFMA_SAMPLE"};
 struct Knobs {
     int v[K_COUNT];
     bool set[K_COUNT];
@@ -104,6 +106,7 @@ struct ts_index {
     void* qstore = nullptr;     float* qf32 = nullptr;       // prepared queries [256 x ld]
     u64* cand = nullptr;        u32* count = nullptr;        float* thr = nullptr;
     u64* priv = nullptr;        u32* pcount = nullptr;       int priv_writers = 0;  // MFMA path: lane-private candidate lists
+    float* sample = nullptr;                                 // MFMA path: dense [256 x 8192] score matrix of the threshold sample
     int* fb_list = nullptr;     int* fb_count = nullptr;     unsigned long long* stat = nullptr;
     u64* partial = nullptr;     u64* partial2 = nullptr;     size_t partial_bytes = 0;
     float* res_scores = nullptr; int64_t* res_idx = nullptr; size_t res_cap = 0;  // device result buffers (entries)
@@ -337,7 +340,7 @@ extern "C" int ts_index_destroy(ts_index* ix) {
         if (ix->parent) ix->parent->nviews.fetch_sub(1);
     }
     if (ix->attached) ix->rows = nullptr;
-    void* ptrs[] = {ix->rows,  ix->stage,   ix->qstore,   ix->qf32,     ix->cand,       ix->count,  ix->thr, ix->priv, ix->pcount, ix->mask_dev, ix->bias_dev, ix->rank_buf, ix->id_map,
+    void* ptrs[] = {ix->rows,  ix->stage,   ix->qstore,   ix->qf32,     ix->cand,       ix->count,  ix->thr, ix->priv, ix->pcount, ix->sample, ix->mask_dev, ix->bias_dev, ix->rank_buf, ix->id_map,
                     ix->fb_list, ix->fb_count, ix->stat, ix->partial, ix->partial2, ix->res_scores, ix->res_idx, ix->dbg, ix->part, ix->wg_ticks};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -1157,8 +1160,16 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
     if (!ix->attr_done) {
         HIP_TRY(hipFuncSetAttribute((const void*)level_select_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelLds));
         HIP_TRY(hipFuncSetAttribute((const void*)level_select_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelLds));
+        HIP_TRY(hipFuncSetAttribute((const void*)sample_select_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelLds));
+        HIP_TRY(hipFuncSetAttribute((const void*)sample_select_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelLds));
         ix->attr_done = true;
     }
+    // The sparsest level (every score a candidate, at most kLevelSortMax rows) runs as a dense score matrix + one select per
+    // query (kernels_sample.h) instead of the full-pass kernel over the sample + a gather from lane-private lists; the
+    // latter stays selectable (TS_MFMA_SAMPLE=0) as the A/B partner and serves the thresholded sparse levels of the
+    // guaranteed chain (TS_MFMA_STAT=0).
+    const bool dense_sample = ix->knobs.get(K_MFMA_SAMPLE, 1) != 0;
+    if (dense_sample && !ix->sample) HIP_TRY(hipMalloc((void**)&ix->sample, (size_t)kMfmaQ * kLevelSortMax * 4));
     const int grid = std::max(1, std::min(ix->knobs.get(K_MFMA_GRID, ix->cu_count), 2048));
     // lane-private candidate lists: 2 writers x 32 entries per workgroup and query (32x32 shape) or 4 x 16 (16x16 shape)
     const int nwriters = (shape16 ? 4 : 2) * grid;
@@ -1222,6 +1233,39 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
     }
     for (size_t i = 0; i < lv.size(); ++i) {
         const bool full_pass = (i + 1 == lv.size());
+        if (i == 0 && !full_pass && dense_sample && lv[0].ntiles * kTileRows <= kLevelSortMax) {
+            SampleArgs sa;
+            memset(&sa, 0, sizeof(sa));
+            sa.corpus = ix->rows;
+            sa.n = ix->n;
+            sa.ld = (int)ix->ld;
+            sa.ntiles = lv[0].ntiles;
+            sa.tile_stride = lv[0].stride;
+            sa.run = lv[0].run;
+            sa.q = qmat;
+            sa.nq = nq;
+            sa.row_mask = ix->active_mask;
+            sa.scores = ix->sample;
+            sa.row_stride = (int)((lv[0].ntiles * kTileRows + 63) / 64 * 64);
+            sa.fb_count = ix->fb_count;
+            sa.stat = ix->stat;
+            const dim3 sgrid((unsigned)(sa.row_stride / 64), (unsigned)((nq + 63) / 64));
+            if (ix->dtype == TS_F32) sample_scores_kernel<true><<<sgrid, 256, 0, st>>>(sa);
+            else sample_scores_kernel<false><<<sgrid, 256, 0, st>>>(sa);
+            HIP_TRY(hipGetLastError());
+            LevelArgs l;
+            memset(&l, 0, sizeof(l));
+            l.count = ix->count;
+            l.kk = kk;
+            l.thr = ix->thr;
+            l.z_tail = z_tail;
+            l.tail_p = tail_p;
+            l.tail_z = (float)normal_tail_z(std::min(0.25, 32.0 / sample_rows));
+            if (kk <= 64) sample_select_kernel<1><<<nq, kLevelThreads, kLevelLds, st>>>(l, ix->sample, sa.row_stride, (int)(lv[0].ntiles * kTileRows));
+            else sample_select_kernel<4><<<nq, kLevelThreads, kLevelLds, st>>>(l, ix->sample, sa.row_stride, (int)(lv[0].ntiles * kTileRows));
+            HIP_TRY(hipGetLastError());
+            continue;
+        }
         MfmaArgs a;
         a.corpus = (const unsigned short*)ix->rows;
         a.n = ix->n;
@@ -1238,7 +1282,7 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         a.cand = ix->cand;
         a.count = ix->count;
         a.cap = kCandCap;
-        a.first_level = (i == 0) ? 1 : 0;      // thresholds and per-search counters are initialised inside this launch
+        a.first_level = (i == 0) ? 1 : 0;      // thresholds and per-search counters are initialised inside the first launch of a search
         a.nq_real = nq;
         a.fb_count = ix->fb_count;
         a.stat = ix->stat;
@@ -1346,7 +1390,9 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         l.z_tail = full_pass ? 0.0f : z_tail;
         l.tail_p = full_pass ? 0.0f : tail_p;
         l.tail_z = (float)normal_tail_z(std::min(0.25, 32.0 / sample_rows));
-        l.min_fill = (z_tail > 0.0f) ? (int)std::min<int64_t>(k, pop) : 0;
+        // fewer candidates back than there are answers = the threshold was too high (an estimate that overshot, or a sample
+        // score that differs from the pass's in the last bit): exact re-run
+        l.min_fill = (int)std::min<int64_t>(k, pop);
         l.out_scores = out_scores;
         l.out_idx = out_idx;
         l.k_user = k;

@@ -283,25 +283,34 @@ class SentenceEncoder:
             out[torch.as_tensor(sel, device=self.device)] = self.pool(hidden, enc["attention_mask"], normalize_embeddings)
         return out
 
-    def pool(self, hidden: torch.Tensor, attention_mask: torch.Tensor, normalize: bool) -> torch.Tensor:
+    def pool(self, hidden: torch.Tensor, attention_mask: torch.Tensor, normalize: bool,
+             out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
         """Everything behind the transformer forward: Pooling, the checkpoint's Dense modules, Normalize -> fp32
         ``[n x d]``.  On a GPU pooling (cls / mean / last token) + L2 normalisation are ONE fused HIP kernel
         (``ts_pool_normalize``) instead of five torch ops; Dense modules, when the checkpoint has them, run between the
-        pooling and the normalisation.  On CPU the torch expression of sentence-transformers' modules."""
+        pooling and the normalisation.  On CPU the torch expression of sentence-transformers' modules.
+        ``out_dtype=torch.bfloat16``: the fused kernel rounds (to nearest even) on the way out, which is the form a bf16
+        inner-product index multiplies - `TheoremIndex.search_device` then reads the tensor in place, no preparation
+        launch ("writing straight into the query buffer consumed by ts_search")."""
         normalize = bool(normalize or self.pipeline.normalize)
         fused = hidden.is_cuda and hidden.dtype in (torch.float32, torch.bfloat16) and self.pooling in _POOL_CODES
+        if out_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("out_dtype must be torch.float32 or torch.bfloat16")
+        if out_dtype == torch.bfloat16 and not (fused and not self.pipeline.dense):
+            return self.pool(hidden, attention_mask, normalize).to(torch.bfloat16)
         if fused:
             import ctypes as C
             from . import _ffi
             hidden = hidden.contiguous()
             mask = attention_mask.to(torch.int64).contiguous()
             n, seq, d = hidden.shape
-            emb = torch.empty((n, d), dtype=torch.float32, device=hidden.device)
+            emb = torch.empty((n, d), dtype=out_dtype, device=hidden.device)
             norm_here = normalize and not self.pipeline.dense
             _ffi.check(_ffi.load().ts_pool_normalize(
                 hidden.device.index or 0, C.c_void_p(hidden.data_ptr()), 1 if hidden.dtype == torch.bfloat16 else 0,
                 C.c_void_p(mask.data_ptr()), n, seq, d, _POOL_CODES[self.pooling], 1 if norm_here else 0,
-                C.c_void_p(emb.data_ptr()), 0, d, C.c_void_p(torch.cuda.current_stream(hidden.device).cuda_stream)))
+                C.c_void_p(emb.data_ptr()), 1 if out_dtype == torch.bfloat16 else 0, d,
+                C.c_void_p(torch.cuda.current_stream(hidden.device).cuda_stream)))
             if not self.pipeline.dense:
                 return emb
         else:
