@@ -170,3 +170,22 @@ def test_encode_multi_process_fans_out_over_replicas(tmp_path):
         enc.stop_multi_process_pool(pool)
     # pool=None with fewer than two visible GPUs: the same call runs in this process
     assert np.allclose(enc.encode_multi_process(texts, pool=None, batch_size=4), want, atol=1e-6)
+
+
+def test_encode_multi_process_notices_a_dead_replica(tmp_path):
+    """a worker that dies without answering (killed for memory, a GPU fault) must not leave the caller waiting
+    forever: the call raises and the pool is stopped."""
+    root = str(tmp_path / "ckpt")
+    write_checkpoint(root, pooling="mean", normalize=True)
+    enc = SentenceEncoder(root, device="cpu")
+    texts = [TEXTS[i % 4] for i in range(12)]
+    pool = enc.start_multi_process_pool(["cpu", "cpu"])
+    try:
+        assert enc.encode_multi_process(texts, pool=pool, batch_size=4).shape[0] == 12     # both replicas are up
+        pool["workers"][1][0].kill()                                                      # ... and one is gone
+        pool["workers"][1][0].join(timeout=10)
+        with pytest.raises(RuntimeError, match="died"):
+            enc.encode_multi_process(texts, pool=pool, batch_size=4)
+        assert not any(p.is_alive() for p, _, _ in pool["workers"])
+    finally:
+        enc.stop_multi_process_pool(pool)

@@ -387,12 +387,36 @@ class SentenceEncoder:
         for j, (a, b) in enumerate(bounds):
             pool["workers"][j % nw][1].put((j, texts[a:b], batch_size, normalize_embeddings))
         parts = {}
+        import queue as _queue
         for j in range(len(bounds)):
-            idx, arr = pool["workers"][j % nw][2].get()
+            proc, _, outq = pool["workers"][j % nw]
+            while True:
+                # a replica that died without answering (killed for memory, a GPU fault, a crash while loading the model)
+                # would leave a plain get() waiting forever: poll, and look at the process in between
+                try:
+                    idx, arr = outq.get(timeout=2.0)
+                    break
+                except _queue.Empty:
+                    if not proc.is_alive():
+                        dev = pool["devices"][j % nw]
+                        self._drop_pool(pool)
+                        raise RuntimeError(f"the encoder replica on {dev} died (exit code {proc.exitcode}) without answering; "
+                                           "the pool has been stopped - the next call starts a fresh one")
             if isinstance(arr, Exception):
+                self._drop_pool(pool)              # the other replicas may still hold chunks of this call: start afresh
                 raise arr
             parts[idx] = arr
         return np.concatenate([parts[j] for j in range(len(bounds))], axis=0)
+
+    def _drop_pool(self, pool: dict) -> None:
+        """Stop every worker of a pool whose call failed (its queues may hold answers of that call)."""
+        for p, _, _ in pool["workers"]:
+            if p.is_alive():
+                p.terminate()
+        for p, _, _ in pool["workers"]:
+            p.join(timeout=10)
+        if pool is self._pool:
+            self._pool = None
 
     def close(self) -> None:
         if self._pool is not None:
