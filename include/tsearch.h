@@ -59,7 +59,7 @@ extern "C" {
 
 #define TS_ALGO_AUTO 0
 #define TS_ALGO_SCAN 1 /* streaming dot-product scan with per-wave running top-k (any dtype, any d) */
-#define TS_ALGO_MFMA 2 /* MFMA contraction with thresholded candidate selection (bf16 index, d = 384, 512, 768 or 1024; fp32 index, d = 768 or 1024) */
+#define TS_ALGO_MFMA 2 /* MFMA contraction with thresholded candidate selection (bf16 or fp32 index, d = 384, 512, 768 or 1024) */
 
 #define TS_MAX_K 256
 

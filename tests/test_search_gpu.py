@@ -25,7 +25,7 @@ def ts():
 def algos_for(dtype, d):
     if dtype == "bf16" and d in (384, 512, 768, 1024):
         return ["scan", "mfma"]
-    return ["scan", "mfma"] if (dtype == "f32" and d in (768, 1024)) else ["scan"]     # fp32 MFMA (exact fp32) at d = 768 / 1024
+    return ["scan", "mfma"] if (dtype == "f32" and d in (384, 512, 768, 1024)) else ["scan"]     # fp32 MFMA (exact fp32)
 
 
 def check(q, c, metric, dtype, k, scores, idx):
@@ -234,6 +234,35 @@ def test_mfma_narrow_widths(ts, d):
         sa, ia = ix.search(q[:40], 10)              # auto picks the MFMA path for a batch
         ss, is_ = ix.search(q[:40], 10, algo="scan")
         assert np.mean(ia == is_) > 0.999
+        # round 3: these widths run the 16x16x32 kernel (d = 384 as one unit of 12 k-steps per tile, d = 512 as two of 8);
+        # the 32x32x16 kernel is the A/B partner - bit-identical answers (bf16 products are exact, fp32 sums of the same set)
+        for nq, k in ((64, 10), (200, 10), (256, 50)):
+            s16, i16 = ix.search(q[:nq], k, algo="mfma")
+            ix.set_option("TS_MFMA_SHAPE", 32)
+            s32, i32 = ix.search(q[:nq], k, algo="mfma")
+            ix.set_option("TS_MFMA_SHAPE", None)
+            assert np.array_equal(i16, i32) and np.allclose(s16, s32, atol=2e-7), (d, nq, k)
+        ix.set_option("TS_MFMA_STAT", 0)            # the guaranteed chain at these widths runs the 32x32 kernel
+        sg, ig = ix.search(q[:100], 10, algo="mfma")
+        ix.set_option("TS_MFMA_STAT", None)
+        check(q[:100], c, "cos", "bf16", 10, sg, ig)
+
+
+@pytest.mark.parametrize("d", [384, 512])
+def test_fp32_batches_at_narrow_widths_run_on_the_fp32_mfma_path(ts, d):
+    """fp32 x 384 / 512 (MiniLM-class models in the reference's fp32): round 2 served a batch as ceil(Q / 4) scan passes;
+    now the F32 mode of the 16x16 kernel (v_mfma_f32_16x16x4_f32, exact fp32)."""
+    q, c = oracle.golden_inputs(60_007, 150, d, 40 + d, "cos")
+    with ts.TheoremIndex.from_embeddings(c, dtype="f32", metric="cos") as ix:
+        for nq, k in ((5, 10), (64, 10), (65, 3), (150, 100)):
+            s, i, st = ix.search(q[:nq], k, return_stats=True)
+            assert st["algo"] == 2 and st["fallback_queries"] == 0, (d, nq, st)
+            check(q[:nq], c, "cos", "f32", k, s, i)
+        ix.set_option("TS_MFMA_STAT", 0)            # no sparse level of this kernel at these widths: the batch takes the scan
+        s, i, st = ix.search(q[:20], 10, return_stats=True)
+        ix.set_option("TS_MFMA_STAT", None)
+        assert st["algo"] == 1
+        check(q[:20], c, "cos", "f32", 10, s, i)
 
 
 def test_clustered_corpus_is_served_without_reruns(ts):
@@ -639,8 +668,9 @@ def test_dense_threshold_sample_and_the_list_form_give_the_same_answers(ts, dtyp
         ix.set_option("TS_MFMA_SAMPLE", None)
         assert st1["algo"] == st0["algo"] == 2 and st1["levels"] == st0["levels"]
         assert st1["fallback_queries"] == 0 and st0["fallback_queries"] == 0
-        assert np.array_equal(i1, i0) and np.array_equal(s1, s0)
-        assert np.array_equal(m1[1], m0[1]) and np.array_equal(m1[0], m0[0]) and mask[m1[1]].all()
+        # (d = 384: the list form runs the 32x32 kernel, whose fp32 sums add the same exact products in another order)
+        assert np.array_equal(i1, i0) and (np.array_equal(s1, s0) if d != 384 else np.allclose(s1, s0, atol=2e-7))
+        assert np.array_equal(m1[1], m0[1]) and np.allclose(m1[0], m0[0], atol=2e-7) and mask[m1[1]].all()
         # the two samples see the same rows: candidate counts of the full pass agree to within the estimates' noise
         assert 0.5 < st1["candidates"] / max(1, st0["candidates"]) < 2.0, (st1, st0)
         check(q, c, "ip", dtype, k, s1, i1)

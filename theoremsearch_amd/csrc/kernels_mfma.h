@@ -59,18 +59,23 @@ template <> struct MfmaGeom<384> { static constexpr int kUnitK = 192, kSlots = 8
 // fp32 rows seen as twice as many 2-byte elements (kernels_mfma16.h, F32): 1024 floats = 4096-byte rows, eight 16 KiB units
 template <> struct MfmaGeom<2048> { static constexpr int kUnitK = 256, kSlots = 8; };
 template <> struct MfmaGeom<1536> { static constexpr int kUnitK = 384, kSlots = 6; };   // 768 floats: 3072-byte rows, four 24 KiB units
-template <int D> struct MfmaDims {
+// the 16x16x32 kernel (kernels_mfma16.h) walks units of 8 or 12 k-steps of 32: d = 384 streams as ONE unit per tile
+// (12 k-steps, 24 KiB, six slots - the image of a half tile of d = 768); the other widths share the geometry above
+template <int D> struct MfmaGeom16 : MfmaGeom<D> {};
+template <> struct MfmaGeom16<384> { static constexpr int kUnitK = 384, kSlots = 6; };
+template <int D, class Geom = MfmaGeom<D>> struct MfmaDims {
     static constexpr int kKSteps = D / 16;
-    static constexpr int kUnitK = MfmaGeom<D>::kUnitK;
+    static constexpr int kUnitK = Geom::kUnitK;
     static constexpr int kUnitSteps = kUnitK / 16;
     static constexpr int kUnits = D / kUnitK;                     // units per tile
     static constexpr int kUnitBytes = kTileRows * kUnitK * 2;
-    static constexpr int kSlots = MfmaGeom<D>::kSlots;
+    static constexpr int kSlots = Geom::kSlots;
     static constexpr int kLds = kSlots * kUnitBytes;
     static constexpr int kPieces = kUnitBytes / 4096;            // DMA pieces per wave per unit
     static constexpr int kPieceEvery = kUnitSteps / kPieces;     // one piece every so many k-steps
     static constexpr int kAhead = 4;                             // A fragments (k-steps) in flight
 };
+template <int D> using Mfma16Dims = MfmaDims<D, MfmaGeom16<D>>;
 constexpr int mfma_queries_per_launch(int d, int groups) { return 128 * groups; }
 
 struct MfmaArgs {

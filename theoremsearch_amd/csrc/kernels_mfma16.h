@@ -203,7 +203,7 @@ __device__ __forceinline__ void mfma16_append_block(const f32x4& a0, const f32x4
 template <int D, int NB, int VARIANT, bool SPARSE, bool F32 = false>
 __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a) {
     constexpr int Deq = F32 ? 2 * D : D;                 // row length in 2-byte elements
-    using dims = MfmaDims<Deq>;
+    using dims = Mfma16Dims<Deq>;
     constexpr bool kNoEpi = VARIANT == 1 || VARIANT == 7;
     constexpr bool kNoDma = VARIANT == 7;
     constexpr bool kNoMma = VARIANT == 2;
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     static_assert(kUnitSteps % kPieces == 0 && kPieceEvery >= 1, "DMA pieces must spread evenly over the k-steps");
     static_assert(NB >= 1 && NB * kSteps * 4 <= 384, "query fragments must fit the register file");
     static_assert(!F32 || NB <= 2, "the fp32 issue order is written for one or two query blocks per wave");
-    static_assert(kUnits == 2 || kUnits == 4 || kUnits == 8, "units per tile");
+    static_assert(kUnits == 1 || kUnits == 2 || kUnits == 4 || kUnits == 8, "units per tile");
     constexpr bool kStaged = !SPARSE;                    // full pass: candidates through LDS (see kMfma16StageCap)
     constexpr int kFrags = NB * kSteps;                  // query fragments of this wave
     // A-fragment ring of kA k-steps: during k-step s the two reads of k-step s + kA - 1 are issued into the slot k-step s - 1
@@ -506,7 +506,8 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         constexpr bool steady_ = false;                                                                    \
         const unsigned char* isrc = tile_src + issue_ui * (kUnitK * 2);                                    \
         const unsigned char* ssrc = nullptr;                                                               \
-        const unsigned idst = lds0 + issue_slot * kUnitBytes;                                              \
+        /* (wave-uniform by construction; with one unit per tile hipcc loses track of that and would hand M0 a VGPR) */ \
+        const unsigned idst = __builtin_amdgcn_readfirstlane(lds0 + issue_slot * kUnitBytes);              \
         TS16_STEP(UI, 0); TS16_STEP(UI, 1); TS16_STEP(UI, 2); TS16_STEP(UI, 3);                            \
         TS16_STEP(UI, 4); TS16_STEP(UI, 5); TS16_STEP(UI, 6); TS16_STEP(UI, 7);                            \
         if constexpr (kUnitSteps > 8) { TS16_STEP(UI, 8 % kUnitSteps); TS16_STEP(UI, 9 % kUnitSteps); TS16_STEP(UI, 10 % kUnitSteps); TS16_STEP(UI, 11 % kUnitSteps); } \
@@ -529,7 +530,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     for (int t = 0; t < nt; ++t) {
         if (t < nt_steady) {
             TS16_UNIT_S(0);
-            TS16_UNIT_S(1);
+            if constexpr (kUnits >= 2) TS16_UNIT_S(1 % kUnits);
             if constexpr (kUnits >= 4) {
                 TS16_UNIT_S(2 % kUnits);
                 TS16_UNIT_S(3 % kUnits);
@@ -553,7 +554,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
             }
         } else {
             TS16_UNIT(0);
-            TS16_UNIT(1);
+            if constexpr (kUnits >= 2) TS16_UNIT(1 % kUnits);
             if constexpr (kUnits >= 4) {
                 TS16_UNIT(2 % kUnits);
                 TS16_UNIT(3 % kUnits);

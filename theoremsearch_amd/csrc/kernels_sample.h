@@ -64,29 +64,42 @@ __global__ void __launch_bounds__(256) sample_scores_kernel(SampleArgs a) {
     f32x4 acc[4];
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int s0 = 0; s0 < steps; s0 += 4) {                       // steps is a multiple of 4 for every served width
-        uint4 av[4][4], bv[4];
+    // chunks of 4 k-steps (steps is a multiple of 4 for every served width), double-buffered: the 20 loads of chunk c + 1
+    // are in flight while the 16 (fp32: 64) MFMAs of chunk c issue - the kernel is a chain of L2 round trips otherwise
+    uint4 av[2][4][4], bv[2][4];
+    auto load_chunk = [&](int buf, int s0) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int64_t off = (int64_t)(s0 + s) * kStepElems * kElem;
-            bv[s] = *(const uint4*)(brow + off);
+            bv[buf][s] = *(const uint4*)(brow + off);
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb) av[s][rb] = *(const uint4*)(arow[rb] + off);
+            for (int rb = 0; rb < 4; ++rb) av[buf][s][rb] = *(const uint4*)(arow[rb] + off);
         }
+    };
+    auto mma_chunk = [&](int buf) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb) {
                 if constexpr (F32) {
-                    const float* af = reinterpret_cast<const float*>(&av[s][rb]);
-                    const float* bf = reinterpret_cast<const float*>(&bv[s]);
+                    const float* af = reinterpret_cast<const float*>(&av[buf][s][rb]);
+                    const float* bf = reinterpret_cast<const float*>(&bv[buf][s]);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[i], acc[rb], 0, 0, 0);
                 } else {
-                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(reinterpret_cast<const bf16x8&>(av[s][rb]),
-                                                                      reinterpret_cast<const bf16x8&>(bv[s]), acc[rb], 0, 0, 0);
+                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(reinterpret_cast<const bf16x8&>(av[buf][s][rb]),
+                                                                      reinterpret_cast<const bf16x8&>(bv[buf][s]), acc[rb], 0, 0, 0);
                 }
             }
+        }
+    };
+    load_chunk(0, 0);
+    for (int s0 = 0; s0 < steps; s0 += 8) {                       // two chunks per trip: the buffer index stays static
+        if (s0 + 4 < steps) load_chunk(1, s0 + 4);
+        mma_chunk(0);
+        if (s0 + 4 < steps) {
+            if (s0 + 8 < steps) load_chunk(0, s0 + 8);
+            mma_chunk(1);
         }
     }
     // lane holds sample positions p0 + 16 rb + 4 kq + {0..3} for query qrow

@@ -697,9 +697,15 @@ extern "C" int ts_index_download(ts_index* ix, void* host_rows, int64_t row0, in
 static inline bool mfma_dim(int d) { return d == 384 || d == 512 || d == 768 || d == 1024; }
 // indexes the batched MFMA path serves: bf16 at the four widths, fp32 at d = 768 (kernels_mfma_f32.h) and d = 1024
 // (kernels_mfma16.h, F32) on the exact-fp32 matrix instructions
+// d = 384 / 512 on the 16x16 kernel exist as the full pass only: they need the usual two-level search (dense threshold
+// sample + full pass), not the guaranteed chain (TS_MFMA_STAT=0) or the list-form sample (TS_MFMA_SAMPLE=0)
+static inline bool two_level_search(const ts_index* ix) {
+    return ix->knobs.get(K_MFMA_STAT, 1) != 0 && ix->knobs.get(K_MFMA_SAMPLE, 1) != 0;
+}
 static inline bool mfma_index(const ts_index* ix) {
-    return (ix->dtype == TS_BF16 && mfma_dim(ix->d)) ||
-           (ix->dtype == TS_F32 && (ix->d == 768 || ix->d == 1024) && ix->knobs.get(K_MFMA_F32, 16) != 0);
+    if (ix->dtype == TS_BF16) return mfma_dim(ix->d);
+    if (ix->knobs.get(K_MFMA_F32, 16) == 0) return false;
+    return ix->d == 768 || ix->d == 1024 || ((ix->d == 384 || ix->d == 512) && two_level_search(ix));
 }
 
 static int ensure_search_scratch(ts_index* ix, int k) {
@@ -1027,8 +1033,11 @@ static int launch_mfma(bool full_pass, int variant, int grid, hipStream_t st, co
 
 template <int D, int NB>
 static int launch_mfma16(bool full_pass, int variant, int grid, hipStream_t st, const MfmaArgs& a) {
-    constexpr int lds = MfmaDims<D>::kLds + kMfma16StageBytes;
+    constexpr int lds = Mfma16Dims<D>::kLds + kMfma16StageBytes;
     static_assert(lds <= 160 * 1024, "DMA ring + staged candidates must fit the CU's LDS");
+    // d = 384 / 512: the full pass only (the threshold sample has its own kernel; the thresholded sparse levels of the
+    // guaranteed chain run the 32x32 kernel for these widths: use_shape16)
+    constexpr bool kSparseToo = (D == 768 || D == 1024);
 #ifdef TS_DIAG
     constexpr bool kDiag = (D == 768 && NB == 4);     // the timing-only variants exist for the headline shape only
 #else
@@ -1040,7 +1049,8 @@ static int launch_mfma16(bool full_pass, int variant, int grid, hipStream_t st, 
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_done.load(std::memory_order_acquire) & bit)) {
         HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        if constexpr (kSparseToo)
+            HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         if constexpr (kDiag) {
             HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -1053,7 +1063,8 @@ static int launch_mfma16(bool full_pass, int variant, int grid, hipStream_t st, 
         attr_done.fetch_or(bit, std::memory_order_release);
     }
     if (!full_pass) {
-        mfma16_topk_kernel<D, NB, 0, true><<<grid, kMfmaThreads, lds, st>>>(a);
+        if constexpr (kSparseToo) mfma16_topk_kernel<D, NB, 0, true><<<grid, kMfmaThreads, lds, st>>>(a);
+        else return fail(TS_ERR_INTERNAL, "no sparse level of the 16x16 kernel at d = %d", D);
     } else if (kDiag && variant != 0) {
         if constexpr (kDiag) {
             if (variant == 1) mfma16_topk_kernel<D, NB, 1, false><<<grid, kMfmaThreads, lds, st>>>(a);
@@ -1099,29 +1110,41 @@ static int launch_mfma_f32(bool full_pass, int variant, int grid, hipStream_t st
 // Which MFMA shape serves this index: d = 768 runs the 16x16x32 kernel (kernels_mfma16.h) unless TS_MFMA_SHAPE=32 asks for
 // the 32x32x16 one (kernels_mfma.h), which also serves the other widths.
 static bool use_shape16(const ts_index* ix) {
+    // d = 384 / 512 (round 3): the 16x16 kernel has the full pass only for these widths, so it serves them when the search
+    // is the usual two-level one (dense threshold sample + full pass); the guaranteed chain (TS_MFMA_STAT=0) and the
+    // list-form sample (TS_MFMA_SAMPLE=0) run the 32x32 kernel (bf16) - fp32 at these widths has no other matrix kernel
+    const bool narrow = ix->d == 384 || ix->d == 512;
+    const bool two_level = two_level_search(ix);
     // fp32: the 16x16x4 form of the same kernel (10M x 768, 256 queries: 14.1 ms a pass against 14.8 ms of the 32x32x2
     // kernel, which TS_MFMA_F32=32 still selects for d = 768)
-    if (ix->dtype == TS_F32) return ix->d == 1024 || ix->knobs.get(K_MFMA_F32, 16) != 32;
-    return ix->dtype == TS_BF16 && (ix->d == 768 || ix->d == 1024) && ix->knobs.get(K_MFMA_SHAPE, 16) != 32;
+    if (ix->dtype == TS_F32) return ix->d != 768 || ix->knobs.get(K_MFMA_F32, 16) != 32;
+    if (narrow && !two_level) return false;
+    return ix->dtype == TS_BF16 && mfma_dim(ix->d) && ix->knobs.get(K_MFMA_SHAPE, 16) != 32;
 }
 
 // fp32 index: mfma16_topk_kernel<D, NB, ., ., F32 = true>.  d = 1024: one block of 16 queries per wave, 64 per launch;
 // d = 768: two blocks, 128 per launch (one block when the batch has at most 64 queries)
 template <int D, int NB>
 static int launch_mfma16_f32(bool full_pass, int grid, hipStream_t st, const MfmaArgs& a) {
-    constexpr int lds = MfmaDims<2 * D>::kLds + kMfma16StageBytes;
+    constexpr int lds = Mfma16Dims<2 * D>::kLds + kMfma16StageBytes;
     static_assert(lds <= 160 * 1024, "DMA ring + staged candidates must fit the CU's LDS");
+    constexpr bool kSparseToo = (D == 768 || D == 1024);        // d = 384 / 512: the full pass only (as launch_mfma16)
     static std::atomic<unsigned long long> attr_done{0};
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_done.load(std::memory_order_acquire) & bit)) {
         HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        if constexpr (kSparseToo)
+            HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<D, NB, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done.fetch_or(bit, std::memory_order_release);
     }
-    if (!full_pass) mfma16_topk_kernel<D, NB, 0, true, true><<<grid, kMfmaThreads, lds, st>>>(a);
-    else mfma16_topk_kernel<D, NB, 0, false, true><<<grid, kMfmaThreads, lds, st>>>(a);
+    if (!full_pass) {
+        if constexpr (kSparseToo) mfma16_topk_kernel<D, NB, 0, true, true><<<grid, kMfmaThreads, lds, st>>>(a);
+        else return fail(TS_ERR_INTERNAL, "no sparse level of the 16x16 kernel at d = %d", D);
+    } else {
+        mfma16_topk_kernel<D, NB, 0, false, true><<<grid, kMfmaThreads, lds, st>>>(a);
+    }
     HIP_TRY(hipGetLastError());
     return TS_OK;
 }
@@ -1131,7 +1154,7 @@ static int launch_mfma16_f32(bool full_pass, int grid, hipStream_t st, const Mfm
 static int mfma_block_queries(const ts_index* ix, int nq) {
     if (ix->dtype == TS_F32) {
         if (ix->d == 1024) return 64;                          // one block of 16 queries x 4 waves
-        if (use_shape16(ix)) return nq <= 64 ? 64 : 128;       // one or two blocks per wave
+        if (use_shape16(ix)) return nq <= 64 ? 64 : 128;       // one or two blocks per wave (d = 384, 512, 768)
         return kMfmaF32Queries;                                // 32x32x2 kernel: 32 queries x 4 waves
     }
     if (use_shape16(ix)) {
@@ -1298,9 +1321,13 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         hipEvent_t stop = full_pass ? prof_begin(ix, st, ix->n) : nullptr;  // only the full pass is bracketed
         int rc;
         if (ix->dtype == TS_F32 && ix->d == 1024) rc = launch_mfma16_f32<1024, 1>(full_pass, grid, st, a);
+        else if (ix->dtype == TS_F32 && ix->d == 512) rc = (nb16 == 1) ? launch_mfma16_f32<512, 1>(full_pass, grid, st, a) : launch_mfma16_f32<512, 2>(full_pass, grid, st, a);
+        else if (ix->dtype == TS_F32 && ix->d == 384) rc = (nb16 == 1) ? launch_mfma16_f32<384, 1>(full_pass, grid, st, a) : launch_mfma16_f32<384, 2>(full_pass, grid, st, a);
         else if (ix->dtype == TS_F32 && shape16 && nb16 == 1) rc = launch_mfma16_f32<768, 1>(full_pass, grid, st, a);
         else if (ix->dtype == TS_F32 && shape16) rc = launch_mfma16_f32<768, 2>(full_pass, grid, st, a);
         else if (ix->dtype == TS_F32) rc = launch_mfma_f32(full_pass, variant, grid, st, a);
+        else if (shape16 && ix->d == 512) rc = (nb16 == 4) ? launch_mfma16<512, 4>(full_pass, variant, grid, st, a) : (nb16 == 3) ? launch_mfma16<512, 3>(full_pass, variant, grid, st, a) : (nb16 == 2) ? launch_mfma16<512, 2>(full_pass, variant, grid, st, a) : launch_mfma16<512, 1>(full_pass, variant, grid, st, a);
+        else if (shape16 && ix->d == 384) rc = (nb16 == 4) ? launch_mfma16<384, 4>(full_pass, variant, grid, st, a) : (nb16 == 3) ? launch_mfma16<384, 3>(full_pass, variant, grid, st, a) : (nb16 == 2) ? launch_mfma16<384, 2>(full_pass, variant, grid, st, a) : launch_mfma16<384, 1>(full_pass, variant, grid, st, a);
         else if (shape16 && ix->d == 1024 && nb16 == 3) rc = launch_mfma16<1024, 3>(full_pass, variant, grid, st, a);
         else if (shape16 && ix->d == 1024 && nb16 == 2) rc = launch_mfma16<1024, 2>(full_pass, variant, grid, st, a);
         else if (shape16 && ix->d == 1024) rc = launch_mfma16<1024, 1>(full_pass, variant, grid, st, a);
@@ -1450,7 +1477,7 @@ static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_
     if (algo < TS_ALGO_AUTO || algo > TS_ALGO_MFMA) return fail(TS_ERR_INVALID, "algo %d", algo);
     const bool mfma_ok = mfma_index(ix) && ix->n >= 1;
     if (algo == TS_ALGO_MFMA && !mfma_ok)
-        return fail(TS_ERR_UNSUPPORTED, "the MFMA path needs a bf16 index with d = 384, 512, 768 or 1024, or an fp32 index with d = 768 or 1024");
+        return fail(TS_ERR_UNSUPPORTED, "the MFMA path needs a bf16 or fp32 index with d = 384, 512, 768 or 1024");
     if (nq == 0) return TS_OK;
     std::lock_guard<std::mutex> lock(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));
