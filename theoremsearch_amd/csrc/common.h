@@ -112,4 +112,54 @@ __device__ __forceinline__ void bitonic_sort_desc(u64* keys, int n, int tid, int
     __syncthreads();
 }
 
+// One workgroup, after a full pass (block 0 of the launch that follows it - the exact re-run's, tsearch_api.hip): the workgroups of the pass are dispatched round-robin over the 8 XCDs, and the XCDs
+// of one device run it at rates a few per cent apart (per-XCD clock under the shared power budget), so with equal shares
+// the launch waits for the slowest XCD.  Shares move towards equal finishing times: share_w *= 1 + 0.7 (T / t_x(w) - 1),
+// t_x = mean time of the workgroups with w % 8 = x, T = mean of the t_x; boundaries are rounded, monotone, and keep a
+// minimum share.  The answers do not depend on the partition.  `tmp`: 2 part_g + 16 doubles of LDS; part_g <= blockDim.x.
+__device__ __forceinline__ void rebalance_tiles(int64_t* part, const unsigned* wg_ticks, int G, float gain, double* tmp) {
+    // G <= blockDim.x: one thread per workgroup of the pass
+    double* sh[2] = {tmp, tmp + G};               // shares, then their running sum (two buffers for the scan)
+    double* tx = tmp + 2 * G;                     // [8] summed time per XCD, [8] counts
+    const int w = threadIdx.x;
+    if (w < 16) tx[w] = 0.0;
+    __syncthreads();
+    const int64_t ntiles = part[G];
+    bool ok = ntiles > 0;
+    double share = 0.0;
+    if (w < G) {
+        const unsigned t = wg_ticks[w];
+        share = (double)(part[w + 1] - part[w]);
+        if (t == 0 || share <= 0.0) ok = false;
+        atomicAdd(&tx[w & 7], (double)t);
+        atomicAdd(&tx[8 + (w & 7)], 1.0);
+    }
+    if (!__syncthreads_and(ok ? 1 : 0)) return;   // a workgroup without work or time: leave the table alone
+    double T = 0.0;
+    int nx = 0;
+    for (int x = 0; x < 8; ++x)
+        if (tx[8 + x] > 0.0) { T += tx[x] / tx[8 + x]; ++nx; }
+    T /= (double)(nx > 0 ? nx : 1);
+    if (w < G) {
+        double f = 1.0 + (double)gain * (T / (tx[w & 7] / tx[8 + (w & 7)]) - 1.0);
+        f = f < 0.9 ? 0.9 : (f > 1.1 ? 1.1 : f);
+        const double floor_share = (double)ntiles / (4.0 * G);
+        share *= f;
+        sh[0][w] = share > floor_share ? share : floor_share;
+    }
+    __syncthreads();
+    int cur = 0;                                  // inclusive scan of the shares (Hillis-Steele)
+    for (int d = 1; d < G; d <<= 1) {
+        if (w < G) sh[cur ^ 1][w] = sh[cur][w] + (w >= d ? sh[cur][w - d] : 0.0);
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (w < G) {
+        const double total = sh[cur][G - 1];
+        const int64_t b = (w + 1 == G) ? ntiles : (int64_t)(sh[cur][w] * ((double)ntiles / total) + 0.5);
+        part[w + 1] = b;                        // shares >= ntiles / (4.2 G) >= 7 tiles: boundaries stay strictly increasing
+    }
+}
+
+
 }  // namespace ts

@@ -39,6 +39,13 @@ struct ScanArgs {
     int64_t* out_idx;
     int64_t row_offset;
     const int64_t* id_map;
+    // the launch behind a full pass of the 16x16 matrix kernel: block 0 first moves that pass's tile boundaries towards
+    // equal finishing times for the NEXT search (rebalance_tiles, common.h) - this launch exists anyway and is almost
+    // always empty, so the job costs no launch and no extra workgroup of the final select
+    int64_t* part;                // [part_g + 1] tile boundaries, updated in place; NULL = nothing to move
+    const unsigned* wg_ticks;     // [part_g] time of each workgroup of that pass (100 MHz ticks)
+    int part_g;
+    float part_gain;
 };
 
 __device__ __forceinline__ float scan_query_elem(const ScanArgs& a, int64_t off) {
@@ -187,6 +194,10 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanArgs a) {
     constexpr int GROUPS = 64 / G;
     constexpr int RW = kScanRB * GROUPS;  // rows per wave iteration
     __shared__ u64 lds_keys[1024];
+    if (!EMIT && a.part && blockIdx.x == 0) {
+        rebalance_tiles(a.part, a.wg_ticks, a.part_g, a.part_gain, (double*)lds_keys);
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const int gl = lane & (G - 1);
     const int grp = lane / G;
@@ -272,6 +283,10 @@ __global__ void __launch_bounds__(256) scan_generic_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* lds_keys = (u64*)smem;            // 1024 keys
     float* lds_q = (float*)(smem + 8192);  // QB x ld floats
+    if (!EMIT && a.part && blockIdx.x == 0) {
+        rebalance_tiles(a.part, a.wg_ticks, a.part_g, a.part_gain, (double*)lds_keys);
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t W = (int64_t)gridDim.x * (blockDim.x >> 6);

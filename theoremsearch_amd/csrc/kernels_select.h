@@ -92,12 +92,7 @@ struct LevelArgs {
     int* fb_list;
     int* fb_count;
     unsigned long long* stat_candidates;  // sum of candidates seen at the final level
-    // final level, block nq (one past the queries): move the tile boundaries of the full pass for the NEXT search
-    int64_t* part;                        // [part_g + 1] tile boundaries, updated in place
-    const unsigned* wg_ticks;             // [part_g] time of each workgroup in the pass just finished (100 MHz ticks)
-    int part_g;
     int nq;
-    float part_gain;                      // share of the measured imbalance corrected per search
 };
 
 constexpr int kLevelSortMax = 8192;
@@ -257,55 +252,6 @@ __device__ __forceinline__ u64* lds_select_top(u64* keys, int cnt, int kl, u64* 
 //   * streaming path (many equal scores in the cut bin: duplicates, saturated scores): every wave runs its slice through
 //     a running top-kl (WaveTopK) and the eight lists are merged by one sort - what this kernel always did before.
 // Both give the same `best[0 .. kl)`: the kl largest keys in descending order.
-// One workgroup, after a full pass: the workgroups of the pass are dispatched round-robin over the 8 XCDs, and the XCDs
-// of one device run it at rates a few per cent apart (per-XCD clock under the shared power budget), so with equal shares
-// the launch waits for the slowest XCD.  Shares move towards equal finishing times: share_w *= 1 + 0.7 (T / t_x(w) - 1),
-// t_x = mean time of the workgroups with w % 8 = x, T = mean of the t_x; boundaries are rounded, monotone, and keep a
-// minimum share.  The answers do not depend on the partition.  `tmp`: 2 part_g + 16 doubles of LDS; part_g <= blockDim.x.
-__device__ __forceinline__ void rebalance_tiles(const LevelArgs& a, double* tmp) {
-    const int G = a.part_g;                       // <= blockDim.x: one thread per workgroup of the pass
-    double* sh[2] = {tmp, tmp + G};               // shares, then their running sum (two buffers for the scan)
-    double* tx = tmp + 2 * G;                     // [8] summed time per XCD, [8] counts
-    const int w = threadIdx.x;
-    if (w < 16) tx[w] = 0.0;
-    __syncthreads();
-    const int64_t ntiles = a.part[G];
-    bool ok = ntiles > 0;
-    double share = 0.0;
-    if (w < G) {
-        const unsigned t = a.wg_ticks[w];
-        share = (double)(a.part[w + 1] - a.part[w]);
-        if (t == 0 || share <= 0.0) ok = false;
-        atomicAdd(&tx[w & 7], (double)t);
-        atomicAdd(&tx[8 + (w & 7)], 1.0);
-    }
-    if (!__syncthreads_and(ok ? 1 : 0)) return;   // a workgroup without work or time: leave the table alone
-    double T = 0.0;
-    int nx = 0;
-    for (int x = 0; x < 8; ++x)
-        if (tx[8 + x] > 0.0) { T += tx[x] / tx[8 + x]; ++nx; }
-    T /= (double)(nx > 0 ? nx : 1);
-    if (w < G) {
-        double f = 1.0 + (double)a.part_gain * (T / (tx[w & 7] / tx[8 + (w & 7)]) - 1.0);
-        f = f < 0.9 ? 0.9 : (f > 1.1 ? 1.1 : f);
-        const double floor_share = (double)ntiles / (4.0 * G);
-        share *= f;
-        sh[0][w] = share > floor_share ? share : floor_share;
-    }
-    __syncthreads();
-    int cur = 0;                                  // inclusive scan of the shares (Hillis-Steele)
-    for (int d = 1; d < G; d <<= 1) {
-        if (w < G) sh[cur ^ 1][w] = sh[cur][w] + (w >= d ? sh[cur][w - d] : 0.0);
-        __syncthreads();
-        cur ^= 1;
-    }
-    if (w < G) {
-        const double total = sh[cur][G - 1];
-        const int64_t b = (w + 1 == G) ? ntiles : (int64_t)(sh[cur][w] * ((double)ntiles / total) + 0.5);
-        a.part[w + 1] = b;                        // shares >= ntiles / (4.2 G) >= 7 tiles: boundaries stay strictly increasing
-    }
-}
-
 // Pass threshold of the next level from the kl best keys of a sample (`best`, sorted descending; cnt keys were sampled;
 // mean / sd of all sampled scores).  Shared by level_select_kernel (candidate lists of a sample level) and
 // sample_select_kernel (the dense sample matrix).
@@ -361,10 +307,6 @@ __global__ void __launch_bounds__(kLevelThreads) level_select_kernel(LevelArgs a
     u32& base_shared = ctr[2];
     u32& nsmall = ctr[3];                                     // (ctr[4], ctr[8..11]: lds_select_top's cut bin, mean, sd)
     const int q = blockIdx.x;
-    if (a.part && q == a.nq) {
-        rebalance_tiles(a, (double*)smem);
-        return;
-    }
     if (threadIdx.x == 0) {
         fill = 0;
         produced = 0;

@@ -107,6 +107,7 @@ struct ts_index {
     u64* cand = nullptr;        u32* count = nullptr;        float* thr = nullptr;
     u64* priv = nullptr;        u32* pcount = nullptr;       int priv_writers = 0;  // MFMA path: lane-private candidate lists
     float* sample = nullptr;                                 // MFMA path: dense [256 x 8192] score matrix of the threshold sample
+    bool rebalance_pending = false; int rebalance_grid = 0;  // the exact re-run's launch also moves the full pass's tile boundaries
     int* fb_list = nullptr;     int* fb_count = nullptr;     unsigned long long* stat = nullptr;
     u64* partial = nullptr;     u64* partial2 = nullptr;     size_t partial_bytes = 0;
     float* res_scores = nullptr; int64_t* res_idx = nullptr; size_t res_cap = 0;  // device result buffers (entries)
@@ -902,6 +903,17 @@ static int scan_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         a.out_idx = out_idx;
         a.row_offset = ix->row_offset;
         a.id_map = ix->id_map;
+        // an almost always empty launch: one workgroup per CU dispatches (and drains) faster than four; when it does
+        // run, a pass at a lower share of the HBM rate is the price of the rare query the estimate failed for
+        grid = std::min(grid, ix->cu_count);
+        if (ix->rebalance_pending && ix->rebalance_grid <= 256) {
+            a.part = ix->part;
+            a.wg_ticks = ix->wg_ticks;
+            a.part_g = ix->rebalance_grid;
+            const int b = ix->knobs.get(K_MFMA_BALANCE, 1);      // TS_MFMA_BALANCE = n > 1: gain n / 10 (default 0.7)
+            a.part_gain = (b >= 2 && b <= 10) ? 0.1f * (float)b : 0.7f;
+        }
+        ix->rebalance_pending = false;
     }
     // k > 64 keeps 4 keys per lane and query: on bf16 x 768 four queries at once need all 256 VGPRs, one wave per SIMD
     // (measured 0.18 of the HBM rate against 0.8 for one query per pass); the other shapes keep two waves
@@ -1236,7 +1248,7 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
     // equal finishing times for the next search (kernels_select.h, rebalance_tiles).  The table starts as equal shares and
     // is re-made whenever the grid or the number of tiles changes.
     const int64_t full_tiles = lv.back().ntiles;
-    const bool balance = shape16 && ix->knobs.get(K_MFMA_BALANCE, 1) != 0 && grid >= 8 && grid <= kLevelThreads && lv.back().stride == 1 &&
+    const bool balance = shape16 && ix->knobs.get(K_MFMA_BALANCE, 1) != 0 && grid >= 8 && grid <= 256 && lv.back().stride == 1 &&
                          lv.back().run == 1 && full_tiles >= 32 * (int64_t)grid && (variant == 0 || variant == 3);
     if (balance && (ix->part_g != grid || ix->part_ntiles != full_tiles)) {
         if (ix->part_g != grid) {
@@ -1428,19 +1440,14 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         l.fb_list = ix->fb_list;
         l.fb_count = ix->fb_count;
         l.stat_candidates = ix->stat;
-        const bool move = balance && full_pass;      // one more workgroup: it moves the boundaries for the next search
-        l.part = move ? ix->part : nullptr;
-        l.wg_ticks = ix->wg_ticks;
-        l.part_g = grid;
         l.nq = nq;
-        {   // TS_MFMA_BALANCE = n > 1: gain n / 10 (default 0.7)
-            const int b = ix->knobs.get(K_MFMA_BALANCE, 1);
-            l.part_gain = (b >= 2 && b <= 10) ? 0.1f * (float)b : 0.7f;
-        }
-        if (kk <= 64) level_select_kernel<1><<<nq + (move ? 1 : 0), kLevelThreads, kLevelLds, st>>>(l);
-        else level_select_kernel<4><<<nq + (move ? 1 : 0), kLevelThreads, kLevelLds, st>>>(l);
+        if (kk <= 64) level_select_kernel<1><<<nq, kLevelThreads, kLevelLds, st>>>(l);
+        else level_select_kernel<4><<<nq, kLevelThreads, kLevelLds, st>>>(l);
         HIP_TRY(hipGetLastError());
     }
+    // block 0 of the launch below moves the tile boundaries of the pass just finished for the next search
+    ix->rebalance_pending = balance;
+    ix->rebalance_grid = grid;
     // exact fall-back for queries that lost candidates (device-side count; one empty launch when 0)
     if (!in_place) TS_TRY(scan_search(ix, nq, k, out_scores, out_idx, ix->fb_list, ix->fb_count, st));
     else if (ix->dtype == TS_F32) TS_TRY(scan_search(ix, nq, k, out_scores, out_idx, ix->fb_list, ix->fb_count, st, (const float*)qmat));
