@@ -5,9 +5,16 @@
 // Round 2 ran the full-pass kernel itself over the sample (SPARSE instantiation: 393 KB of query fragments per workgroup
 // for ONE tile of work, every score appended to lane-private lists that the select then gathered from 1,024 writers):
 // 30-36 us + 21-24 us per search, whatever the corpus size - a tenth of the step of an eighth-of-the-corpus shard.  This
-// kernel is shaped for the sample instead: a workgroup takes 64 sample rows x 64 queries (one per CU at 4,096 rows x 256
-// queries), each wave 16 queries x the 64 rows as four 16x16 accumulators, operands straight from global memory (the
-// sample and the queries are L2-resident after the first touch), no LDS, no ring.
+// kernel is shaped for the sample instead, and for latency: the whole launch is two memory round trips deep.
+//   * a workgroup takes RB blocks of 16 sample rows (bf16: 64 rows, fp32: 32) and brings them into LDS by LDS-DMA
+//     (global_load_lds_dwordx4), all pieces in flight at once: every 128-byte line of a row is fetched once, in ONE round trip to HBM
+//     (a first version read operand fragments straight from global memory, 64 bytes of each row per k-step: a chain of
+//     six dependent HBM round trips, 22 us at 4,096 rows and 44 us at 8,192);
+//   * the queries come from L2 (every workgroup reads the same 393 KB) as MFMA B fragments, one 16-byte load per k-step
+//     and lane, all of a 64-query chunk in flight at once; wave w holds queries 16 w .. 16 w + 15 of the chunk;
+//   * bf16: a workgroup loops over the query chunks (the rows are read from HBM exactly once; 64 or 128 workgroups);
+//     fp32: one chunk per workgroup (grid.y), because the exact-fp32 MFMA is 1/16 of the bf16 rate and the sample's
+//     1.6 GFLOP want the whole chip.
 //
 // Arithmetic: v_mfma_f32_16x16x32_bf16 (bf16 rows) or v_mfma_f32_16x16x4_f32 (fp32 rows: float i of a 16-byte chunk times
 // float i of the matching query chunk, as the full pass does).  The sums may differ from the full pass's in the order of
@@ -21,7 +28,7 @@ namespace ts {
 struct SampleArgs {
     const void* corpus;       // [n_pad x ld] storage dtype
     int64_t n;                // real rows
-    int ld;                   // elements per row (multiple of 64)
+    int ld;                   // elements per row (multiple of 64, at most 1024)
     int64_t ntiles;           // sample tiles; sample position p = 32 * tile + row
     int64_t tile_stride;      // sample tile j is global tile (j / run) * run * tile_stride + j % run
     int run;
@@ -30,24 +37,33 @@ struct SampleArgs {
     const u32* row_mask;      // optional filter: disallowed rows score -inf (the sample sees the allowed rows only)
     float* scores;            // [64 * ceil(nq / 64)][row_stride]
     int row_stride;           // sample positions per query row of `scores` (multiple of 64, >= 32 * ntiles)
+    int chunks_per_wg;        // query chunks of 64 one workgroup serves (grid.y = ceil(chunks / chunks_per_wg))
     int* fb_count;            // per-search counters, reset here (this is the first launch of a search)
     unsigned long long* stat;
 };
 
-// grid = (row_stride / 64, ceil(nq / 64)), 256 threads
-template <bool F32>
+constexpr int kSampleRowPad = 16;                                   // bytes: rows land 4 banks apart, the 16-row reads spread out
+constexpr int sample_lds_bytes(int rows, int row_bytes) { return rows * (row_bytes + kSampleRowPad); }
+
+// RB = row blocks of 16 per workgroup (bf16: 4, fp32: 2).  grid = (row_stride / (16 RB), ceil(chunks / chunks_per_wg)),
+// 256 threads, dynamic LDS = sample_lds_bytes(16 RB, ld * elem).
+template <bool F32, int RB>
 __global__ void __launch_bounds__(256) sample_scores_kernel(SampleArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char srows[];
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         *a.fb_count = 0;
         *a.stat = 0ull;
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r16 = lane & 15, kq = lane >> 4;
-    const int64_t p0 = (int64_t)blockIdx.x * 64;                  // first sample position of this workgroup
-    const int qrow = blockIdx.y * 64 + wave * 16 + r16;           // this lane's query (B operand) and output column
-    const int64_t npos = a.ntiles * kTileRows;
+    constexpr int kRows = 16 * RB;
     constexpr int kElem = F32 ? 4 : 2;
     constexpr int kStepElems = F32 ? 16 : 32;                     // elements per k-step (16 bytes per lane and quarter)
+    constexpr int kSeg = 32;                                      // k-steps whose query fragments are in flight together
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int64_t p0 = (int64_t)blockIdx.x * kRows;               // first sample position of this workgroup
+    const int64_t npos = a.ntiles * kTileRows;
+    const int row_bytes = a.ld * kElem;
+    const int pitch = row_bytes + kSampleRowPad;
     const int steps = a.ld / kStepElems;
     // global row of sample position p (rows of positions past the sample are clamped; their scores are never used)
     auto row_of = [&](int64_t p) -> int64_t {
@@ -55,66 +71,76 @@ __global__ void __launch_bounds__(256) sample_scores_kernel(SampleArgs a) {
         const int64_t gt = (a.run == 1) ? j * a.tile_stride : (j / a.run) * a.run * a.tile_stride + j % a.run;
         return gt * kTileRows + (p & 31);
     };
-    const unsigned char* arow[4];
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb)
-        arow[rb] = (const unsigned char*)a.corpus + (row_of(p0 + 16 * rb + r16) * a.ld + (F32 ? 4 : 8) * kq) * kElem;
-    const unsigned char* brow = (const unsigned char*)a.q + ((int64_t)qrow * a.ld + (F32 ? 4 : 8) * kq) * kElem;
-
-    f32x4 acc[4];
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // chunks of 4 k-steps (steps is a multiple of 4 for every served width), double-buffered: the 20 loads of chunk c + 1
-    // are in flight while the 16 (fp32: 64) MFMAs of chunk c issue - the kernel is a chain of L2 round trips otherwise
-    uint4 av[2][4][4], bv[2][4];
-    auto load_chunk = [&](int buf, int s0) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int64_t off = (int64_t)(s0 + s) * kStepElems * kElem;
-            bv[buf][s] = *(const uint4*)(brow + off);
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb) av[buf][s][rb] = *(const uint4*)(arow[rb] + off);
-        }
-    };
-    auto mma_chunk = [&](int buf) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb) {
-                if constexpr (F32) {
-                    const float* af = reinterpret_cast<const float*>(&av[buf][s][rb]);
-                    const float* bf = reinterpret_cast<const float*>(&bv[buf][s]);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[i], acc[rb], 0, 0, 0);
-                } else {
-                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(reinterpret_cast<const bf16x8&>(av[buf][s][rb]),
-                                                                      reinterpret_cast<const bf16x8&>(bv[buf][s]), acc[rb], 0, 0, 0);
-                }
+    // rows -> LDS by LDS-DMA (no registers, no compiler-made waits): wave w moves rows w, w + 4, ... in pieces of 64 lanes x
+    // 16 bytes - whole 128-byte lines per request, every piece of every row in flight before the single wait below
+    {
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)srows;
+        const int per_row = row_bytes / 16;
+        for (int rr = 0; rr < kRows / 4; ++rr) {
+            const int r = wv + 4 * rr;
+            const unsigned char* src = (const unsigned char*)a.corpus + row_of(p0 + r) * row_bytes;
+            for (int pc = 0; pc * 64 < per_row; ++pc) {
+                const int c = pc * 64 + lane;
+                if (c < per_row) lds_dma16(src + c * 16, lds_base + r * pitch + pc * 1024);
             }
         }
-    };
-    load_chunk(0, 0);
-    for (int s0 = 0; s0 < steps; s0 += 8) {                       // two chunks per trip: the buffer index stays static
-        if (s0 + 4 < steps) load_chunk(1, s0 + 4);
-        mma_chunk(0);
-        if (s0 + 4 < steps) {
-            if (s0 + 8 < steps) load_chunk(0, s0 + 8);
-            mma_chunk(1);
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    // lane holds sample positions p0 + 16 rb + 4 kq + {0..3} for query qrow
-    float* out = a.scores + (int64_t)qrow * a.row_stride + p0 + 4 * kq;
+    __syncthreads();
+    const unsigned char* arow[RB];
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
-        float v[4];
+    for (int rb = 0; rb < RB; ++rb) arow[rb] = srows + (16 * rb + r16) * pitch + kq * 16;
+    // validity of this lane's output positions (the same for every query chunk)
+    bool ok[RB][4];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int64_t p = p0 + 16 * rb + 4 * kq + g;
             const int64_t row = row_of(p);
-            const bool ok = p < npos && row < a.n && (!a.row_mask || ((a.row_mask[row >> 5] >> (row & 31)) & 1u));
-            v[g] = ok ? acc[rb][g] : -INFINITY;
+            ok[rb][g] = p < npos && row < a.n && (!a.row_mask || ((a.row_mask[row >> 5] >> (row & 31)) & 1u));
         }
-        *(float4*)(out + 16 * rb) = make_float4(v[0], v[1], v[2], v[3]);
+    const int nchunks = (a.nq + 63) / 64;
+    const int c_begin = blockIdx.y * a.chunks_per_wg, c_end = min(nchunks, c_begin + a.chunks_per_wg);
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        const int qrow = ch * 64 + wave * 16 + r16;               // this lane's query (B operand) and output column
+        const unsigned char* brow = (const unsigned char*)a.q + ((int64_t)qrow * a.ld + (F32 ? 4 : 8) * kq) * kElem;
+        f32x4 acc[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // k in segments of at most kSeg k-steps (bf16: one segment up to d = 1024; fp32: two): a segment's query fragments
+        // are all requested before its first MFMA
+        for (int s0 = 0; s0 < steps; s0 += kSeg) {
+            uint4 bv[kSeg];
+#pragma unroll
+            for (int s = 0; s < kSeg; ++s)
+                if (s0 + s < steps) bv[s] = *(const uint4*)(brow + (int64_t)(s0 + s) * 64);
+#pragma unroll
+            for (int s = 0; s < kSeg; ++s) {
+                if (s0 + s < steps) {
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) {
+                        const uint4 av = *(const uint4*)(arow[rb] + (s0 + s) * 64);
+                        if constexpr (F32) {
+                            const float* af = reinterpret_cast<const float*>(&av);
+                            const float* bf = reinterpret_cast<const float*>(&bv[s]);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[i], acc[rb], 0, 0, 0);
+                        } else {
+                            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(reinterpret_cast<const bf16x8&>(av),
+                                                                              reinterpret_cast<const bf16x8&>(bv[s]), acc[rb], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        // lane holds sample positions p0 + 16 rb + 4 kq + {0..3} for query qrow
+        float* out = a.scores + (int64_t)qrow * a.row_stride + p0 + 4 * kq;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+            *(float4*)(out + 16 * rb) = make_float4(ok[rb][0] ? acc[rb][0] : -INFINITY, ok[rb][1] ? acc[rb][1] : -INFINITY,
+                                                    ok[rb][2] ? acc[rb][2] : -INFINITY, ok[rb][3] ? acc[rb][3] : -INFINITY);
     }
 }
 
