@@ -299,6 +299,14 @@ int ts_pool_normalize(int device, const void *hidden, int h_dtype, const int64_t
                       int32_t seq, int32_t d, int pooling, int normalize, void *out, int out_dtype,
                       int64_t out_ld, void *stream);
 
+/* Residual add + LayerNorm of the encoder, one kernel: out = LayerNorm(a + b) * gamma + beta over rows of d elements
+ * (BertSelfOutput / BertOutput of the sentence-transformer the reference loads, compare_embeddings.py:11-12: 25 add +
+ * 25 layer_norm launches per BERT-base forward in PyTorch).  a, b, out: device [rows x d] dense; gamma, beta: device [d];
+ * all of `dtype` (TS_F32 | TS_BF16), 16-byte aligned; the sum, the mean and the variance are taken in fp32.
+ * d a multiple of 8 (bf16) / 4 (fp32), at most 2048 / 1024.  `out` may alias a or b. */
+int ts_add_layernorm(int device, const void *a, const void *b, const void *gamma, const void *beta, float eps, int64_t rows,
+                     int32_t d, int dtype, void *out, void *stream);
+
 /* ---- kernel timing inside the library ----------------------------------------------------------
  * With profiling enabled, every launch of the dominant kernel of a search (the full-corpus pass of
  * the MFMA path, or the scan kernel) is bracketed by a hipEvent pair on the stream it runs on.

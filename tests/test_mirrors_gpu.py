@@ -422,3 +422,65 @@ def test_generate_embeddings_appends_new_slogan_ids(encoder):
         rows[5]["slogan"] = "Completely different text about schemes."
         assert ge.generate_embeddings([rows[:8]], "gemma", ix, embedder=encoder, slots=slots, overwrite=True) == 8
         assert ix.n == 150 and not np.array_equal(ix.download(5, 1), before)
+
+
+def test_add_layernorm_kernel_matches_torch_in_fp64():
+    """ts_add_layernorm = LayerNorm(a + b) * gamma + beta with the sum, mean and variance in fp32, against the same
+    expression in fp64 on the same (rounded) inputs: fp32 and bf16, the encoder widths, a ragged row count, in place."""
+    import ctypes as C
+    import torch
+    from theoremsearch_amd import _ffi
+    lib = _ffi.load()
+    g = torch.Generator(device="cpu").manual_seed(4)
+    for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
+        for d in (384, 768, 1024):
+            a = (torch.randn((1003, d), generator=g) * 2.0 + 0.3).to(dtype).cuda()
+            b = torch.randn((1003, d), generator=g).to(dtype).cuda()
+            gamma = (1.0 + 0.1 * torch.randn(d, generator=g)).to(dtype).cuda()
+            beta = (0.1 * torch.randn(d, generator=g)).to(dtype).cuda()
+            want = torch.nn.functional.layer_norm(a.double() + b.double(), (d,), gamma.double(), beta.double(), 1e-12)
+            out = torch.empty_like(a)
+            args = (C.c_void_p(gamma.data_ptr()), C.c_void_p(beta.data_ptr()), 1e-12, 1003, d, 1 if dtype == torch.bfloat16 else 0)
+            _ffi.check(lib.ts_add_layernorm(0, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), *args, C.c_void_p(out.data_ptr()),
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            torch.cuda.synchronize()
+            assert torch.allclose(out.double(), want, atol=tol, rtol=tol), (dtype, d, (out.double() - want).abs().max().item())
+            _ffi.check(lib.ts_add_layernorm(0, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), *args, C.c_void_p(a.data_ptr()),
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)))       # in place over `a`
+            torch.cuda.synchronize()
+            assert torch.equal(a, out)
+    with pytest.raises(_ffi.TSearchError):
+        _ffi.check(lib.ts_add_layernorm(0, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(gamma.data_ptr()),
+                                        C.c_void_p(beta.data_ptr()), 1e-12, 4, 10, 1, C.c_void_p(out.data_ptr()), None))
+
+
+def test_fused_bert_forward_matches_the_models_own(encoder):
+    """FusedBertForward (QKV as one GEMM, add + LayerNorm as one kernel) against the model's own forward on the same bf16
+    weights: hidden states of the real tokens within bf16 noise, sentence embeddings within 2e-2 and cosine > 0.9995;
+    fp32 weights: within 2e-4."""
+    import torch
+    from theoremsearch_amd.encoder import SentenceEncoder
+    assert encoder._fused is not None
+    texts = [f"Let $f_{i}$ be a continuous map of a compact space, number {i}. " * (1 + i % 3) for i in range(37)]
+    enc = {k: v.cuda() for k, v in encoder._tokenize(texts).items()}
+    with torch.inference_mode():
+        want = encoder.model(input_ids=enc["input_ids"], attention_mask=enc["attention_mask"]).last_hidden_state.float()
+        got = encoder.forward_hidden(enc["input_ids"], enc["attention_mask"]).float()
+    real = enc["attention_mask"].bool()
+    assert (want - got)[real].abs().max().item() < 0.15 and (want - got)[real].abs().mean().item() < 0.01
+    fused = encoder.encode(texts, normalize_embeddings=True, convert_to_numpy=True)
+    os.environ["TS_ENCODER_FUSED"] = "0"
+    try:
+        plain_enc = SentenceEncoder(num_layers=2, allow_random_init=True)
+    finally:
+        del os.environ["TS_ENCODER_FUSED"]
+    assert plain_enc._fused is None
+    plain = plain_enc.encode(texts, normalize_embeddings=True, convert_to_numpy=True)
+    assert np.abs(fused - plain).max() < 2e-2 and np.min(np.sum(fused * plain, axis=1)) > 0.9995
+    f32 = SentenceEncoder(num_layers=2, allow_random_init=True, dtype=torch.float32)
+    assert f32._fused is not None
+    e32 = {k: v.cuda() for k, v in f32._tokenize(texts[:9]).items()}
+    with torch.inference_mode():
+        w32 = f32.model(input_ids=e32["input_ids"], attention_mask=e32["attention_mask"]).last_hidden_state
+        g32 = f32.forward_hidden(e32["input_ids"], e32["attention_mask"])
+    assert (w32 - g32)[e32["attention_mask"].bool()].abs().max().item() < 2e-4

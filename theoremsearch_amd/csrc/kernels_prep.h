@@ -125,6 +125,89 @@ __global__ void __launch_bounds__(256) pool_normalize_kernel(const void* __restr
     }
 }
 
+// Residual add + LayerNorm of the encoder (BertSelfOutput / BertOutput: LayerNorm(dense_out + input)), one kernel
+// instead of torch's add and layer_norm launches (25 of each per BERT-base forward): out = (x - mean) * rstd * gamma + beta
+// with x = a + b taken in fp32 (torch rounds the sum to the storage type first; this keeps it in fp32), mean and variance
+// over the row in fp32 (two passes over registers: mean first, then the centred squares).  One wave per row, 8 elements
+// (bf16) or 4 (fp32) per 16-byte access; d a multiple of that, at most 64 * kLnMax accesses per row.
+constexpr int kLnMax = 4;
+template <int DT>
+__global__ void __launch_bounds__(256) add_layernorm_kernel(const void* __restrict__ a, const void* __restrict__ b,
+                                                             const void* __restrict__ gamma, const void* __restrict__ beta, float eps,
+                                                             int64_t rows, int d, void* __restrict__ out) {
+    constexpr int VEC = DT == 0 ? 4 : 8;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = d / VEC;
+    float x[kLnMax][VEC];
+    auto unpack = [](const uint4& v, float* f) {
+        if (DT == 0) {
+            f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+        } else {
+            f[0] = bf16_lo(v.x); f[1] = bf16_hi(v.x); f[2] = bf16_lo(v.y); f[3] = bf16_hi(v.y);
+            f[4] = bf16_lo(v.z); f[5] = bf16_hi(v.z); f[6] = bf16_lo(v.w); f[7] = bf16_hi(v.w);
+        }
+    };
+    const uint4* pa = (const uint4*)a + row * nchunk;
+    const uint4* pb = (const uint4*)b + row * nchunk;
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kLnMax; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nchunk) {
+            float fa[VEC], fb[VEC];
+            unpack(pa[c], fa);
+            unpack(pb[c], fb);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                x[j][e] = fa[e] + fb[e];
+                sum += x[j][e];
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    const float mean = sum / (float)d;
+    float sq = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kLnMax; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nchunk) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float t = x[j][e] - mean;
+                sq += t * t;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    const float rstd = rsqrtf(sq / (float)d + eps);
+    uint4* po = (uint4*)out + row * nchunk;
+#pragma unroll
+    for (int j = 0; j < kLnMax; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nchunk) {
+            float g[VEC], be[VEC], y[VEC];
+            unpack(((const uint4*)gamma)[c], g);
+            unpack(((const uint4*)beta)[c], be);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) y[e] = (x[j][e] - mean) * rstd * g[e] + be[e];
+            uint4 o;
+            if (DT == 0) {
+                o = make_uint4(__float_as_uint(y[0]), __float_as_uint(y[1]), __float_as_uint(y[2]), __float_as_uint(y[3]));
+            } else {
+                o.x = (u32)f32_to_bf16(y[0]) | ((u32)f32_to_bf16(y[1]) << 16);
+                o.y = (u32)f32_to_bf16(y[2]) | ((u32)f32_to_bf16(y[3]) << 16);
+                o.z = (u32)f32_to_bf16(y[4]) | ((u32)f32_to_bf16(y[5]) << 16);
+                o.w = (u32)f32_to_bf16(y[6]) | ((u32)f32_to_bf16(y[7]) << 16);
+            }
+            po[c] = o;
+        }
+    }
+}
+
 // Dense device rows -> dense host-layout rows of the storage dtype (for ts_index_download).
 template <int DT>
 __global__ void __launch_bounds__(256) unpad_rows_kernel(const void* __restrict__ src, int64_t ld, void* __restrict__ dst, int d,

@@ -12,9 +12,9 @@
 //     six dependent HBM round trips, 22 us at 4,096 rows and 44 us at 8,192);
 //   * the queries come from L2 (every workgroup reads the same 393 KB) as MFMA B fragments, one 16-byte load per k-step
 //     and lane, all of a 64-query chunk in flight at once; wave w holds queries 16 w .. 16 w + 15 of the chunk;
-//   * bf16: a workgroup loops over the query chunks (the rows are read from HBM exactly once; 64 or 128 workgroups);
-//     fp32: one chunk per workgroup (grid.y), because the exact-fp32 MFMA is 1/16 of the bf16 rate and the sample's
-//     1.6 GFLOP want the whole chip.
+//   * a workgroup serves `chunks_per_wg` query chunks in turn; the host picks it so that the launch fills the chip once
+//     (4,096 rows x 256 bf16 queries: 64 row groups x 4 chunks = 256 workgroups of one chunk each; a first cut with every
+//     chunk looped inside 64 workgroups took 36 us against 15 for this shape: the chunks are independent work).
 //
 // Arithmetic: v_mfma_f32_16x16x32_bf16 (bf16 rows) or v_mfma_f32_16x16x4_f32 (fp32 rows: float i of a 16-byte chunk times
 // float i of the matching query chunk, as the full pass does).  The sums may differ from the full pass's in the order of
@@ -116,22 +116,30 @@ __global__ void __launch_bounds__(256) sample_scores_kernel(SampleArgs a) {
 #pragma unroll
             for (int s = 0; s < kSeg; ++s)
                 if (s0 + s < steps) bv[s] = *(const uint4*)(brow + (int64_t)(s0 + s) * 64);
+            // groups of 4 k-steps (every served width is a multiple): the 4 RB fragment reads of a group are issued before
+            // its MFMAs, so the LDS latency is paid once per group, not once per MFMA
 #pragma unroll
-            for (int s = 0; s < kSeg; ++s) {
-                if (s0 + s < steps) {
+            for (int g4 = 0; g4 < kSeg; g4 += 4) {
+                if (s0 + g4 < steps) {
+                    uint4 av[4][RB];
 #pragma unroll
-                    for (int rb = 0; rb < RB; ++rb) {
-                        const uint4 av = *(const uint4*)(arow[rb] + (s0 + s) * 64);
-                        if constexpr (F32) {
-                            const float* af = reinterpret_cast<const float*>(&av);
-                            const float* bf = reinterpret_cast<const float*>(&bv[s]);
+                    for (int s = 0; s < 4; ++s)
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[i], acc[rb], 0, 0, 0);
-                        } else {
-                            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(reinterpret_cast<const bf16x8&>(av),
-                                                                              reinterpret_cast<const bf16x8&>(bv[s]), acc[rb], 0, 0, 0);
+                        for (int rb = 0; rb < RB; ++rb) av[s][rb] = *(const uint4*)(arow[rb] + (s0 + g4 + s) * 64);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int rb = 0; rb < RB; ++rb) {
+                            if constexpr (F32) {
+                                const float* af = reinterpret_cast<const float*>(&av[s][rb]);
+                                const float* bf = reinterpret_cast<const float*>(&bv[g4 + s]);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[i], acc[rb], 0, 0, 0);
+                            } else {
+                                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(reinterpret_cast<const bf16x8&>(av[s][rb]),
+                                                                                  reinterpret_cast<const bf16x8&>(bv[g4 + s]), acc[rb], 0, 0, 0);
+                            }
                         }
-                    }
                 }
             }
         }

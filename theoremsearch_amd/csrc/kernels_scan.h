@@ -48,8 +48,8 @@ struct ScanArgs {
     float part_gain;
     // feedback partition of the scan itself (specialised kernels, grid a multiple of 8): the row blocks are still dealt in
     // rounds of consecutive blocks - every wave sweeps the same front - but in round r only the workgroups of the XCDs
-    // (blockIdx.x % 8) that xcd_w marks active take part, so a slower XCD gets fewer blocks: XCD j is active in round r iff
-    // floor((r + 1) w_j / 65536) > floor(r w_j / 65536), w_j in (0, 65536] with the fastest XCD at 65536
+    // (blockIdx.x % 8) that xcd_w marks active take part, so a slower XCD gets fewer blocks: XCD j keeps a 16.16 running sum
+    // of its weight w_j in (0, 65536] (the fastest XCD at 65536) and is active in the rounds where the sum carries
     const u32* xcd_w;             // [8]; NULL = every workgroup in every round (equal shares)
     unsigned* scan_ticks;         // [gridDim.x] time each workgroup took (100 MHz ticks); NULL = not recorded
 };
@@ -255,9 +255,9 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanArgs a) {
     const int count = a.qcount ? *a.qcount : a.nq;
     const bool weighted = !EMIT && a.xcd_w != nullptr && (gridDim.x & 7) == 0;
     const int myx = blockIdx.x & 7;
-    unsigned long long xw[8];
+    u32 xw[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) xw[j] = weighted ? (unsigned long long)a.xcd_w[j] : 65536ull;
+    for (int j = 0; j < 8; ++j) xw[j] = weighted ? a.xcd_w[j] : 65536u;
     const unsigned long long t_begin = (!EMIT && a.scan_ticks) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
     for (int g0 = 0; g0 < count; g0 += QB) {
@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanArgs a) {
             for (int q = 0; q < QB; ++q) tk[q].init();
         }
         int64_t blk = gw - W, wbase = 0;
-        unsigned long long round = 0;
+        u32 xacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // 16.16 running sums of the weights: XCD j is active when its sum carries
         for (;;) {
             if (!weighted) {
                 blk += W;
@@ -289,15 +289,16 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanArgs a) {
                 int P = 0, before = 0;
                 bool mine = false;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int act = (int)(((round + 1) * xw[j]) >> 16) - (int)((round * xw[j]) >> 16);
+                for (int j = 0; j < 8; ++j) {                       // scalar work: everything here is wave-uniform
+                    xacc[j] += xw[j];
+                    const int act = (int)(xacc[j] >> 16);
+                    xacc[j] &= 0xFFFFu;
                     before += (j < myx) ? act : 0;
                     mine = mine || (j == myx && act);
                     P += act;
                 }
                 blk = wbase + ((int64_t)(blockIdx.x >> 3) * P + before) * (blockDim.x >> 6) + (threadIdx.x >> 6);
                 wbase += (int64_t)(gridDim.x >> 3) * (blockDim.x >> 6) * P;
-                ++round;
                 if (!mine || blk >= nblocks) continue;
             }
             const int64_t row0 = blk * RW + grp * kScanRB;

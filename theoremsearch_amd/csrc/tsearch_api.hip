@@ -1316,11 +1316,13 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
             sa.row_stride = (int)((lv[0].ntiles * kTileRows + 63) / 64 * 64);
             sa.fb_count = ix->fb_count;
             sa.stat = ix->stat;
-            // bf16: 64 rows per workgroup, every query chunk in turn (rows read from HBM once); fp32: 32 rows x one chunk
+            // 64 (fp32: 32) rows per workgroup; as many query chunks per workgroup as keep the launch within one workgroup
+            // per CU (the chunks of one row group re-read its rows from L2)
             const bool f32 = ix->dtype == TS_F32;
             const int nchunks = (nq + 63) / 64;
             const int wg_rows = f32 ? 32 : 64;
-            sa.chunks_per_wg = f32 ? 1 : nchunks;
+            const int row_groups = sa.row_stride / wg_rows;
+            sa.chunks_per_wg = f32 ? 1 : std::min(nchunks, std::max(1, (row_groups * nchunks + ix->cu_count - 1) / ix->cu_count));
             const dim3 sgrid((unsigned)(sa.row_stride / wg_rows), (unsigned)((nchunks + sa.chunks_per_wg - 1) / sa.chunks_per_wg));
             const int slds = sample_lds_bytes(wg_rows, (int)(ix->ld * ix->elem()));
             if (slds > 160 * 1024) return fail(TS_ERR_INTERNAL, "threshold sample: rows of %lld bytes do not fit the LDS", (long long)(ix->ld * ix->elem()));
@@ -2019,6 +2021,25 @@ extern "C" int ts_pool_normalize(int device, const void* hidden, int h_dtype, co
         pool_normalize_kernel<1, 0><<<grid, 256, 0, st>>>(hidden, attention_mask, seq, d, pooling, normalize, out, out_ld);
     else
         pool_normalize_kernel<1, 1><<<grid, 256, 0, st>>>(hidden, attention_mask, seq, d, pooling, normalize, out, out_ld);
+    HIP_TRY(hipGetLastError());
+    return TS_OK;
+}
+
+extern "C" int ts_add_layernorm(int device, const void* a, const void* b, const void* gamma, const void* beta, float eps, int64_t rows,
+                                int32_t d, int dtype, void* out, void* stream) {
+    if (!a || !b || !gamma || !beta || !out) return fail(TS_ERR_INVALID, "NULL argument");
+    if (dtype != TS_F32 && dtype != TS_BF16) return fail(TS_ERR_INVALID, "dtype %d", dtype);
+    const int vec = dtype == TS_BF16 ? 8 : 4;
+    if (rows < 0 || d < vec || d % vec || d > 64 * kLnMax * vec)
+        return fail(TS_ERR_INVALID, "d = %d must be a multiple of %d and at most %d", d, vec, 64 * kLnMax * vec);
+    if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out) & 15) != 0)
+        return fail(TS_ERR_INVALID, "buffers must be 16-byte aligned");
+    if (rows == 0) return TS_OK;
+    TS_TRY(check_device(device));
+    HIP_TRY(hipSetDevice(device));
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    if (dtype == TS_F32) add_layernorm_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(a, b, gamma, beta, eps, rows, d, out);
+    else add_layernorm_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(a, b, gamma, beta, eps, rows, d, out);
     HIP_TRY(hipGetLastError());
     return TS_OK;
 }
