@@ -168,6 +168,9 @@ def main():
                     help="c5: capture the encoder forward in a HIP graph per stream and replay it every step (default: eager "
                          "launches; measured on one box: 6.24 ms per step replayed, 6.19 eager - the forward is bound by its "
                          "kernels' device time, not by launch gaps)")
+    ap.add_argument("--tune-gemms", action="store_true",
+                    help="c5: let PyTorch's TunableOp pick the fastest hipBLASLt / rocBLAS solution for each of the encoder's "
+                         "four GEMM shapes during the warm-up (seconds of tuning per shape)")
     ap.add_argument("--zero-queries", action="store_true", help="diagnostic: all-zero queries (power probe)")
     ap.add_argument("--zero-corpus", action="store_true", help="diagnostic: all-zero corpus (power probe)")
     args = ap.parse_args()
@@ -273,6 +276,13 @@ def main():
         # BASELINE.json configs[4]: encoder forward (PyTorch-ROCm, random-init BERT-base-shaped stand-in: no weights
         # offline) on synthetic token sequences, pooled + normalised on the device, handed to the search by pointer
         from theoremsearch_amd.encoder import SentenceEncoder
+        if args.tune_gemms:
+            import torch.cuda.tunable as tunable
+            tunable.enable(True)
+            tunable.tuning_enable(True)
+            tunable.set_max_tuning_duration(30)
+            tunable.set_max_tuning_iterations(20)
+            tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"ts_tunableop_rank{rank}.csv"))
         encoder = SentenceEncoder(allow_random_init=True)
         g = torch.Generator(device="cpu").manual_seed(5678)
         tok_ids = torch.randint(1000, 30000, (nq, args.seq_len), generator=g).cuda()

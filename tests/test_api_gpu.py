@@ -440,21 +440,3 @@ def test_pgvector_adapter_exact_form_equals_the_pool_form_when_the_pool_holds_th
         exact = pgvector.search(ix, q[0], k, citation_weight=0.05, citations=cites, exact=True)
         assert exact[0]["row"] == far and far not in [r["row"] for r in pool]
 
-
-def test_answers_do_not_move_with_the_xcd_weights_of_the_scan(ts):
-    """TS_SCAN_BALANCE: the scan deals its row blocks in rounds whose participants follow per-XCD weights that the select
-    behind every pass moves (towards equal finishing times).  Same queries, a dozen searches: the weights move, the answers
-    may not; fp32 and bf16, one query and four per pass."""
-    for dtype in ("f32", "bf16"):
-        q, c = oracle.golden_inputs(400_000, 4, 768, 61, "ip")
-        with ts.TheoremIndex.from_embeddings(c, dtype=dtype, metric="ip") as ix:
-            want1 = ix.search(q[:1], 10, algo="scan")
-            want4 = ix.search(q, 10, algo="scan")
-            ix.set_option("TS_SCAN_BALANCE", 1)
-            for _ in range(12):
-                s1, i1 = ix.search(q[:1], 10, algo="scan")
-                s4, i4 = ix.search(q, 10, algo="scan")
-                assert np.array_equal(i1, want1[1]) and np.array_equal(s1, want1[0])
-                assert np.array_equal(i4, want4[1]) and np.array_equal(s4, want4[0])
-            ix.set_option("TS_SCAN_BALANCE", None)
-            check(q, c, "ip", dtype, 10, *want4)

@@ -46,53 +46,7 @@ struct ScanArgs {
     const unsigned* wg_ticks;     // [part_g] time of each workgroup of that pass (100 MHz ticks)
     int part_g;
     float part_gain;
-    // feedback partition of the scan itself (specialised kernels, grid a multiple of 8): the row blocks are still dealt in
-    // rounds of consecutive blocks - every wave sweeps the same front - but in round r only the workgroups of the XCDs
-    // (blockIdx.x % 8) that xcd_w marks active take part, so a slower XCD gets fewer blocks: XCD j keeps a 16.16 running sum
-    // of its weight w_j in (0, 65536] (the fastest XCD at 65536) and is active in the rounds where the sum carries
-    const u32* xcd_w;             // [8]; NULL = every workgroup in every round (equal shares)
-    unsigned* scan_ticks;         // [gridDim.x] time each workgroup took (100 MHz ticks); NULL = not recorded
 };
-
-// New weights from the times of the pass just finished: XCD j did a share ~ w_j of the rounds in mean time t_j, so its speed
-// is ~ w_j / t_j and equal finishing times want w_j ~ speed_j; damped by `gain`, largest weight = 65536, none below half.
-// One workgroup (any size >= 64 threads); `tmp`: 32 doubles of LDS.
-__device__ __forceinline__ void update_xcd_weights(u32* xcd_w, const unsigned* ticks, int G, float gain, double* tmp) {
-    if (threadIdx.x < 16) tmp[threadIdx.x] = 0.0;
-    __syncthreads();
-    double s = 0.0, c = 0.0;
-    if (threadIdx.x < 64) {                       // lane l sums the workgroups l, l + 64, ... (l % 8 = its XCD)
-        for (int w = threadIdx.x; w < G; w += 64) {
-            const unsigned t = ticks[w];
-            if (t) { s += (double)t; c += 1.0; }
-        }
-        atomicAdd(&tmp[threadIdx.x & 7], s);
-        atomicAdd(&tmp[8 + (threadIdx.x & 7)], c);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double T = 0.0, wn[8], top = 0.0;
-        int nx = 0;
-        bool ok = true;
-        for (int j = 0; j < 8; ++j) {
-            if (tmp[8 + j] <= 0.0) ok = false;
-            else { tmp[j] /= tmp[8 + j]; T += tmp[j]; ++nx; }
-        }
-        if (ok) {
-            T /= (double)nx;
-            for (int j = 0; j < 8; ++j) {
-                double f = 1.0 + (double)gain * (T / tmp[j] - 1.0);
-                f = f < 0.9 ? 0.9 : (f > 1.1 ? 1.1 : f);
-                wn[j] = (double)xcd_w[j] * f;
-                top = wn[j] > top ? wn[j] : top;
-            }
-            for (int j = 0; j < 8; ++j) {
-                const double v = wn[j] / top * 65536.0;
-                xcd_w[j] = (u32)(v < 32768.0 ? 32768.0 : (v > 65536.0 ? 65536.0 : v + 0.5));
-            }
-        }
-    }
-}
 
 __device__ __forceinline__ float scan_query_elem(const ScanArgs& a, int64_t off) {
     return a.qbuf ? a.qbuf[off] : bf16_to_f32(a.qb16[off]);
@@ -253,12 +207,6 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanArgs a) {
     const uint4* __restrict__ base = (const uint4*)a.corpus;
     const int64_t ld16 = a.ld / VEC;  // row stride in 16-byte chunks
     const int count = a.qcount ? *a.qcount : a.nq;
-    const bool weighted = !EMIT && a.xcd_w != nullptr && (gridDim.x & 7) == 0;
-    const int myx = blockIdx.x & 7;
-    u32 xw[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) xw[j] = weighted ? a.xcd_w[j] : 65536u;
-    const unsigned long long t_begin = (!EMIT && a.scan_ticks) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
     for (int g0 = 0; g0 < count; g0 += QB) {
         float qv[QB][CH][VEC];
@@ -277,30 +225,7 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanArgs a) {
 #pragma unroll
             for (int q = 0; q < QB; ++q) tk[q].init();
         }
-        int64_t blk = gw - W, wbase = 0;
-        u32 xacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // 16.16 running sums of the weights: XCD j is active when its sum carries
-        for (;;) {
-            if (!weighted) {
-                blk += W;
-                if (blk >= nblocks) break;
-            } else {
-                // round `round` of the weighted deal: which XCDs take part, and this wave's place among their waves
-                if (wbase >= nblocks) break;
-                int P = 0, before = 0;
-                bool mine = false;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {                       // scalar work: everything here is wave-uniform
-                    xacc[j] += xw[j];
-                    const int act = (int)(xacc[j] >> 16);
-                    xacc[j] &= 0xFFFFu;
-                    before += (j < myx) ? act : 0;
-                    mine = mine || (j == myx && act);
-                    P += act;
-                }
-                blk = wbase + ((int64_t)(blockIdx.x >> 3) * P + before) * (blockDim.x >> 6) + (threadIdx.x >> 6);
-                wbase += (int64_t)(gridDim.x >> 3) * (blockDim.x >> 6) * P;
-                if (!mine || blk >= nblocks) continue;
-            }
+        for (int64_t blk = gw; blk < nblocks; blk += W) {
             const int64_t row0 = blk * RW + grp * kScanRB;
             uint4 v[kScanRB][CH];
 #pragma unroll
@@ -346,10 +271,8 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanArgs a) {
             }
         }
     }
-    if constexpr (!EMIT) {
-        if (a.scan_ticks && threadIdx.x == 0) a.scan_ticks[blockIdx.x] = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_begin);
+    if constexpr (!EMIT)
         if (a.done_ctr && count > 0) scan_finish<KR>(a, count, lds_keys);
-    }
 }
 
 // Generic: any ld (multiple of 64 elements), QB queries per pass staged in LDS (QB = 1 or 4).

@@ -34,11 +34,6 @@ struct SelectArgs {
     const int64_t* id_map;  // optional: local row -> global id (subset indexes); replaces row + row_offset
     const int* qlist;    // optional slot -> query id
     const int* qcount;   // optional device-side slot count
-    // select_hist_kernel, block `nslots` (one past the slots): new XCD weights of the scan from the times of its pass
-    u32* xcd_w;
-    const unsigned* scan_ticks;
-    int scan_grid, nslots;
-    float xcd_gain;
 };
 
 // grid = (segments, slots); 256 threads; SEG keys of LDS.
@@ -441,10 +436,6 @@ __global__ void __launch_bounds__(kLevelThreads) select_hist_kernel(SelectArgs a
     u32* hist = (u32*)(wlists + (kLevelThreads / 64) * TS_MAX_K_INTERNAL);
     u32* ctr = hist + kLevelBins;
     const int slot = blockIdx.x;
-    if (a.xcd_w && slot == a.nslots) {
-        update_xcd_weights(a.xcd_w, a.scan_ticks, a.scan_grid, a.xcd_gain, (double*)smem);
-        return;
-    }
     if (a.qcount && slot >= *a.qcount) return;
     const int lane = threadIdx.x & 63;
     if (threadIdx.x == 0) {

@@ -61,13 +61,13 @@ enum Knob {
     K_MFMA_MIN_RANK, K_MFMA_VARIANT, K_MFMA_GROUPS, K_MFMA_GRID, K_MFMA_STAT, K_MFMA_STAT_CANDS, K_MFMA_TAIL_FIT,
     K_MFMA_NO_IDLE, K_MFMA_AHEAD, K_MFMA_TARGET_CANDS, K_MFMA_FIRST_ROWS, K_MFMA_TARGET_SPARSE, K_MFMA_RUN,
     K_MFMA_MIN_ROWS, K_MFMA_SHAPE, K_MFMA_F32, K_SCAN_GENERIC, K_SCAN_MAX_QUERIES, K_MFMA_BALANCE, K_PROBE_SPREAD, K_MFMA_SAMPLE,
-    K_SCAN_BALANCE, K_COUNT
+    K_COUNT
 };
 static const char* const kKnobNames[K_COUNT] = {
     "TS_MFMA_MIN_RANK", "TS_MFMA_VARIANT", "TS_MFMA_GROUPS", "TS_MFMA_GRID", "TS_MFMA_STAT", "TS_MFMA_STAT_CANDS",
     "TS_MFMA_TAIL_FIT", "TS_MFMA_NO_IDLE", "TS_MFMA_AHEAD", "TS_MFMA_TARGET_CANDS", "TS_MFMA_FIRST_ROWS",
     "TS_MFMA_TARGET_SPARSE", "TS_MFMA_RUN", "TS_MFMA_MIN_ROWS", "TS_MFMA_SHAPE", "TS_MFMA_F32", "TS_SCAN_GENERIC",
-    "TS_SCAN_MAX_QUERIES", "TS_MFMA_BALANCE", "TS_PROBE_SPREAD", "TS_MFMA_SAMPLE", "TS_SCAN_BALANCE"};
+    "TS_SCAN_MAX_QUERIES", "TS_MFMA_BALANCE", "TS_PROBE_SPREAD", "TS_MFMA_SAMPLE"};
 struct Knobs {
     int v[K_COUNT];
     bool set[K_COUNT];
@@ -107,7 +107,6 @@ struct ts_index {
     u64* cand = nullptr;        u32* count = nullptr;        float* thr = nullptr;
     u64* priv = nullptr;        u32* pcount = nullptr;       int priv_writers = 0;  // MFMA path: lane-private candidate lists
     float* sample = nullptr;                                 // MFMA path: dense [256 x 8192] score matrix of the threshold sample
-    u32* scan_w = nullptr;      unsigned* scan_ticks = nullptr; int scan_ticks_n = 0;   // scan kernel: XCD weights, per-workgroup times
     bool rebalance_pending = false; int rebalance_grid = 0;  // the exact re-run's launch also moves the full pass's tile boundaries
     int* fb_list = nullptr;     int* fb_count = nullptr;     unsigned long long* stat = nullptr;
     u64* partial = nullptr;     u64* partial2 = nullptr;     size_t partial_bytes = 0;
@@ -342,7 +341,7 @@ extern "C" int ts_index_destroy(ts_index* ix) {
         if (ix->parent) ix->parent->nviews.fetch_sub(1);
     }
     if (ix->attached) ix->rows = nullptr;
-    void* ptrs[] = {ix->rows,  ix->stage,   ix->qstore,   ix->qf32,     ix->cand,       ix->count,  ix->thr, ix->priv, ix->pcount, ix->sample, ix->scan_w, ix->scan_ticks, ix->mask_dev, ix->bias_dev, ix->rank_buf, ix->id_map,
+    void* ptrs[] = {ix->rows,  ix->stage,   ix->qstore,   ix->qf32,     ix->cand,       ix->count,  ix->thr, ix->priv, ix->pcount, ix->sample, ix->mask_dev, ix->bias_dev, ix->rank_buf, ix->id_map,
                     ix->fb_list, ix->fb_count, ix->stat, ix->partial, ix->partial2, ix->res_scores, ix->res_idx, ix->dbg, ix->part, ix->wg_ticks};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -804,7 +803,7 @@ static int launch_scan(const ts_index* ix, ScanArgs a, int qb_pref, hipStream_t 
 
 // Reduce [slots][m] partial keys to the final k per query: select rounds of 4096-key segments.
 static int run_select_rounds(ts_index* ix, int slots, int m, int k, float* out_scores, int64_t* out_idx, const int* qlist,
-                             const int* qcount, hipStream_t st, int balance_grid = 0) {
+                             const int* qcount, hipStream_t st) {
     const u64* in = ix->partial;
     u64* scratch[2] = {ix->partial2, ix->partial};
     int which = 0;
@@ -831,17 +830,8 @@ static int run_select_rounds(ts_index* ix, int slots, int m, int k, float* out_s
             a.qcount = qcount;
             a.out_scores = out_scores;
             a.out_idx = out_idx;
-            if (balance_grid > 0) {                 // one more workgroup: new XCD weights for the next scan
-                a.xcd_w = ix->scan_w;
-                a.scan_ticks = ix->scan_ticks;
-                a.scan_grid = balance_grid;
-                a.nslots = slots;
-                const int b = ix->knobs.get(K_SCAN_BALANCE, 0);
-                a.xcd_gain = (b >= 2 && b <= 10) ? 0.1f * (float)b : 0.5f;
-            }
-            const int nblk = slots + (balance_grid > 0 ? 1 : 0);
-            if (k <= 64) select_hist_kernel<1><<<nblk, kLevelThreads, kHistSelectLds, st>>>(a);
-            else select_hist_kernel<4><<<nblk, kLevelThreads, kHistSelectLds, st>>>(a);
+            if (k <= 64) select_hist_kernel<1><<<slots, kLevelThreads, kHistSelectLds, st>>>(a);
+            else select_hist_kernel<4><<<slots, kLevelThreads, kHistSelectLds, st>>>(a);
             HIP_TRY(hipGetLastError());
             return TS_OK;
         }
@@ -929,34 +919,12 @@ static int scan_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
     // (measured 0.18 of the HBM rate against 0.8 for one query per pass); the other shapes keep two waves
     const bool wide_k_one_wave = k > 64 && ix->dtype == TS_BF16 && (ix->ld == 768 || ix->ld == 384);
     const int qb = ((nq >= 2 || qcount) && !wide_k_one_wave) ? 4 : 1;
-    // Feedback partition of the scan (TS_SCAN_BALANCE, off by default: DESIGN.md section 3.1 has the A/B): XCD weights from
-    // the previous pass's per-workgroup times; the one-launch select behind the pass computes the next ones
-    int balance_grid = 0;
-    if (!one_launch && ix->knobs.get(K_SCAN_BALANCE, 0) != 0 && (grid & 7) == 0 && grid * k > 1024 && grid * k <= kHistSelectMax &&
-        ix->n >= 262144) {
-        if (!ix->scan_w) {
-            HIP_TRY(hipMalloc((void**)&ix->scan_w, 8 * 4));
-            const u32 ones[8] = {65536, 65536, 65536, 65536, 65536, 65536, 65536, 65536};
-            HIP_TRY(hipMemcpy(ix->scan_w, ones, sizeof(ones), hipMemcpyHostToDevice));
-        }
-        if (ix->scan_ticks_n < grid) {
-            if (ix->scan_ticks) HIP_TRY(hipFree(ix->scan_ticks));
-            ix->scan_ticks = nullptr;
-            ix->scan_ticks_n = 0;
-            HIP_TRY(hipMalloc((void**)&ix->scan_ticks, (size_t)grid * 4));
-            HIP_TRY(hipMemset(ix->scan_ticks, 0, (size_t)grid * 4));
-            ix->scan_ticks_n = grid;
-        }
-        a.xcd_w = ix->scan_w;
-        a.scan_ticks = ix->scan_ticks;
-        balance_grid = grid;
-    }
     hipEvent_t stop = qcount ? nullptr : prof_begin(ix, st, ix->n);  // the MFMA path's fall-back pass is not bracketed
     launch_scan<false>(ix, a, qb, st, grid);
     prof_end(stop, st);
     HIP_TRY(hipGetLastError());
     if (one_launch) return TS_OK;
-    return run_select_rounds(ix, nq, grid * k, k, out_scores, out_idx, qlist, qcount, st, balance_grid);
+    return run_select_rounds(ix, nq, grid * k, k, out_scores, out_idx, qlist, qcount, st);
 }
 
 struct Level { int64_t stride, ntiles; int run; };

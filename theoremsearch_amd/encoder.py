@@ -501,7 +501,10 @@ class FusedBertForward:
         x = self.model.embeddings(input_ids=input_ids, token_type_ids=token_type_ids)
         B, S, H = x.shape
         hd = H // self.heads
-        mask = attention_mask[:, None, None, :].to(torch.bool)           # padding keys are never attended to
+        # padding keys are never attended to: ONE additive mask per forward (a boolean mask is expanded to a bias inside every
+        # scaled_dot_product_attention call: two fill launches per layer)
+        mask = torch.zeros((B, 1, 1, S), dtype=x.dtype, device=x.device).masked_fill_(
+            ~attention_mask[:, None, None, :].to(torch.bool), float("-inf"))
         for L in self.layers:
             qkv = F.linear(x, L["wqkv"], L["bqkv"]).view(B, S, 3, self.heads, hd).permute(2, 0, 3, 1, 4)
             ctx = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], attn_mask=mask)
