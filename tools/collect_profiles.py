@@ -54,7 +54,10 @@ def main(src, tag):
     for extra in ("clock_probe.json",):
         if os.path.exists(os.path.join(src, extra)):
             shutil.copy(os.path.join(src, extra), os.path.join(out, f"{tag}_{extra}"))
-    for w in ("c3", "c2", "c2b"):
+    stats = newest(glob.glob(os.path.join(src, "trace_c5", "**", "*kernel_stats.csv"), recursive=True))
+    if stats:
+        shutil.copy(stats[0], os.path.join(out, f"{tag}_c5_kernel_stats.csv"))
+    for w in ("c3", "c2", "c2b", "c5", "c1"):
         b = os.path.join(src, f"bench_{w}.json")
         if os.path.exists(b) and os.path.getsize(b) > 0:
             shutil.copy(b, os.path.join(out, f"{tag}_bench_{w}.json"))

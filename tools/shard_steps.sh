@@ -5,9 +5,9 @@ set -e
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$R/gpurun_out/${1:-shards}"
 mkdir -p "$OUT"
-timeout -k 10 300 python3 "$R/bench.py" --workload c3 --no-cpu-baseline --no-recall > "$OUT/steps_10000000.json" 2> "$OUT/steps_10000000.log"
+timeout -k 10 300 python3 "$R/bench.py" --workload c3 --no-cpu-baseline --no-recall --no-ceiling > "$OUT/steps_10000000.json" 2> "$OUT/steps_10000000.log"
 for n in 5000000 2500000 1250000; do
-  timeout -k 10 200 python3 "$R/bench.py" --workload c3 --rows $n --force-dist --no-cpu-baseline --no-recall > "$OUT/steps_$n.json" 2> "$OUT/steps_$n.log"
+  timeout -k 10 200 python3 "$R/bench.py" --workload c3 --rows $n --force-dist --no-cpu-baseline --no-recall --no-ceiling --steps 100 --warmup 10 > "$OUT/steps_$n.json" 2> "$OUT/steps_$n.log"
 done
 python3 - "$OUT" <<'PY'
 import json, sys
@@ -15,11 +15,14 @@ out = sys.argv[1]
 rows = {}
 for n in (10000000, 5000000, 2500000, 1250000):
     d = json.loads(open(f"{out}/steps_{n}.json").read().strip().splitlines()[-1])
-    rows[str(n)] = {"ms_per_step": d["ms_per_step"], "kernel_ms": d["roofline"]["kernel_ms"], "queries_per_s": d["value"]}
+    rows[str(n)] = {"ms_per_step": d["ms_per_step"], "kernel_ms": d["roofline"]["kernel_ms"], "queries_per_s": d["value"],
+                    "step_minus_kernel_ms": round(d["ms_per_step"] - d["roofline"]["kernel_ms"], 4),
+                    "sustained_ms_per_step": (d.get("sustained") or {}).get("ms_per_step")}
 whole = rows["10000000"]["ms_per_step"]
-res = {"note": "bench.py on ONE box, un-profiled, same build: the whole 10M x 768 bf16 corpus (no exchange) and its 2 / 4 / 8-way "
-               "shares with the exchange + merge path on (--rows N --force-dist, world 1): ms per step of 256 queries, "
-               "full-pass kernel ms, queries/s",
+res = {"note": "bench.py on ONE box, un-profiled, same build: the whole 10M x 768 bf16 corpus (no exchange; 20 timed steps with the "
+               "kernel timer's brackets, as the default run) and its 2 / 4 / 8-way shares with the exchange + merge path on "
+               "(--rows N --force-dist, world 1; 100 timed steps without brackets, kernel ms from the bracketed sustained leg "
+               "behind them): ms per step of 256 queries, full-pass kernel ms, queries/s",
        "rows": rows,
        "step_ratio_vs_whole_corpus": {k: round(whole / v["ms_per_step"], 2) for k, v in rows.items()}}
 json.dump(res, open(f"{out}/shard_steps.json", "w"), indent=1)
