@@ -34,7 +34,7 @@ def one_case(rng, big: bool, case: int = 0, watchdog: bool = True) -> str:
         n = int(rng.choice([1_000_000, 1_700_001, 2_500_000]))
         nq = int(rng.choice([5, 16, 33, 130]))
         k = int(rng.choice([1, 10, 10, 50, 256]))
-    mfma_ok = dtype == "bf16" and d in (384, 512, 768, 1024)
+    mfma_ok = d in (384, 512, 768, 1024)               # bf16, and fp32 on the exact-fp32 matrix instructions
     algo = str(rng.choice(["auto", "scan", "mfma"])) if mfma_ok else str(rng.choice(["auto", "scan"]))
     if big:
         algo = "auto" if rng.random() < 0.4 else "mfma"     # "auto" may carry a dense host mask (masked MFMA pass)
@@ -53,14 +53,38 @@ def one_case(rng, big: bool, case: int = 0, watchdog: bool = True) -> str:
         members = rng.choice(n, n // 25, replace=False)
         c[members] += (rng.random(members.size).astype(np.float32) * np.float32(4.0))[:, None] * u
     mask = (rng.random(n) < float(rng.choice([0.05, 0.3, 0.8]))) if use_mask else None
+    # round 3: now and then the citation-weighted ranking (scan kernel + one fp32 side array), or device queries in the
+    # storage form (read in place by the matrix kernels when they fill a launch; prepared otherwise)
+    mode = "plain"
+    if not big and algo != "mfma" and nq <= 8 and rng.random() < 0.3:
+        mode = "biased"
+    elif mask is None and metric == "ip" and rng.random() < 0.3:
+        mode = "device"
+    bias, w = None, 0.0
     with ts.TheoremIndex.from_embeddings(c, dtype=dtype, metric=metric) as ix:
-        if mask is not None:
+        if mode == "biased":
+            bias = np.log(rng.integers(1, 5000, n).astype(np.float64)).astype(np.float32) * (rng.random(n) < 0.8)
+            w = float(rng.choice([0.0, 0.001, 0.02]))
+            scores, _, idx = ix.search_biased(q, k, bias, w, mask=mask)
+        elif mode == "device":
+            import torch
+            qs = oracle.f32_to_bf16_bits(q) if dtype == "bf16" else q
+            qd = torch.from_numpy(qs.view(np.int16) if dtype == "bf16" else qs).cuda()
+            o_s = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+            o_i = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            ix.search_device(qd.data_ptr(), dtype, nq, k, o_s.data_ptr(), o_i.data_ptr(), 0, algo=algo)
+            ix.synchronize()
+            scores, idx = o_s.cpu().numpy(), o_i.cpu().numpy()
+        elif mask is not None:
             scores, idx = ix.search(q, k, mask=mask)
         else:
             scores, idx = ix.search(q, k, algo=algo)
     rows = np.flatnonzero(mask) if mask is not None else np.arange(n)
     qp, cp = oracle.prepared_inputs(q, c[rows], metric, dtype)
     truth = oracle.scores_fp64(qp, cp)
+    if mode == "biased":
+        truth = truth + w * bias[rows].astype(np.float64)[None, :]
     m = min(k, rows.size)
     local = np.full_like(idx, -1)
     valid = idx >= 0
@@ -71,7 +95,7 @@ def one_case(rng, big: bool, case: int = 0, watchdog: bool = True) -> str:
     assert stats["recall"] == 1.0, stats
     if watchdog:
         faulthandler.cancel_dump_traceback_later()
-    return (f"case {case}: n={n} d={d} {dtype} {metric} nq={nq} k={k} algo={algo} mask={use_mask} ok "
+    return (f"case {case}: n={n} d={d} {dtype} {metric} nq={nq} k={k} algo={algo} mask={use_mask} {mode} ok "
             f"({time.time() - t0:.1f}s)")
 
 
