@@ -484,3 +484,24 @@ def test_fused_bert_forward_matches_the_models_own(encoder):
         w32 = f32.model(input_ids=e32["input_ids"], attention_mask=e32["attention_mask"]).last_hidden_state
         g32 = f32.forward_hidden(e32["input_ids"], e32["attention_mask"])
     assert (w32 - g32)[e32["attention_mask"].bool()].abs().max().item() < 2e-4
+
+
+def test_bench_under_torch_distributed_run_with_two_ranks_sharing_the_gpu():
+    """The driver's launch form for N > 1 (python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N), rehearsed
+    with two ranks on the box's one GPU (--share-gpu: gloo carries the exchange through host memory, RCCL refuses two ranks
+    per GPU): shard bounds, the bare timed region + bracketed sustained leg, max-over-ranks timing, the merged parity check
+    and the single JSON line of rank 0."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--rows", "600000",
+           "--nq", "64", "--steps", "3", "--warmup", "1", "--sustained-steps", "4"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 2 and doc["steps"] == 3 and doc["recall_at_10"] == 1.0 and doc["parity"]["violations"] == 0
+    assert doc["config"]["rows"] == 600000 and "x2" in doc["config"]["parallelism"]
+    assert doc["sustained"]["steps"] == 4 and doc["roofline"]["kernel_ms"] > 0 and doc["cpu_baseline"] is None
