@@ -440,3 +440,30 @@ def test_pgvector_adapter_exact_form_equals_the_pool_form_when_the_pool_holds_th
         exact = pgvector.search(ix, q[0], k, citation_weight=0.05, citations=cites, exact=True)
         assert exact[0]["row"] == far and far not in [r["row"] for r in pool]
 
+
+
+def test_biased_search_argument_checks(ts):
+    import ctypes as C
+    from theoremsearch_amd import _ffi
+    lib = _ffi.load()
+    q, c = oracle.golden_inputs(3000, 2, 768, 5, "ip")
+    with ts.TheoremIndex.from_embeddings(c, metric="ip") as ix:
+        bias = np.zeros(3000, np.float32)
+        with pytest.raises(ValueError):
+            ix.search_biased(q, 5, bias[:10], 0.1)                       # one value per row
+        s = np.empty((2, 5), np.float32)
+        i = np.empty((2, 5), np.int64)
+        args = (ix.handle, _ffi.as_ptr(q), 0, 0, 2, 5)
+        assert lib.ts_search_biased(*args, None, 0, 0.1, None, 0, _ffi.as_ptr(s), None, _ffi.as_ptr(i), 0, None) == -1   # bias NULL
+        assert lib.ts_search_biased(*args, _ffi.as_ptr(bias), 0, float("nan"), None, 0, _ffi.as_ptr(s), None, _ffi.as_ptr(i), 0, None) == -1
+        assert lib.ts_search_biased(*args, _ffi.as_ptr(bias), 0, 0.1, None, 0, _ffi.as_ptr(s), None, _ffi.as_ptr(i), 0, None) == 0   # out_sims optional
+        sub = ix.subset(np.arange(0, 3000, 3))
+        with pytest.raises(_ffi.TSearchError) as e:
+            sub.search_biased(q, 5, bias[:1000], 0.1)
+        assert e.value.code == -5
+        sub.close()
+        # k results fewer than k rows allowed: padded like every search
+        mask = np.zeros(3000, bool)
+        mask[[5, 17]] = True
+        ws, sims, idx = ix.search_biased(q, 5, bias, 0.1, mask=mask)
+        assert set(idx[0, :2].tolist()) == {5, 17} and (idx[:, 2:] == -1).all() and np.isneginf(ws[:, 2:]).all() and np.isneginf(sims[:, 2:]).all()

@@ -6,15 +6,15 @@
 // for ONE tile of work, every score appended to lane-private lists that the select then gathered from 1,024 writers):
 // 30-36 us + 21-24 us per search, whatever the corpus size - a tenth of the step of an eighth-of-the-corpus shard.  This
 // kernel is shaped for the sample instead, and for latency: the whole launch is two memory round trips deep.
-//   * a workgroup takes RB blocks of 16 sample rows (bf16: 64 rows, fp32: 32) and brings them into LDS by LDS-DMA
+//   * a workgroup takes RB = 2 blocks of 16 sample rows and brings them into LDS by LDS-DMA
 //     (global_load_lds_dwordx4), all pieces in flight at once: every 128-byte line of a row is fetched once, in ONE round trip to HBM
 //     (a first version read operand fragments straight from global memory, 64 bytes of each row per k-step: a chain of
 //     six dependent HBM round trips, 22 us at 4,096 rows and 44 us at 8,192);
 //   * the queries come from L2 (every workgroup reads the same 393 KB) as MFMA B fragments, one 16-byte load per k-step
 //     and lane, all of a 64-query chunk in flight at once; wave w holds queries 16 w .. 16 w + 15 of the chunk;
-//   * a workgroup serves `chunks_per_wg` query chunks in turn; the host picks it so that the launch fills the chip once
-//     (4,096 rows x 256 bf16 queries: 64 row groups x 4 chunks = 256 workgroups of one chunk each; a first cut with every
-//     chunk looped inside 64 workgroups took 36 us against 15 for this shape: the chunks are independent work).
+//   * a workgroup serves `chunks_per_wg` query chunks in turn (the host passes 1: 4,096 rows x 256 queries = 128 row
+//     groups x 4 chunks = 512 workgroups, two to a CU; a first cut with every chunk looped inside 64 workgroups of 64 rows
+//     took 36 us against 15 for this shape: the chunks are independent work).
 //
 // Arithmetic: v_mfma_f32_16x16x32_bf16 (bf16 rows) or v_mfma_f32_16x16x4_f32 (fp32 rows: float i of a 16-byte chunk times
 // float i of the matching query chunk, as the full pass does).  The sums may differ from the full pass's in the order of
@@ -45,7 +45,7 @@ struct SampleArgs {
 constexpr int kSampleRowPad = 16;                                   // bytes: rows land 4 banks apart, the 16-row reads spread out
 constexpr int sample_lds_bytes(int rows, int row_bytes) { return rows * (row_bytes + kSampleRowPad); }
 
-// RB = row blocks of 16 per workgroup (bf16: 4, fp32: 2).  grid = (row_stride / (16 RB), ceil(chunks / chunks_per_wg)),
+// RB = row blocks of 16 per workgroup (2: 32 rows).  grid = (row_stride / (16 RB), ceil(chunks / chunks_per_wg)),
 // 256 threads, dynamic LDS = sample_lds_bytes(16 RB, ld * elem).
 template <bool F32, int RB>
 __global__ void __launch_bounds__(256) sample_scores_kernel(SampleArgs a) {

@@ -1284,15 +1284,13 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
             sa.row_stride = (int)((lv[0].ntiles * kTileRows + 63) / 64 * 64);
             sa.fb_count = ix->fb_count;
             sa.stat = ix->stat;
-            // 32 rows per workgroup and one 64-query chunk (bf16 at 4,096 rows x 256 queries: 512 workgroups of 50 KB LDS,
-            // two or three to a CU; TS_MFMA_SAMPLE=2: 64 rows and as many chunks per workgroup as keep the launch within one
-            // workgroup per CU - the chunks of one row group re-read its rows from L2 either way)
+            // 32 rows per workgroup and one 64-query chunk: 512 workgroups of 50 KB LDS at 4,096 rows x 256 queries, two to
+            // a CU (64-row workgroups serving two chunks each measured the same: 15.2 / 25.0 us against 14.9 / 24.3 us at
+            // 4,096 / 8,192 rows - the launch is latency, not work)
             const bool f32 = ix->dtype == TS_F32;
             const int nchunks = (nq + 63) / 64;
-            const bool wide = !f32 && ix->knobs.get(K_MFMA_SAMPLE, 1) == 2;
-            const int wg_rows = wide ? 64 : 32;
-            const int row_groups = sa.row_stride / wg_rows;
-            sa.chunks_per_wg = wide ? std::min(nchunks, std::max(1, (row_groups * nchunks + ix->cu_count - 1) / ix->cu_count)) : 1;
+            const int wg_rows = 32;
+            sa.chunks_per_wg = 1;
             const dim3 sgrid((unsigned)(sa.row_stride / wg_rows), (unsigned)((nchunks + sa.chunks_per_wg - 1) / sa.chunks_per_wg));
             const int slds = sample_lds_bytes(wg_rows, (int)(ix->ld * ix->elem()));
             if (slds > 160 * 1024) return fail(TS_ERR_INTERNAL, "threshold sample: rows of %lld bytes do not fit the LDS", (long long)(ix->ld * ix->elem()));
@@ -1304,12 +1302,10 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
                 if (!(sample_attr.load(std::memory_order_acquire) & bit)) {
                     HIP_TRY(hipFuncSetAttribute((const void*)sample_scores_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                     HIP_TRY(hipFuncSetAttribute((const void*)sample_scores_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                    HIP_TRY(hipFuncSetAttribute((const void*)sample_scores_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                     sample_attr.fetch_or(bit, std::memory_order_release);
                 }
             }
             if (f32) sample_scores_kernel<true, 2><<<sgrid, 256, slds, st>>>(sa);
-            else if (wide) sample_scores_kernel<false, 4><<<sgrid, 256, slds, st>>>(sa);
             else sample_scores_kernel<false, 2><<<sgrid, 256, slds, st>>>(sa);
             HIP_TRY(hipGetLastError());
             LevelArgs l;
