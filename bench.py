@@ -302,7 +302,8 @@ def main():
 
     def encode_queries():
         with torch.inference_mode():
-            hidden = encoder.forward_hidden(tok_ids, tok_mask)      # fused BERT forward (QKV as one GEMM, add + LayerNorm as one kernel)
+            # fused BERT forward (QKV as one GEMM, add + LayerNorm as one kernel); the synthetic batch has no padding
+            hidden = encoder.forward_hidden(tok_ids, tok_mask, no_padding=True)
             # fused mean-pool + L2 normalise + round to bf16 (ts_pool_normalize): the form the bf16 index multiplies, read in
             # place by the search - no fp32 round trip, no preparation launch
             return encoder.pool(hidden, tok_mask, True, out_dtype=torch.bfloat16 if bf16 else torch.float32)

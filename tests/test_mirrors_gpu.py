@@ -468,6 +468,13 @@ def test_fused_bert_forward_matches_the_models_own(encoder):
         got = encoder.forward_hidden(enc["input_ids"], enc["attention_mask"]).float()
     real = enc["attention_mask"].bool()
     assert (want - got)[real].abs().max().item() < 0.15 and (want - got)[real].abs().mean().item() < 0.01
+    same = [texts[0]] * 5                                    # no padding: the attention runs without a mask
+    es = {k: v.cuda() for k, v in encoder._tokenize(same).items()}
+    assert bool(es["attention_mask"].all())
+    with torch.inference_mode():
+        w_ = encoder.model(input_ids=es["input_ids"], attention_mask=es["attention_mask"]).last_hidden_state.float()
+        g_ = encoder.forward_hidden(es["input_ids"], es["attention_mask"], no_padding=True).float()
+    assert (w_ - g_).abs().max().item() < 0.15 and (w_ - g_).abs().mean().item() < 0.01
     fused = encoder.encode(texts, normalize_embeddings=True, convert_to_numpy=True)
     os.environ["TS_ENCODER_FUSED"] = "0"
     try:

@@ -151,14 +151,26 @@ __global__ void __launch_bounds__(256) add_layernorm_kernel(const void* __restri
     };
     const uint4* pa = (const uint4*)a + row * nchunk;
     const uint4* pb = (const uint4*)b + row * nchunk;
+    // every load of the row - the two operands, gamma and beta - is requested before the first use: one memory round trip
+    uint4 ra[kLnMax], rb[kLnMax], rg[kLnMax], re[kLnMax];
+#pragma unroll
+    for (int j = 0; j < kLnMax; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nchunk) {
+            ra[j] = pa[c];
+            rb[j] = pb[c];
+            rg[j] = ((const uint4*)gamma)[c];
+            re[j] = ((const uint4*)beta)[c];
+        }
+    }
     float sum = 0.0f;
 #pragma unroll
     for (int j = 0; j < kLnMax; ++j) {
         const int c = lane + 64 * j;
         if (c < nchunk) {
             float fa[VEC], fb[VEC];
-            unpack(pa[c], fa);
-            unpack(pb[c], fb);
+            unpack(ra[j], fa);
+            unpack(rb[j], fb);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 x[j][e] = fa[e] + fb[e];
@@ -190,8 +202,8 @@ __global__ void __launch_bounds__(256) add_layernorm_kernel(const void* __restri
         const int c = lane + 64 * j;
         if (c < nchunk) {
             float g[VEC], be[VEC], y[VEC];
-            unpack(((const uint4*)gamma)[c], g);
-            unpack(((const uint4*)beta)[c], be);
+            unpack(rg[j], g);
+            unpack(re[j], be);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) y[e] = (x[j][e] - mean) * rstd * g[e] + be[e];
             uint4 o;

@@ -281,16 +281,20 @@ class SentenceEncoder:
         out = torch.empty((len(texts), self.embedding_dim), dtype=torch.float32, device=self.device)
         for start in range(0, len(texts), batch_size):
             sel = order[start:start + batch_size]
-            enc = {k: v.to(self.device) for k, v in self._tokenize([texts[i] for i in sel]).items()}
+            tok = self._tokenize([texts[i] for i in sel])
+            no_padding = bool(tok["attention_mask"].all())                  # decided on the host copy: no device sync
+            enc = {k: v.to(self.device) for k, v in tok.items()}
             fwd = {k: v for k, v in enc.items() if k in ("input_ids", "attention_mask", "token_type_ids")}
-            hidden = self.forward_hidden(**fwd)
+            hidden = self.forward_hidden(**fwd, no_padding=no_padding)
             out[torch.as_tensor(sel, device=self.device)] = self.pool(hidden, enc["attention_mask"], normalize_embeddings)
         return out
 
-    def forward_hidden(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, token_type_ids=None) -> torch.Tensor:
-        """Last hidden state ``[n x seq x d]`` of the transformer: the fused BERT forward where it applies, else the model's."""
+    def forward_hidden(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, token_type_ids=None,
+                       no_padding: bool = False) -> torch.Tensor:
+        """Last hidden state ``[n x seq x d]`` of the transformer: the fused BERT forward where it applies, else the model's.
+        ``no_padding=True``: the caller knows ``attention_mask`` is all ones (the attention then runs without a mask)."""
         if self._fused is not None:
-            return self._fused(input_ids, attention_mask, token_type_ids)
+            return self._fused(input_ids, attention_mask, token_type_ids, no_padding=no_padding)
         kw = {"input_ids": input_ids, "attention_mask": attention_mask}
         if token_type_ids is not None:
             kw["token_type_ids"] = token_type_ids
@@ -496,14 +500,16 @@ class FusedBertForward:
             C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)))
         return out
 
-    def __call__(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, token_type_ids: Optional[torch.Tensor] = None):
+    def __call__(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, token_type_ids: Optional[torch.Tensor] = None,
+                 no_padding: bool = False):
         F = torch.nn.functional
         x = self.model.embeddings(input_ids=input_ids, token_type_ids=token_type_ids)
         B, S, H = x.shape
         hd = H // self.heads
         # padding keys are never attended to: ONE additive mask per forward (a boolean mask is expanded to a bias inside every
-        # scaled_dot_product_attention call: two fill launches per layer)
-        mask = torch.zeros((B, 1, 1, S), dtype=x.dtype, device=x.device).masked_fill_(
+        # scaled_dot_product_attention call: two fill launches per layer); none at all when the caller knows the batch has no
+        # padding (every sequence as long as the batch: 50 instead of 60 us per layer for projections + attention)
+        mask = None if no_padding else torch.zeros((B, 1, 1, S), dtype=x.dtype, device=x.device).masked_fill_(
             ~attention_mask[:, None, None, :].to(torch.bool), float("-inf"))
         for L in self.layers:
             qkv = F.linear(x, L["wqkv"], L["bqkv"]).view(B, S, 3, self.heads, hd).permute(2, 0, 3, 1, 4)
