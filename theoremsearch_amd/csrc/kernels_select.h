@@ -419,123 +419,6 @@ __global__ void __launch_bounds__(kLevelThreads) sample_select_kernel(LevelArgs 
     if (threadIdx.x == 0) a.thr[q] = thr;
 }
 
-// ---- one wave per query ---------------------------------------------------------------------------------------------------
-// The two selects of a batched search are small jobs (64 candidates per query at the final level; 4,096 or 8,192 sample
-// scores per query of which the 32 best and two moments matter) that the one-workgroup-per-query kernels above pay 12 and
-// 15-21 us for: 512 threads, 130 KB of LDS, a dozen workgroup barriers each.  One WAVE per query does them with no barrier
-// and no LDS beyond a 2 KB hand-over: a running top-k over the candidates (WaveTopK: only keys that beat the current k-th
-// are inserted, k ln(n / k) of them), the loads of 256 keys in flight together.  Four queries per workgroup.
-
-// Final level of the 16x16 full pass (candidates staged to the shared list only): the k best candidates of query q, or the
-// query's number on the re-run list when candidates were lost (list overflow) or fewer than min_fill came back.
-template <int KR>
-__global__ void __launch_bounds__(256) final_select_wave_kernel(LevelArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= a.nq) return;
-    const u32 raw = a.count[q];
-    const u32 ns = min(raw, (u32)a.cap);
-    const u64* src = a.cand + (int64_t)q * a.cap;
-    WaveTopK<KR> tk;
-    tk.init();
-    for (u32 i0 = 0; i0 < ns; i0 += 256) {
-        u64 key[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const u32 i = i0 + 64 * j + lane;
-            key[j] = (i < ns) ? src[i] : 0ull;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            u64 m = __ballot(key[j] > tk.thr);
-            while (m) {
-                const int from = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const u64 K = shfl_u64(key[j], from);
-                if (K > tk.thr) tk.insert(K, a.k_user, lane);
-            }
-        }
-    }
-    if (lane == 0) {
-        a.count[q] = 0;
-        atomicAdd(a.stat_candidates, (unsigned long long)raw);
-    }
-    if (raw > (u32)a.cap || (int)ns < a.min_fill) {
-        if (lane == 0) a.fb_list[atomicAdd(a.fb_count, 1)] = q;
-        return;
-    }
-#pragma unroll
-    for (int r = 0; r < KR; ++r) {
-        const int i = r * 64 + lane;
-        if (i < a.k_user) {
-            const u64 key = tk.key[r];
-            a.out_scores[(int64_t)q * a.k_user + i] = key ? key_score(key) : -INFINITY;
-            a.out_idx[(int64_t)q * a.k_user + i] = !key ? -1 : a.id_map ? a.id_map[key_row(key)] : (int64_t)key_row(key) + a.row_offset;
-        }
-    }
-}
-
-// Sample level, dense form: thr[q] from query q's row of the sample score matrix - the kl best scores by a running top-kl,
-// mean and standard deviation of all live scores in the same sweep (fp64 sums), then level_threshold as everywhere.
-template <int KR>
-__global__ void __launch_bounds__(256) sample_select_wave_kernel(LevelArgs a, const float* scores, int row_stride, int npos) {
-    __shared__ u64 best_all[4][TS_MAX_K_INTERNAL];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q = blockIdx.x * 4 + wave;
-    if (q >= a.nq) return;
-    u64* best = best_all[wave];
-    const float* src = scores + (int64_t)q * row_stride;
-    const int m = min(npos, kLevelSortMax);
-    const int kk = a.kk;
-    constexpr int kTailM = 32;
-    const bool tail_fit = a.tail_p > 0.0f;
-    const int kl = tail_fit ? max(kk, kTailM) : kk;
-    WaveTopK<KR> tk;
-    tk.init();
-    double s1 = 0.0, s2 = 0.0;
-    int cnt = 0;
-    for (int i0 = 0; i0 < m; i0 += 256) {                   // row_stride is a multiple of 64 and positions >= npos hold -inf
-        const int i = i0 + 4 * lane;
-        const float4 v = (i < row_stride) ? *(const float4*)(src + i) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-        const float sc[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const bool live = (i + e < m) && sc[e] == sc[e] && sc[e] > -INFINITY;
-            if (live) {
-                s1 += (double)sc[e];
-                s2 += (double)sc[e] * (double)sc[e];
-                ++cnt;
-            }
-            const u64 key = live ? make_key(sc[e], (u32)(i + e)) : 0ull;
-            u64 mm = __ballot(key > tk.thr);
-            while (mm) {
-                const int from = __ffsll((long long)mm) - 1;
-                mm &= mm - 1;
-                const u64 K = shfl_u64(key, from);
-                if (K > tk.thr) tk.insert(K, kl, lane);
-            }
-        }
-    }
-    s1 = wave_sum_f64_sel(s1);
-    s2 = wave_sum_f64_sel(s2);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-    double mean = 0.0, sd = 0.0;
-    if (cnt > 0) {
-        mean = s1 / cnt;
-        sd = sqrt(fmax(s2 / cnt - mean * mean, 0.0));
-    }
-#pragma unroll
-    for (int r = 0; r < KR; ++r) best[r * 64 + lane] = tk.key[r];     // sorted descending, zero = empty
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    const float thr = level_threshold(a, best, cnt, kk, tail_fit, mean, sd);
-    if (lane == 0) {
-        a.thr[q] = thr;
-        a.count[q] = 0;                                       // the shared list of the full pass starts empty
-    }
-}
-
 // One-launch reduction of the scan's partial lists (up to kHistSelectMax keys per query: 1024 workgroups x k <= 12) to the
 // final k: the keys are loaded into LDS (empty slots squeezed out by ballot), then lds_select_top's histogram cut + short
 // sort.  Replaces two select_kernel rounds (10 bitonic sorts of 1024 keys + a final one: 22 + 7 us and a kernel boundary)

@@ -61,13 +61,13 @@ enum Knob {
     K_MFMA_MIN_RANK, K_MFMA_VARIANT, K_MFMA_GROUPS, K_MFMA_GRID, K_MFMA_STAT, K_MFMA_STAT_CANDS, K_MFMA_TAIL_FIT,
     K_MFMA_NO_IDLE, K_MFMA_AHEAD, K_MFMA_TARGET_CANDS, K_MFMA_FIRST_ROWS, K_MFMA_TARGET_SPARSE, K_MFMA_RUN,
     K_MFMA_MIN_ROWS, K_MFMA_SHAPE, K_MFMA_F32, K_SCAN_GENERIC, K_SCAN_MAX_QUERIES, K_MFMA_BALANCE, K_PROBE_SPREAD, K_MFMA_SAMPLE,
-    K_MFMA_WAVE_SELECT, K_COUNT
+    K_COUNT
 };
 static const char* const kKnobNames[K_COUNT] = {
     "TS_MFMA_MIN_RANK", "TS_MFMA_VARIANT", "TS_MFMA_GROUPS", "TS_MFMA_GRID", "TS_MFMA_STAT", "TS_MFMA_STAT_CANDS",
     "TS_MFMA_TAIL_FIT", "TS_MFMA_NO_IDLE", "TS_MFMA_AHEAD", "TS_MFMA_TARGET_CANDS", "TS_MFMA_FIRST_ROWS",
     "TS_MFMA_TARGET_SPARSE", "TS_MFMA_RUN", "TS_MFMA_MIN_ROWS", "TS_MFMA_SHAPE", "TS_MFMA_F32", "TS_SCAN_GENERIC",
-    "TS_SCAN_MAX_QUERIES", "TS_MFMA_BALANCE", "TS_PROBE_SPREAD", "TS_MFMA_SAMPLE", "TS_MFMA_WAVE_SELECT"};
+    "TS_SCAN_MAX_QUERIES", "TS_MFMA_BALANCE", "TS_PROBE_SPREAD", "TS_MFMA_SAMPLE"};
 struct Knobs {
     int v[K_COUNT];
     bool set[K_COUNT];
@@ -1207,7 +1207,6 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
     // latter stays selectable (TS_MFMA_SAMPLE=0) as the A/B partner and serves the thresholded sparse levels of the
     // guaranteed chain (TS_MFMA_STAT=0).
     const bool dense_sample = ix->knobs.get(K_MFMA_SAMPLE, 1) != 0;
-    const bool wave_select = ix->knobs.get(K_MFMA_WAVE_SELECT, 1) != 0;
     if (dense_sample && !ix->sample) HIP_TRY(hipMalloc((void**)&ix->sample, (size_t)kMfmaQ * kLevelSortMax * 4));
     const int grid = std::max(1, std::min(ix->knobs.get(K_MFMA_GRID, ix->cu_count), 2048));
     // lane-private candidate lists: 2 writers x 32 entries per workgroup and query (32x32 shape) or 4 x 16 (16x16 shape)
@@ -1321,11 +1320,7 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
             l.tail_p = tail_p;
             l.tail_z = (float)normal_tail_z(std::min(0.25, 32.0 / sample_rows));
             l.nq = nq;
-            // one wave per query (TS_MFMA_WAVE_SELECT=0: one workgroup per query, the A/B partner)
-            if (wave_select) {
-                if (kk <= 64) sample_select_wave_kernel<1><<<(nq + 3) / 4, 256, 0, st>>>(l, ix->sample, sa.row_stride, (int)(lv[0].ntiles * kTileRows));
-                else sample_select_wave_kernel<4><<<(nq + 3) / 4, 256, 0, st>>>(l, ix->sample, sa.row_stride, (int)(lv[0].ntiles * kTileRows));
-            } else if (kk <= 64) sample_select_kernel<1><<<nq, kLevelThreads, kLevelLds, st>>>(l, ix->sample, sa.row_stride, (int)(lv[0].ntiles * kTileRows));
+            if (kk <= 64) sample_select_kernel<1><<<nq, kLevelThreads, kLevelLds, st>>>(l, ix->sample, sa.row_stride, (int)(lv[0].ntiles * kTileRows));
             else sample_select_kernel<4><<<nq, kLevelThreads, kLevelLds, st>>>(l, ix->sample, sa.row_stride, (int)(lv[0].ntiles * kTileRows));
             HIP_TRY(hipGetLastError());
             continue;
@@ -1470,10 +1465,7 @@ static int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* 
         l.fb_count = ix->fb_count;
         l.stat_candidates = ix->stat;
         l.nq = nq;
-        if (wave_select && full_pass && l.nwriters == 0) {      // the 16x16 full pass: one shared list per query, one wave each
-            if (k <= 64) final_select_wave_kernel<1><<<(nq + 3) / 4, 256, 0, st>>>(l);
-            else final_select_wave_kernel<4><<<(nq + 3) / 4, 256, 0, st>>>(l);
-        } else if (kk <= 64) level_select_kernel<1><<<nq, kLevelThreads, kLevelLds, st>>>(l);
+        if (kk <= 64) level_select_kernel<1><<<nq, kLevelThreads, kLevelLds, st>>>(l);
         else level_select_kernel<4><<<nq, kLevelThreads, kLevelLds, st>>>(l);
         HIP_TRY(hipGetLastError());
     }
