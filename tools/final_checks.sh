@@ -3,7 +3,7 @@
 # on one GPU.
 set -e
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
-OUT="$R/gpurun_out/${1:-r03b}"
+OUT="$R/gpurun_out/${1:-checks}"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 bash "$R/tools/shard_steps.sh" "$(basename "$OUT")" > "$OUT/shard_steps.log" 2>&1 || echo "shard steps failed" >&2
