@@ -220,7 +220,10 @@ class TheoremIndex:
                       stream: int = 0, algo: str = "auto", mask_ptr: int = 0) -> None:
         """Asynchronous search on device buffers (queries [nq x d] dense; outputs [nq x k] f32 / i64),
         enqueued on ``stream`` (0 = the index's own stream).  ``mask_ptr``: device uint32 bitmask
-        (ceil(n / 32) words) restricting the rows, see `search`."""
+        (ceil(n / 32) words) restricting the rows, see `search`.
+        Queries that already have the form the matrix kernels multiply (the index's dtype, an inner-product index, a
+        whole launch's worth: 64 / 128 / 192 / 256 of them) are read in place - keep them unchanged until the enqueued work
+        has run (work enqueued later on the same stream is ordered behind it anyway)."""
         if mask_ptr:
             _ffi.check(self._lib.ts_search_filtered(self._h, C.c_void_p(q_ptr), _DTYPES[q_dtype], 1, int(nq), int(k),
                                                     C.c_void_p(mask_ptr), 1, C.c_void_p(out_scores_ptr),
