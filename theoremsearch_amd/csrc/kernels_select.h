@@ -480,9 +480,13 @@ struct MergeArgs {
 
 constexpr int kMergeMax = 4096;
 
+// CAP = LDS entries per workgroup (>= the power of two that holds nparts * k_in).  The exchange of the sharded search
+// merges 8 x 10 candidates per query: with CAP = 128 the workgroup is one wave and 1.5 KB of LDS, so the merge on the side
+// stream does not take CU slots from the next batch's threshold sample (the 4,096-entry form holds 48 KB per workgroup).
+template <int CAP>
 __global__ void __launch_bounds__(256) merge_kernel(MergeArgs a) {
-    __shared__ u32 so[kMergeMax];
-    __shared__ int64_t si[kMergeMax];
+    __shared__ u32 so[CAP];
+    __shared__ int64_t si[CAP];
     const int q = blockIdx.x;
     const int m = a.nparts * a.k_in;
     int P = 2;
@@ -526,6 +530,13 @@ __global__ void __launch_bounds__(256) merge_kernel(MergeArgs a) {
         a.out_scores[(int64_t)q * a.k_out + i] = ok ? unord_f32(so[i]) : -INFINITY;
         a.out_idx[(int64_t)q * a.k_out + i] = ok ? si[i] : -1;
     }
+}
+
+inline void launch_merge(const MergeArgs& a, hipStream_t st) {
+    const int m = a.nparts * a.k_in;
+    if (m <= 128) merge_kernel<128><<<a.nq, 64, 0, st>>>(a);
+    else if (m <= 1024) merge_kernel<1024><<<a.nq, 256, 0, st>>>(a);
+    else merge_kernel<kMergeMax><<<a.nq, 256, 0, st>>>(a);
 }
 
 }  // namespace ts

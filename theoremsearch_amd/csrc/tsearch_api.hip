@@ -1950,7 +1950,7 @@ extern "C" int ts_merge_topk(int device, const float* scores, const int64_t* idx
     const size_t nin = (size_t)nparts * nq * k_in, nout = (size_t)nq * k_out;
     if (on_device) {
         a.scores = scores; a.idx = idx; a.out_scores = out_scores; a.out_idx = out_idx;
-        merge_kernel<<<nq, 256, 0, st>>>(a);
+        launch_merge(a, st);
         HIP_TRY(hipGetLastError());
         return TS_OK;
     }
@@ -1964,7 +1964,7 @@ extern "C" int ts_merge_topk(int device, const float* scores, const int64_t* idx
     HIP_TRY(hipMemcpyAsync(ds, scores, nin * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(di, idx, nin * 8, hipMemcpyHostToDevice, st));
     a.scores = ds; a.idx = di; a.out_scores = dos; a.out_idx = doi;
-    merge_kernel<<<nq, 256, 0, st>>>(a);
+    launch_merge(a, st);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_scores, dos, nout * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(out_idx, doi, nout * 8, hipMemcpyDeviceToHost, st));
@@ -2084,7 +2084,7 @@ extern "C" int ts_merge_topk_packed(int device, const void* packed, int64_t part
     a.part_stride_idx = part_stride_bytes / 8;
     a.out_scores = out_scores;
     a.out_idx = out_idx;
-    merge_kernel<<<nq, 256, 0, (hipStream_t)stream>>>(a);
+    launch_merge(a, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return TS_OK;
 }
