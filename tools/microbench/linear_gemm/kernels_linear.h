@@ -69,11 +69,15 @@ __device__ __forceinline__ void lin_mfma(f32x4& acc, const bf16x8& wfrag, const 
     if constexpr (AG) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(wfrag), "v"(xfrag));
     else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(wfrag), "v"(xfrag));
 }
-__device__ __forceinline__ void lin_settle() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }
+__device__ __forceinline__ void lin_settle() { asm volatile("s_nop 15\n\ts_nop 3" ::: "memory"); }
 
 __device__ __forceinline__ float gelu_erf(float v) { return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
 
-constexpr int linear_lds_bytes(int BM, int BN, int S) { return S * (((BM + BN) / 8 + 3) / 4) * 4096; }
+constexpr int linear_stage_pitch(int BN) { return BN * 2 + 16; }   // bytes per row of the epilogue's staging tile
+constexpr int linear_lds_bytes(int BM, int BN, int S) {
+    const int ring = S * (((BM + BN) / 8 + 3) / 4) * 4096, stage = BM * linear_stage_pitch(BN);
+    return ring > stage ? ring : stage;
+}
 
 // ACT: 0 = none, 1 = exact erf GELU (of the bf16-rounded sum, as an elementwise GELU behind a bf16 GEMM sees it)
 template <int BM, int BN, int WM, int WN, int S, int ACT>
@@ -161,16 +165,41 @@ __global__ void __launch_bounds__(256, 1) linear_bf16_kernel(LinearArgs a) {
             }
     };
 
+    // the MFMAs of the unit's second k-step with the DMA pieces of the refill between them (one piece every kEvery MFMAs):
+    // issued in one burst, a wave's PPW DMA instructions hold its in-order issue while the memory pipe takes them, and
+    // with one wave per SIMD nothing else runs - DMA time and MFMA time then ADD (measured: 8 + 18 = 26 us on the qkv shape)
+    constexpr int kEvery = (TM * TN) / PPW >= 1 ? (TM * TN) / PPW : 1;
+    static_assert((TM * TN) / kEvery >= PPW, "every piece finds its place between the MFMAs");
+    auto mma_issue = [&](const bf16x8 (&wf)[TN], const bf16x8 (&xf)[TM], int unit, int slot) {
+        const unsigned char* wk = a.w + (int64_t)unit * 128;
+        const unsigned char* xk = a.x + (int64_t)unit * 128;
+        const unsigned dst = dma_dst0 + slot * kUnitBytes;
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                if ((i * TM + j) * 4 < 256) lin_mfma<true>(acc[i][j], wf[i], xf[j]);
+                else lin_mfma<false>(acc[i][j], wf[i], xf[j]);
+                const int c = j * TN + i;
+                if (c % kEvery == kEvery - 1 && c / kEvery < PPW && !(TS_LIN_DBG & 2)) {
+                    const int pi = c / kEvery;
+                    const int p = wave + 4 * pi;
+                    const bool is_w = (p < kPiecesW) || (p >= kPieces && wave < kPiecesW);
+                    lin_dma16(voff[pi], is_w ? wk : xk, dst + pi * 4096);
+                }
+            }
+    };
+
     const int nu = a.K / 64;
     int issued = 0;
-    for (; issued < S && issued < nu; ++issued)                           // every slot of the ring is filled
-        if (!(TS_LIN_DBG & 2)) issue(issued, issued);
+    for (; issued < S; ++issued)                                          // every slot of the ring is filled (units past
+        if (!(TS_LIN_DBG & 2)) issue(min(issued, nu - 1), issued);        // the end: the last one again, never read)
     int slot = 0;
     for (int u = 0; u < nu; ++u) {
-        // unit u has landed (this wave's pieces; barrier A makes it everyone's); units u + 1 .. u + S - 1 may be in flight
-        if (TS_LIN_DBG & 2) {
-        } else if (u + S <= nu) wait_vmcnt<(S - 1) * PPW>();
-        else wait_vmcnt<0>();
+        // unit u has landed (this wave's pieces; barrier A makes it everyone's); S - 1 later refills may be in flight - every
+        // unit issues exactly PPW pieces (past the end of K the last unit again, into a slot nobody reads any more), so the
+        // count is the same in every iteration
+        if (!(TS_LIN_DBG & 2)) wait_vmcnt<(S - 1) * PPW>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (!(TS_LIN_DBG & 8) || u == 0) load(wf0, xf0, slot, 0);
@@ -179,33 +208,41 @@ __global__ void __launch_bounds__(256, 1) linear_bf16_kernel(LinearArgs a) {
         if (!(TS_LIN_DBG & 8) || u == 0) load(wf1, xf1, slot, 1);
         if (!(TS_LIN_DBG & 4)) mma(wf0, xf0, TM / 2, TM);
         // every fragment of the unit is in registers a quarter of the way through it: behind barrier B the slot takes unit
-        // u + S, which then has S - 1/4 units of MFMA time to land (with the refill at the NEXT unit's start a 256 x 288 tile,
-        // whose ring holds two units, ran at a third of the MFMA rate: one burst of 68 KB per CU, then everybody waits)
+        // u + S, which then has S - 1/4 units of MFMA time to land
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (issued < nu) {
-            if (!(TS_LIN_DBG & 2)) issue(issued, slot);
-            ++issued;
-        }
-        if (!(TS_LIN_DBG & 4)) mma(wf1, xf1, 0, TM);
+        if (!(TS_LIN_DBG & 4)) mma_issue(wf1, xf1, min(issued, nu - 1), slot);
+        // wait states between the last MFMA and whatever hipcc places behind the loop: it knows nothing of what the MFMA
+        // statements are, and read three accumulator registers of the 256 x 288 tile right behind the last of them (spilled
+        // straight from the accumulation: 0.2 % of that tile's outputs wrong).  Inside the loop body nothing can be put
+        // between the MFMAs and these; 20 cycles per unit of 1,500-2,300.
+        lin_settle();
+        ++issued;
         slot = (slot + 1 == S) ? 0 : slot + 1;
     }
     wait_vmcnt<0>();
-    lin_settle();
+    __builtin_amdgcn_s_barrier();                          // every wave's DMA has landed and every fragment read is done: the
+    asm volatile("" ::: "memory");                         // ring's LDS becomes the staging tile of the epilogue
 
-    // epilogue: lane holds y[m][n .. n + 3] of every accumulator tile
+    // epilogue: lane holds y[m][n .. n + 3] of every accumulator tile; bias (+ GELU), round, 8 bytes into the staging tile
+    // [BM][BN] (row pitch + 16 bytes); then the workgroup writes the tile out in whole rows, 16 bytes per lane (a first cut
+    // stored the 8 bytes straight from the accumulator layout - 16 rows x 32 bytes per instruction: 19-22 us for the 38-50 MB
+    // outputs, ~2 TB/s)
+    constexpr int kPitch = linear_stage_pitch(BN);
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
-        const int n = n0 + (wn * TN + i) * 16 + 4 * q;
+        const int nl = (wn * TN + i) * 16 + 4 * q;
         float b[4] = {0.f, 0.f, 0.f, 0.f};
         if (a.bias) {
-            const uint2 bb = *(const uint2*)(a.bias + n);
+            const uint2 bb = *(const uint2*)(a.bias + n0 + nl);
             b[0] = bf16_lo(bb.x); b[1] = bf16_hi(bb.x); b[2] = bf16_lo(bb.y); b[3] = bf16_hi(bb.y);
         }
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
-            const int m = m0 + (wm * TM + j) * 16 + r16;
+            const int ml = (wm * TM + j) * 16 + r16;
             unsigned short o[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -213,9 +250,17 @@ __global__ void __launch_bounds__(256, 1) linear_bf16_kernel(LinearArgs a) {
                 if (ACT == 1) h = f32_to_bf16(gelu_erf(bf16_to_f32(h)));
                 o[r] = h;
             }
-            if (m < a.M && !(TS_LIN_DBG & 1))
-                *(uint2*)(a.y + (int64_t)m * a.N + n) = make_uint2((u32)o[0] | ((u32)o[1] << 16), (u32)o[2] | ((u32)o[3] << 16));
+            *(__attribute__((address_space(3))) u32x2*)(lbase + ml * kPitch + nl * 2) =
+                u32x2{(u32)o[0] | ((u32)o[1] << 16), (u32)o[2] | ((u32)o[3] << 16)};
         }
+    }
+    __syncthreads();
+    constexpr int kCPR = BN / 8;                           // 16-byte chunks per row
+    for (int idx = threadIdx.x; idx < BM * kCPR; idx += 256) {
+        const int row = idx / kCPR, c = idx - row * kCPR;
+        const u32x4 v = *(__attribute__((address_space(3))) const u32x4*)(lbase + row * kPitch + c * 16);
+        if (m0 + row < a.M && !(TS_LIN_DBG & 1))
+            *(u32x4*)((unsigned char*)a.y + ((int64_t)(m0 + row) * a.N + n0) * 2 + c * 16) = v;
     }
 }
 
