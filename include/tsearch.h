@@ -307,6 +307,16 @@ int ts_pool_normalize(int device, const void *hidden, int h_dtype, const int64_t
 int ts_add_layernorm(int device, const void *a, const void *b, const void *gamma, const void *beta, float eps, int64_t rows,
                      int32_t d, int dtype, void *out, void *stream);
 
+/* The encoder's input layer, one kernel: out[i] = LayerNorm(word[ids[i]] + type[type_ids[i]] + pos[i % seq]) * gamma + beta
+ * (BertEmbeddings of the sentence-transformer the reference loads, compare_embeddings.py:11-12: three gathers, two adds and a
+ * layer_norm launch per forward in PyTorch).  ids, type_ids: device int64 [tokens] (type_ids may be NULL: row 0); word / pos /
+ * type: device tables [n_word | n_pos | n_type][d]; gamma, beta: device [d]; out: device [tokens][d]; all of `dtype`
+ * (TS_F32 | TS_BF16), 16-byte aligned; sums, mean and variance in fp32.  d as for ts_add_layernorm.  Ids outside a table are
+ * clamped to it. */
+int ts_embed_layernorm(int device, const int64_t *ids, const int64_t *type_ids, const void *word, const void *pos, const void *type,
+                       int64_t n_word, int64_t n_pos, int64_t n_type, const void *gamma, const void *beta, float eps,
+                       int64_t tokens, int32_t seq, int32_t d, int dtype, void *out, void *stream);
+
 /* ---- kernel timing inside the library ----------------------------------------------------------
  * With profiling enabled, every launch of the dominant kernel of a search (the full-corpus pass of
  * the MFMA path, or the scan kernel) is bracketed by a hipEvent pair on the stream it runs on.

@@ -454,6 +454,48 @@ def test_add_layernorm_kernel_matches_torch_in_fp64():
                                         C.c_void_p(beta.data_ptr()), 1e-12, 4, 10, 1, C.c_void_p(out.data_ptr()), None))
 
 
+def test_embed_layernorm_kernel_matches_the_modules_own(encoder):
+    """ts_embed_layernorm = BertEmbeddings (word + token type + position, LayerNorm) against the same expression in fp64 on the
+    same tables: fp32 and bf16, token types given and absent, a ragged token count, ids at both ends of the tables."""
+    import ctypes as C
+    import torch
+    from theoremsearch_amd import _ffi
+    lib = _ffi.load()
+    g = torch.Generator(device="cpu").manual_seed(9)
+    for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
+        for d in (384, 768, 1024):
+            V, P, T, B, S = 1000, 64, 2, 7, 19
+            word = torch.randn((V, d), generator=g).to(dtype).cuda()
+            pos = torch.randn((P, d), generator=g).to(dtype).cuda()
+            typ = torch.randn((T, d), generator=g).to(dtype).cuda()
+            gamma = (1.0 + 0.1 * torch.randn(d, generator=g)).to(dtype).cuda()
+            beta = (0.1 * torch.randn(d, generator=g)).to(dtype).cuda()
+            ids = torch.randint(0, V, (B, S), generator=g)
+            ids[0, 0], ids[0, 1] = 0, V - 1
+            ids = ids.cuda()
+            for tt in (None, torch.randint(0, T, (B, S), generator=g).cuda()):
+                x = word.double()[ids] + (typ.double()[tt] if tt is not None else typ.double()[0]) + pos.double()[torch.arange(S)][None]
+                want = torch.nn.functional.layer_norm(x, (d,), gamma.double(), beta.double(), 1e-12)
+                out = torch.empty((B, S, d), dtype=dtype, device="cuda")
+                _ffi.check(lib.ts_embed_layernorm(0, C.c_void_p(ids.data_ptr()), C.c_void_p(tt.data_ptr()) if tt is not None else None,
+                                                  C.c_void_p(word.data_ptr()), C.c_void_p(pos.data_ptr()), C.c_void_p(typ.data_ptr()),
+                                                  V, P, T, C.c_void_p(gamma.data_ptr()), C.c_void_p(beta.data_ptr()), 1e-12, B * S, S, d,
+                                                  1 if dtype == torch.bfloat16 else 0, C.c_void_p(out.data_ptr()),
+                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                torch.cuda.synchronize()
+                assert torch.allclose(out.double(), want, atol=tol, rtol=tol), (dtype, d, (out.double() - want).abs().max().item())
+    with pytest.raises(_ffi.TSearchError):
+        _ffi.check(lib.ts_embed_layernorm(0, C.c_void_p(ids.data_ptr()), None, C.c_void_p(word.data_ptr()), C.c_void_p(pos.data_ptr()),
+                                          C.c_void_p(typ.data_ptr()), V, P, T, C.c_void_p(gamma.data_ptr()), C.c_void_p(beta.data_ptr()),
+                                          1e-12, 4, 2, 10, 1, C.c_void_p(out.data_ptr()), None))
+    # the module of the encoder itself: the fused forward's input layer against BertEmbeddings
+    enc = {k: v.cuda() for k, v in encoder._tokenize(["Let $G$ be a finite group.", "Every bounded sequence has a convergent subsequence."]).items()}
+    with torch.inference_mode():
+        want = encoder.model.embeddings(input_ids=enc["input_ids"], token_type_ids=enc.get("token_type_ids")).float()
+        got = encoder._fused._embed(enc["input_ids"], enc.get("token_type_ids")).float()
+    assert torch.allclose(got, want, atol=4e-2, rtol=4e-2), (got - want).abs().max().item()
+
+
 def test_fused_bert_forward_matches_the_models_own(encoder):
     """FusedBertForward (QKV as one GEMM, add + LayerNorm as one kernel) against the model's own forward on the same bf16
     weights: hidden states of the real tokens within bf16 noise, sentence embeddings within 2e-2 and cosine > 0.9995;

@@ -1985,14 +1985,19 @@ extern "C" int ts_pool_normalize(int device, const void* hidden, int h_dtype, co
     HIP_TRY(hipSetDevice(device));
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)n);
-    if (h_dtype == TS_F32 && out_dtype == TS_F32)
-        pool_normalize_kernel<0, 0><<<grid, 256, 0, st>>>(hidden, attention_mask, seq, d, pooling, normalize, out, out_ld);
-    else if (h_dtype == TS_F32)
-        pool_normalize_kernel<0, 1><<<grid, 256, 0, st>>>(hidden, attention_mask, seq, d, pooling, normalize, out, out_ld);
-    else if (out_dtype == TS_F32)
-        pool_normalize_kernel<1, 0><<<grid, 256, 0, st>>>(hidden, attention_mask, seq, d, pooling, normalize, out, out_ld);
-    else
-        pool_normalize_kernel<1, 1><<<grid, 256, 0, st>>>(hidden, attention_mask, seq, d, pooling, normalize, out, out_ld);
+    // the encoders' shapes take the vector form (16-byte loads, tokens dealt over thread groups); anything else the general one
+    const int vec = h_dtype == TS_BF16 ? 8 : 4;
+    const bool vform = d % vec == 0 && d / vec <= 256 && seq <= kPoolVecSeq && ((uintptr_t)hidden & 15) == 0;
+#define TS_POOL_LAUNCH(H, O)                                                                                                  \
+    do {                                                                                                                      \
+        if (vform) pool_normalize_vec_kernel<H, O><<<grid, 256, 0, st>>>(hidden, attention_mask, seq, d, pooling, normalize, out, out_ld); \
+        else pool_normalize_kernel<H, O><<<grid, 256, 0, st>>>(hidden, attention_mask, seq, d, pooling, normalize, out, out_ld); \
+    } while (0)
+    if (h_dtype == TS_F32 && out_dtype == TS_F32) TS_POOL_LAUNCH(0, 0);
+    else if (h_dtype == TS_F32) TS_POOL_LAUNCH(0, 1);
+    else if (out_dtype == TS_F32) TS_POOL_LAUNCH(1, 0);
+    else TS_POOL_LAUNCH(1, 1);
+#undef TS_POOL_LAUNCH
     HIP_TRY(hipGetLastError());
     return TS_OK;
 }
@@ -2010,8 +2015,51 @@ extern "C" int ts_add_layernorm(int device, const void* a, const void* b, const 
     TS_TRY(check_device(device));
     HIP_TRY(hipSetDevice(device));
     const unsigned grid = (unsigned)((rows + 3) / 4);
-    if (dtype == TS_F32) add_layernorm_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(a, b, gamma, beta, eps, rows, d, out);
-    else add_layernorm_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(a, b, gamma, beta, eps, rows, d, out);
+    const int per_lane = (d / vec + 63) / 64;              // 16-byte accesses per lane
+    hipStream_t st = (hipStream_t)stream;
+#define TS_LN_LAUNCH(DT_)                                                                                        \
+    do {                                                                                                         \
+        if (per_lane <= 1) add_layernorm_kernel<DT_, 1><<<grid, 256, 0, st>>>(a, b, gamma, beta, eps, rows, d, out); \
+        else if (per_lane <= 2) add_layernorm_kernel<DT_, 2><<<grid, 256, 0, st>>>(a, b, gamma, beta, eps, rows, d, out); \
+        else add_layernorm_kernel<DT_, 4><<<grid, 256, 0, st>>>(a, b, gamma, beta, eps, rows, d, out);           \
+    } while (0)
+    if (dtype == TS_F32) TS_LN_LAUNCH(0);
+    else TS_LN_LAUNCH(1);
+#undef TS_LN_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return TS_OK;
+}
+
+extern "C" int ts_embed_layernorm(int device, const int64_t* ids, const int64_t* type_ids, const void* word, const void* pos,
+                                  const void* type, int64_t n_word, int64_t n_pos, int64_t n_type, const void* gamma, const void* beta,
+                                  float eps, int64_t tokens, int32_t seq, int32_t d, int dtype, void* out, void* stream) {
+    if (!ids || !word || !pos || !type || !gamma || !beta || !out) return fail(TS_ERR_INVALID, "NULL argument");
+    if (dtype != TS_F32 && dtype != TS_BF16) return fail(TS_ERR_INVALID, "dtype %d", dtype);
+    const int vec = dtype == TS_BF16 ? 8 : 4;
+    if (tokens < 0 || seq < 1 || d < vec || d % vec || d > 64 * kLnMax * vec)
+        return fail(TS_ERR_INVALID, "d = %d must be a multiple of %d and at most %d; seq >= 1", d, vec, 64 * kLnMax * vec);
+    if (n_word < 1 || n_pos < 1 || n_type < 1) return fail(TS_ERR_INVALID, "empty embedding table");
+    if ((((uintptr_t)word | (uintptr_t)pos | (uintptr_t)type | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out) & 15) != 0)
+        return fail(TS_ERR_INVALID, "tables and output must be 16-byte aligned");
+    if (tokens == 0) return TS_OK;
+    TS_TRY(check_device(device));
+    HIP_TRY(hipSetDevice(device));
+    const unsigned grid = (unsigned)((tokens + 3) / 4);
+    const int per_lane = (d / vec + 63) / 64;
+    hipStream_t st = (hipStream_t)stream;
+#define TS_EMB_LAUNCH(DT_, LN_)                                                                                              \
+    embed_layernorm_kernel<DT_, LN_><<<grid, 256, 0, st>>>(ids, type_ids, word, pos, type, n_word, n_pos, n_type, gamma, beta, eps, \
+                                                          tokens, seq, d, out)
+    if (dtype == TS_F32) {
+        if (per_lane <= 1) TS_EMB_LAUNCH(0, 1);
+        else if (per_lane <= 2) TS_EMB_LAUNCH(0, 2);
+        else TS_EMB_LAUNCH(0, 4);
+    } else {
+        if (per_lane <= 1) TS_EMB_LAUNCH(1, 1);
+        else if (per_lane <= 2) TS_EMB_LAUNCH(1, 2);
+        else TS_EMB_LAUNCH(1, 4);
+    }
+#undef TS_EMB_LAUNCH
     HIP_TRY(hipGetLastError());
     return TS_OK;
 }

@@ -454,7 +454,8 @@ class FusedBertForward:
     * query / key / value projections as ONE GEMM over the concatenated weight (three 8,192 x 768 x 768 GEMMs fill the
       chip a third each: 24 us apiece against 41 us for the fused one, measured per layer at 256 x 32 tokens);
     * ``LayerNorm(dense_out + input)`` as ONE HIP kernel (``ts_add_layernorm``) instead of an add and a layer_norm launch
-      (18 + 7 us of device time twice per layer).
+      (18 + 7 us of device time twice per layer);
+    * the input layer (three embedding gathers, two adds, LayerNorm) as ONE HIP kernel (``ts_embed_layernorm``).
 
     Same weights, same order of operations, exact erf GELU (whatever ``config.hidden_act`` names); the attention is
     ``scaled_dot_product_attention`` with the padding mask, as the model's own ``sdpa`` path.  Used on a GPU for bf16 / fp32
@@ -488,6 +489,31 @@ class FusedBertForward:
         p = next(model.parameters())
         return p.is_cuda and p.dtype in (torch.float32, torch.bfloat16) and cfg.hidden_size % 8 == 0 and cfg.hidden_size <= 1024
 
+    def _embed(self, input_ids: torch.Tensor, token_type_ids: Optional[torch.Tensor]) -> torch.Tensor:
+        """BertEmbeddings (word + token type + position, LayerNorm; dropout is the identity in eval) as ONE HIP kernel
+        (``ts_embed_layernorm``) instead of three gathers, two adds and a layer_norm launch.  Anything the kernel's form does not
+        cover (a sequence longer than the position table, a module without the three tables) runs the module itself."""
+        import ctypes as C
+        from . import _ffi
+        emb = self.model.embeddings
+        tables = [getattr(emb, n, None) for n in ("word_embeddings", "position_embeddings", "token_type_embeddings")]
+        ln = getattr(emb, "LayerNorm", None)
+        B, S = input_ids.shape
+        if any(t is None for t in tables) or ln is None or S > tables[1].weight.shape[0] or input_ids.dtype != torch.int64:
+            return emb(input_ids=input_ids, token_type_ids=token_type_ids)
+        w, p, t = (m.weight for m in tables)
+        ids = input_ids.contiguous()
+        tt = token_type_ids.contiguous().to(torch.int64) if token_type_ids is not None else None
+        H = w.shape[1]
+        out = torch.empty((B, S, H), dtype=w.dtype, device=w.device)
+        _ffi.check(_ffi.load().ts_embed_layernorm(
+            w.device.index or 0, C.c_void_p(ids.data_ptr()), C.c_void_p(tt.data_ptr()) if tt is not None else None,
+            C.c_void_p(w.data_ptr()), C.c_void_p(p.data_ptr()), C.c_void_p(t.data_ptr()), w.shape[0], p.shape[0], t.shape[0],
+            C.c_void_p(ln.weight.data_ptr()), C.c_void_p(ln.bias.data_ptr()), self.eps, B * S, S, H,
+            1 if w.dtype == torch.bfloat16 else 0, C.c_void_p(out.data_ptr()),
+            C.c_void_p(torch.cuda.current_stream(w.device).cuda_stream)))
+        return out
+
     def _add_ln(self, a: torch.Tensor, b: torch.Tensor, ln) -> torch.Tensor:
         import ctypes as C
         from . import _ffi
@@ -503,7 +529,7 @@ class FusedBertForward:
     def __call__(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, token_type_ids: Optional[torch.Tensor] = None,
                  no_padding: bool = False):
         F = torch.nn.functional
-        x = self.model.embeddings(input_ids=input_ids, token_type_ids=token_type_ids)
+        x = self._embed(input_ids, token_type_ids)
         B, S, H = x.shape
         hd = H // self.heads
         # padding keys are never attended to: ONE additive mask per forward (a boolean mask is expanded to a bias inside every
