@@ -317,6 +317,16 @@ int ts_embed_layernorm(int device, const int64_t *ids, const int64_t *type_ids, 
                        int64_t n_word, int64_t n_pos, int64_t n_type, const void *gamma, const void *beta, float eps,
                        int64_t tokens, int32_t seq, int32_t d, int dtype, void *out, void *stream);
 
+/* Self-attention of the encoder for short sequences, one kernel: out = softmax(Q K^T / sqrt(64) + key mask) V per (sequence,
+ * head), bf16, straight from the fused query / key / value projection (BertSelfAttention of the sentence-transformer the
+ * reference loads, compare_embeddings.py:11-12; a query is one sentence: app_showcase_model.py:92).  qkv: device bf16
+ * [batch][seq][3][heads][64] (the output of one GEMM over the concatenated projection weights); attention_mask: device int64
+ * [batch][seq], 0 = padding key, or NULL; out: device bf16 [batch][seq][heads * 64].  head_dim must be 64 and seq at most 64
+ * (TS_ERR_UNSUPPORTED otherwise: the caller keeps its library attention).  Scores and softmax in fp32, probabilities rounded to
+ * bf16 for the second product (as flash attention does). */
+int ts_attention_bf16(int device, const void *qkv, const int64_t *attention_mask, int32_t batch, int32_t seq, int32_t heads,
+                      int32_t head_dim, void *out, void *stream);
+
 /* ---- kernel timing inside the library ----------------------------------------------------------
  * With profiling enabled, every launch of the dominant kernel of a search (the full-corpus pass of
  * the MFMA path, or the scan kernel) is bracketed by a hipEvent pair on the stream it runs on.

@@ -496,6 +496,43 @@ def test_embed_layernorm_kernel_matches_the_modules_own(encoder):
     assert torch.allclose(got, want, atol=4e-2, rtol=4e-2), (got - want).abs().max().item()
 
 
+def test_short_sequence_attention_kernel_matches_fp64():
+    """ts_attention_bf16 = softmax(Q K^T / 8 + key mask) V per (sequence, head) from the fused projection's layout, against the
+    same expression in fp64 on the same bf16 inputs: every tile count (1 .. 64 tokens, ragged lengths), with and without a key
+    mask (every sequence keeps at least its first token), a head count that does not fill the last workgroup; and against
+    torch's scaled_dot_product_attention; longer sequences and other head sizes are refused."""
+    import ctypes as C
+    import torch
+    from theoremsearch_amd import _ffi
+    lib = _ffi.load()
+    g = torch.Generator(device="cpu").manual_seed(11)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for B, S, H in ((3, 1, 2), (5, 7, 3), (4, 16, 12), (9, 19, 5), (6, 32, 12), (3, 33, 2), (2, 48, 3), (5, 61, 7), (2, 64, 12)):
+        qkv = (torch.randn((B, S, 3, H, 64), generator=g) * 1.5).to(torch.bfloat16).cuda()
+        lens = torch.randint(1, S + 1, (B,), generator=g)
+        km = (torch.arange(S)[None, :] < lens[:, None]).to(torch.int64).cuda()
+        for mask in (None, km):
+            q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3).double() for i in range(3))            # [B][H][S][64]
+            sc = q @ k.transpose(-1, -2) / 8.0
+            if mask is not None:
+                sc = sc.masked_fill(mask[:, None, None, :] == 0, float("-inf"))
+            want = (torch.softmax(sc, dim=-1) @ v).permute(0, 2, 1, 3).reshape(B, S, H * 64)
+            out = torch.empty((B, S, H * 64), dtype=torch.bfloat16, device="cuda")
+            _ffi.check(lib.ts_attention_bf16(0, C.c_void_p(qkv.data_ptr()), C.c_void_p(mask.data_ptr()) if mask is not None else None,
+                                             B, S, H, 64, C.c_void_p(out.data_ptr()), st))
+            torch.cuda.synchronize()
+            err = (out.double() - want).abs().max().item()
+            assert err <= 3e-2, (B, S, H, mask is not None, err)                               # bf16 probabilities and output
+            bias = None if mask is None else torch.zeros((B, 1, 1, S), dtype=torch.bfloat16, device="cuda").masked_fill_(
+                mask[:, None, None, :] == 0, float("-inf"))
+            ref = torch.nn.functional.scaled_dot_product_attention(*(qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3)), attn_mask=bias)
+            ref = ref.transpose(1, 2).reshape(B, S, H * 64)
+            assert (out.float() - ref.float()).abs().max().item() <= 4e-2
+    for S, hd in ((65, 64), (16, 32)):
+        with pytest.raises(_ffi.TSearchError):
+            _ffi.check(lib.ts_attention_bf16(0, C.c_void_p(qkv.data_ptr()), None, 1, S, 1, hd, C.c_void_p(out.data_ptr()), st))
+
+
 def test_fused_bert_forward_matches_the_models_own(encoder):
     """FusedBertForward (QKV as one GEMM, add + LayerNorm as one kernel) against the model's own forward on the same bf16
     weights: hidden states of the real tokens within bf16 noise, sentence embeddings within 2e-2 and cosine > 0.9995;

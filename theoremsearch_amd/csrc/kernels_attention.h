@@ -1,0 +1,186 @@
+// Self-attention of the encoder for short sequences (BertSelfAttention of the sentence-transformer the reference loads,
+// compare_embeddings.py:11-12; queries are one sentence each, `model.encode` at app_showcase_model.py:92): softmax(Q K^T / 8 +
+// key mask) V for head size 64 and at most 64 tokens, bf16 in / out, one WAVE per (sequence, head), straight from the fused
+// projection's output [B][S][3][H][64] into the context layout [B][S][H * 64] the output projection reads.
+//
+// Why a kernel of our own: at 256 sequences x 32 tokens the library's flash-attention launch takes 18.7 us per layer for 50 MB
+// of traffic and 0.8 GFLOP - it is built for long sequences (tiles of 64-128 queries per workgroup); here the whole problem of
+// a (sequence, head) is 12 KB and sixteen MFMAs, and the launch is bound by how many of them are in flight.
+//
+//   * scores: v_mfma_f32_16x16x32_bf16 with Q rows as the A operand and K rows as the B operand, both read from global memory as
+//     the fragments they are (16 bytes per lane along the head dimension): D[q][key], lane l holds q = 4 (l >> 4) + r, key = l & 15
+//     of each 16 x 16 tile;
+//   * softmax over the keys in fp32: the 16 lanes of a quarter-wave hold one row's keys of a tile (xor-shuffles 1, 2, 4, 8), the
+//     tiles are registers; padded keys (attention_mask = 0) and keys past the sequence are -inf;
+//   * P goes to LDS as bf16 [q][key] (wave-private) and comes back as the B operand of O^T = V^T P^T, whose A operand (V^T:
+//     lane l holds V[8 (l >> 4) + j][l & 15]) comes from a transposed LDS image of V (16-byte loads of the rows, 4-byte writes
+//     of key pairs);
+//   * O^T leaves the accumulators as [d = 4 (l >> 4) + r][q = l & 15]: four consecutive d per lane, staged through the same LDS and
+//     written as whole 128-byte rows.
+#pragma once
+#include "kernels_mfma16.h"
+
+namespace ts {
+
+constexpr int kAttnMaxSeq = 64;
+constexpr int attn_wave_lds(int T) {
+    const int sp = 16 * T, ks = (sp + 31) / 32;
+    const int p_bytes = sp * (32 * ks + 8) * 2, o_bytes = sp * (64 + 8) * 2;
+    return (p_bytes > o_bytes ? p_bytes : o_bytes) + 64 * (32 * ks + 8) * 2;      // + V^T [64][keys]
+}
+constexpr int attn_vt_offset(int T) {
+    const int sp = 16 * T, ks = (sp + 31) / 32;
+    const int p_bytes = sp * (32 * ks + 8) * 2, o_bytes = sp * (64 + 8) * 2;
+    return p_bytes > o_bytes ? p_bytes : o_bytes;
+}
+
+// T = ceil(S / 16).  grid = ceil(B * H / 4), 256 threads; no workgroup barrier (every wave works in its own LDS slice).
+template <int T>
+__global__ void __launch_bounds__(256) attention_short_kernel(const unsigned short* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                               int B, int S, int H, unsigned short* __restrict__ out) {
+    constexpr int SP = 16 * T;                       // padded sequence
+    constexpr int KS = (SP + 31) / 32;               // 32-key steps of the second product
+    constexpr int PP = 32 * KS + 8;                  // pitch of P rows (elements): 16 bytes of padding spread the banks
+    constexpr int OP = 64 + 8;                       // pitch of O rows
+    __shared__ __attribute__((aligned(16))) unsigned char sbuf[4][attn_wave_lds(T)];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bh = blockIdx.x * 4 + wave;
+    if (bh >= B * H) return;
+    const int b = bh / H, h = bh - b * H;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int64_t tok = (int64_t)3 * H * 64;         // elements per token of the projection's output
+    const unsigned short* base = qkv + (int64_t)b * S * tok + h * 64;
+    unsigned short* sP = (unsigned short*)sbuf[wave];
+
+    // every load of the problem is requested before the first use
+    bf16x8 qf[T][2], kf[T][2];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int row = min(16 * t + r16, S - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qf[t][ks] = *(const bf16x8*)(base + row * tok + 32 * ks + 8 * g);
+            kf[t][ks] = *(const bf16x8*)(base + row * tok + H * 64 + 32 * ks + 8 * g);
+        }
+    }
+    // V rows as they lie (16 bytes per lane: lane -> key pair lane / 8 + 8 i, columns 8 (lane & 7) ..); transposed through LDS below
+    constexpr int KP = SP / 2;                       // key pairs
+    constexpr int VI = (KP + 7) / 8;                 // pairs per lane
+    uint4 v0[VI], v1[VI];
+#pragma unroll
+    for (int i = 0; i < VI; ++i) {
+        const int kp = (lane >> 3) + 8 * i;
+        const int k0 = min(2 * kp, S - 1), k1 = min(2 * kp + 1, S - 1);
+        v0[i] = *(const uint4*)(base + k0 * tok + 2 * H * 64 + 8 * (lane & 7));
+        v1[i] = *(const uint4*)(base + k1 * tok + 2 * H * 64 + 8 * (lane & 7));
+    }
+    bool keyok[T];
+#pragma unroll
+    for (int kj = 0; kj < T; ++kj) {
+        const int key = 16 * kj + r16;
+        keyok[kj] = key < S && (!mask || mask[(int64_t)b * S + key] != 0);
+    }
+    // P's LDS image starts as zeros: keys past the padded sequence inside the last 32-key step contribute nothing
+    for (int i = lane; i < SP * PP / 8; i += 64) ((uint4*)sP)[i] = make_uint4(0u, 0u, 0u, 0u);
+    // V^T [d][key] in LDS: a lane holds 8 columns of two consecutive keys and writes 8 dwords (column d, keys 2 kp and 2 kp + 1);
+    // the second product reads its A fragments (column d = 16 dj + r16, 8 consecutive keys) as 16 bytes.  A first cut gathered
+    // those fragments from global memory with 2-byte loads: 32 instructions of 128 bytes each per wave.
+    unsigned short* sVT = (unsigned short*)(sbuf[wave] + attn_vt_offset(T));
+    if (KS * 32 > SP)                                // keys past the padded sequence: zeros (0 x P = 0, never NaN)
+        for (int i = lane; i < 64 * PP / 8; i += 64) ((uint4*)sVT)[i] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int i = 0; i < VI; ++i) {
+        const int kp = (lane >> 3) + 8 * i;
+        if (kp < KP) {
+            const u32 a[4] = {v0[i].x, v0[i].y, v0[i].z, v0[i].w}, c[4] = {v1[i].x, v1[i].y, v1[i].z, v1[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                u32* dst = (u32*)(sVT + (8 * (lane & 7) + 2 * e) * PP + 2 * kp);
+                dst[0] = (a[e] & 0xFFFFu) | (c[e] << 16);                     // column 2 e: (key 2 kp, key 2 kp + 1)
+                *(u32*)((unsigned short*)dst + PP) = (a[e] >> 16) | (c[e] & 0xFFFF0000u);   // column 2 e + 1
+            }
+        }
+    }
+
+    // scores D[q][key]
+    f32x4 sc[T][T];
+#pragma unroll
+    for (int qi = 0; qi < T; ++qi)
+#pragma unroll
+        for (int kj = 0; kj < T; ++kj) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[qi][ks], kf[kj][ks], a, 0, 0, 0);
+            sc[qi][kj] = a;
+        }
+    // softmax over the keys of row q = 16 qi + 4 g + r: tiles kj are registers, the 16 keys of a tile are the lanes of this quarter
+    constexpr float kScaleLog2e = 0.125f * 1.4426950408889634f;     // 1 / sqrt(64), exp through exp2
+#pragma unroll
+    for (int qi = 0; qi < T; ++qi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int kj = 0; kj < T; ++kj) m = fmaxf(m, keyok[kj] ? sc[qi][kj][r] : -INFINITY);
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            float e[T], sum = 0.0f;
+#pragma unroll
+            for (int kj = 0; kj < T; ++kj) {
+                e[kj] = keyok[kj] ? exp2f((sc[qi][kj][r] - m) * kScaleLog2e) : 0.0f;
+                sum += e[kj];
+            }
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) sum += __shfl_xor(sum, off, 64);
+            const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;        // a row without a single allowed key: zeros
+#pragma unroll
+            for (int kj = 0; kj < T; ++kj) sP[(16 * qi + 4 * g + r) * PP + 16 * kj + r16] = f32_to_bf16(e[kj] * inv);
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // O^T = V^T P^T: A = V^T fragment (d = 16 dj + r16, keys 32 ks + 8 g ..), B = P^T fragment (keys .., q = 16 qi + r16)
+    bf16x8 pf[T][KS];
+#pragma unroll
+    for (int qi = 0; qi < T; ++qi)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) pf[qi][ks] = *(const bf16x8*)(sP + (16 * qi + r16) * PP + 32 * ks + 8 * g);
+    bf16x8 vf[4][KS];
+#pragma unroll
+    for (int dj = 0; dj < 4; ++dj)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) vf[dj][ks] = *(const bf16x8*)(sVT + (16 * dj + r16) * PP + 32 * ks + 8 * g);
+    f32x4 oc[4][T];
+#pragma unroll
+    for (int dj = 0; dj < 4; ++dj)
+#pragma unroll
+        for (int qi = 0; qi < T; ++qi) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dj][ks], pf[qi][ks], a, 0, 0, 0);
+            oc[dj][qi] = a;
+        }
+    // the P image has been read (the fragments are in registers): the same LDS takes O as [q][d]
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    unsigned short* sO = sP;
+#pragma unroll
+    for (int dj = 0; dj < 4; ++dj)
+#pragma unroll
+        for (int qi = 0; qi < T; ++qi) {
+            const u32 lo = (u32)f32_to_bf16(oc[dj][qi][0]) | ((u32)f32_to_bf16(oc[dj][qi][1]) << 16);
+            const u32 hi = (u32)f32_to_bf16(oc[dj][qi][2]) | ((u32)f32_to_bf16(oc[dj][qi][3]) << 16);
+            *(uint2*)(sO + (16 * qi + r16) * OP + 16 * dj + 4 * g) = make_uint2(lo, hi);
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    unsigned short* obase = out + (int64_t)b * S * H * 64 + h * 64;
+    for (int i = lane; i < SP * 8; i += 64) {
+        const int q = i >> 3, c = i & 7;
+        if (q < S) *(uint4*)(obase + (int64_t)q * H * 64 + 8 * c) = *(const uint4*)(sO + q * OP + 8 * c);
+    }
+}
+
+}  // namespace ts

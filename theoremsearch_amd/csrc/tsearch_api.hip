@@ -21,6 +21,7 @@
 #include "kernels_mfma.h"
 #include "kernels_mfma16.h"
 #include "kernels_mfma_f32.h"
+#include "kernels_attention.h"
 #include "kernels_prep.h"
 #include "kernels_sample.h"
 #include "kernels_scan.h"
@@ -2060,6 +2061,31 @@ extern "C" int ts_embed_layernorm(int device, const int64_t* ids, const int64_t*
         else TS_EMB_LAUNCH(1, 4);
     }
 #undef TS_EMB_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return TS_OK;
+}
+
+extern "C" int ts_attention_bf16(int device, const void* qkv, const int64_t* attention_mask, int32_t batch, int32_t seq, int32_t heads,
+                                 int32_t head_dim, void* out, void* stream) {
+    if (!qkv || !out) return fail(TS_ERR_INVALID, "NULL argument");
+    if (batch < 0 || seq < 1 || heads < 1) return fail(TS_ERR_INVALID, "batch = %d, seq = %d, heads = %d", batch, seq, heads);
+    if (head_dim != 64 || seq > kAttnMaxSeq)
+        return fail(TS_ERR_UNSUPPORTED, "head size %d / %d tokens: this kernel serves head size 64 and at most %d tokens", head_dim, seq,
+                    kAttnMaxSeq);
+    if ((((uintptr_t)qkv | (uintptr_t)out) & 15) != 0) return fail(TS_ERR_INVALID, "qkv and out must be 16-byte aligned");
+    if (batch == 0) return TS_OK;
+    TS_TRY(check_device(device));
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)(((int64_t)batch * heads + 3) / 4);
+    const unsigned short* in = (const unsigned short*)qkv;
+    unsigned short* o = (unsigned short*)out;
+    switch ((seq + 15) / 16) {
+        case 1: attention_short_kernel<1><<<grid, 256, 0, st>>>(in, attention_mask, batch, seq, heads, o); break;
+        case 2: attention_short_kernel<2><<<grid, 256, 0, st>>>(in, attention_mask, batch, seq, heads, o); break;
+        case 3: attention_short_kernel<3><<<grid, 256, 0, st>>>(in, attention_mask, batch, seq, heads, o); break;
+        default: attention_short_kernel<4><<<grid, 256, 0, st>>>(in, attention_mask, batch, seq, heads, o); break;
+    }
     HIP_TRY(hipGetLastError());
     return TS_OK;
 }

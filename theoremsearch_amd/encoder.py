@@ -455,7 +455,9 @@ class FusedBertForward:
       chip a third each: 24 us apiece against 41 us for the fused one, measured per layer at 256 x 32 tokens);
     * ``LayerNorm(dense_out + input)`` as ONE HIP kernel (``ts_add_layernorm``) instead of an add and a layer_norm launch
       (18 + 7 us of device time twice per layer);
-    * the input layer (three embedding gathers, two adds, LayerNorm) as ONE HIP kernel (``ts_embed_layernorm``).
+    * the input layer (three embedding gathers, two adds, LayerNorm) as ONE HIP kernel (``ts_embed_layernorm``);
+    * for bf16 models with 64-wide heads and at most 64 tokens, the attention as ONE wave per (sequence, head)
+      (``ts_attention_bf16``; ``TS_ENCODER_ATTENTION=0`` keeps ``scaled_dot_product_attention``).
 
     Same weights, same order of operations, exact erf GELU (whatever ``config.hidden_act`` names); the attention is
     ``scaled_dot_product_attention`` with the padding mask, as the model's own ``sdpa`` path.  Used on a GPU for bf16 / fp32
@@ -514,6 +516,16 @@ class FusedBertForward:
             C.c_void_p(torch.cuda.current_stream(w.device).cuda_stream)))
         return out
 
+    def _attention(self, qkv: torch.Tensor, key_mask: Optional[torch.Tensor], B: int, S: int) -> torch.Tensor:
+        import ctypes as C
+        from . import _ffi
+        qkv = qkv.contiguous()
+        out = torch.empty((B, S, self.heads * 64), dtype=torch.bfloat16, device=qkv.device)
+        _ffi.check(_ffi.load().ts_attention_bf16(
+            qkv.device.index or 0, C.c_void_p(qkv.data_ptr()), C.c_void_p(key_mask.data_ptr()) if key_mask is not None else None,
+            B, S, self.heads, 64, C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream)))
+        return out
+
     def _add_ln(self, a: torch.Tensor, b: torch.Tensor, ln) -> torch.Tensor:
         import ctypes as C
         from . import _ffi
@@ -535,12 +547,20 @@ class FusedBertForward:
         # padding keys are never attended to: ONE additive mask per forward (a boolean mask is expanded to a bias inside every
         # scaled_dot_product_attention call: two fill launches per layer); none at all when the caller knows the batch has no
         # padding (every sequence as long as the batch: 50 instead of 60 us per layer for projections + attention)
-        mask = None if no_padding else torch.zeros((B, 1, 1, S), dtype=x.dtype, device=x.device).masked_fill_(
+        # short sequences (one sentence per query: app_showcase_model.py:92) of a bf16 model with 64-wide heads: the attention as
+        # ONE wave per (sequence, head), straight from the fused projection to the context layout (``ts_attention_bf16``)
+        short = x.dtype == torch.bfloat16 and hd == 64 and S <= 64 and os.environ.get("TS_ENCODER_ATTENTION", "1") != "0"
+        mask = None if (no_padding or short) else torch.zeros((B, 1, 1, S), dtype=x.dtype, device=x.device).masked_fill_(
             ~attention_mask[:, None, None, :].to(torch.bool), float("-inf"))
+        key_mask = None if (no_padding or not short) else attention_mask.to(torch.int64).contiguous()
         for L in self.layers:
-            qkv = F.linear(x, L["wqkv"], L["bqkv"]).view(B, S, 3, self.heads, hd).permute(2, 0, 3, 1, 4)
-            ctx = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], attn_mask=mask)
-            ctx = ctx.transpose(1, 2).reshape(B, S, H)
+            qkv = F.linear(x, L["wqkv"], L["bqkv"])
+            if short:
+                ctx = self._attention(qkv, key_mask, B, S)
+            else:
+                qkv = qkv.view(B, S, 3, self.heads, hd).permute(2, 0, 3, 1, 4)
+                ctx = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], attn_mask=mask)
+                ctx = ctx.transpose(1, 2).reshape(B, S, H)
             x = self._add_ln(F.linear(ctx, L["wo"], L["bo"]), x, L["ln1"])
             h = self.act(F.linear(x, L["w1"], L["b1"]))
             x = self._add_ln(F.linear(h, L["w2"], L["b2"]), x, L["ln2"])
