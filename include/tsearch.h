@@ -324,7 +324,7 @@ int ts_embed_layernorm(int device, const int64_t *ids, const int64_t *type_ids, 
  * [batch][seq], 0 = padding key, or NULL; out: device bf16 [batch][seq][heads * 64].  head_dim must be 64 and seq at most 64
  * (TS_ERR_UNSUPPORTED otherwise: the caller keeps its library attention).  Scores and softmax in fp32, probabilities rounded to
  * bf16 for the second product (as flash attention does). */
-int ts_attention_bf16(int device, const void *qkv, const int64_t *attention_mask, int32_t batch, int32_t seq, int32_t heads,
+int ts_attention_short(int device, const void *qkv, const int64_t *attention_mask, int32_t batch, int32_t seq, int32_t heads,
                       int32_t head_dim, void *out, void *stream);
 
 /* ---- kernel timing inside the library ----------------------------------------------------------

@@ -497,7 +497,7 @@ def test_embed_layernorm_kernel_matches_the_modules_own(encoder):
 
 
 def test_short_sequence_attention_kernel_matches_fp64():
-    """ts_attention_bf16 = softmax(Q K^T / 8 + key mask) V per (sequence, head) from the fused projection's layout, against the
+    """ts_attention_short = softmax(Q K^T / 8 + key mask) V per (sequence, head) from the fused projection's layout, against the
     same expression in fp64 on the same bf16 inputs: every tile count (1 .. 64 tokens, ragged lengths), with and without a key
     mask (every sequence keeps at least its first token), a head count that does not fill the last workgroup; and against
     torch's scaled_dot_product_attention; longer sequences and other head sizes are refused."""
@@ -518,7 +518,7 @@ def test_short_sequence_attention_kernel_matches_fp64():
                 sc = sc.masked_fill(mask[:, None, None, :] == 0, float("-inf"))
             want = (torch.softmax(sc, dim=-1) @ v).permute(0, 2, 1, 3).reshape(B, S, H * 64)
             out = torch.empty((B, S, H * 64), dtype=torch.bfloat16, device="cuda")
-            _ffi.check(lib.ts_attention_bf16(0, C.c_void_p(qkv.data_ptr()), C.c_void_p(mask.data_ptr()) if mask is not None else None,
+            _ffi.check(lib.ts_attention_short(0, C.c_void_p(qkv.data_ptr()), C.c_void_p(mask.data_ptr()) if mask is not None else None,
                                              B, S, H, 64, C.c_void_p(out.data_ptr()), st))
             torch.cuda.synchronize()
             err = (out.double() - want).abs().max().item()
@@ -530,7 +530,7 @@ def test_short_sequence_attention_kernel_matches_fp64():
             assert (out.float() - ref.float()).abs().max().item() <= 4e-2
     for S, hd in ((65, 64), (16, 32)):
         with pytest.raises(_ffi.TSearchError):
-            _ffi.check(lib.ts_attention_bf16(0, C.c_void_p(qkv.data_ptr()), None, 1, S, 1, hd, C.c_void_p(out.data_ptr()), st))
+            _ffi.check(lib.ts_attention_short(0, C.c_void_p(qkv.data_ptr()), None, 1, S, 1, hd, C.c_void_p(out.data_ptr()), st))
 
 
 def test_fused_bert_forward_matches_the_models_own(encoder):

@@ -2065,7 +2065,7 @@ extern "C" int ts_embed_layernorm(int device, const int64_t* ids, const int64_t*
     return TS_OK;
 }
 
-extern "C" int ts_attention_bf16(int device, const void* qkv, const int64_t* attention_mask, int32_t batch, int32_t seq, int32_t heads,
+extern "C" int ts_attention_short(int device, const void* qkv, const int64_t* attention_mask, int32_t batch, int32_t seq, int32_t heads,
                                  int32_t head_dim, void* out, void* stream) {
     if (!qkv || !out) return fail(TS_ERR_INVALID, "NULL argument");
     if (batch < 0 || seq < 1 || heads < 1) return fail(TS_ERR_INVALID, "batch = %d, seq = %d, heads = %d", batch, seq, heads);

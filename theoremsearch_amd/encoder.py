@@ -457,7 +457,7 @@ class FusedBertForward:
       (18 + 7 us of device time twice per layer);
     * the input layer (three embedding gathers, two adds, LayerNorm) as ONE HIP kernel (``ts_embed_layernorm``);
     * for bf16 models with 64-wide heads and at most 64 tokens, the attention as ONE wave per (sequence, head)
-      (``ts_attention_bf16``; ``TS_ENCODER_ATTENTION=0`` keeps ``scaled_dot_product_attention``).
+      (``ts_attention_short``; ``TS_ENCODER_ATTENTION=0`` keeps ``scaled_dot_product_attention``).
 
     Same weights, same order of operations, exact erf GELU (whatever ``config.hidden_act`` names); the attention is
     ``scaled_dot_product_attention`` with the padding mask, as the model's own ``sdpa`` path.  Used on a GPU for bf16 / fp32
@@ -521,7 +521,7 @@ class FusedBertForward:
         from . import _ffi
         qkv = qkv.contiguous()
         out = torch.empty((B, S, self.heads * 64), dtype=torch.bfloat16, device=qkv.device)
-        _ffi.check(_ffi.load().ts_attention_bf16(
+        _ffi.check(_ffi.load().ts_attention_short(
             qkv.device.index or 0, C.c_void_p(qkv.data_ptr()), C.c_void_p(key_mask.data_ptr()) if key_mask is not None else None,
             B, S, self.heads, 64, C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream)))
         return out
@@ -548,7 +548,7 @@ class FusedBertForward:
         # scaled_dot_product_attention call: two fill launches per layer); none at all when the caller knows the batch has no
         # padding (every sequence as long as the batch: 50 instead of 60 us per layer for projections + attention)
         # short sequences (one sentence per query: app_showcase_model.py:92) of a bf16 model with 64-wide heads: the attention as
-        # ONE wave per (sequence, head), straight from the fused projection to the context layout (``ts_attention_bf16``)
+        # ONE wave per (sequence, head), straight from the fused projection to the context layout (``ts_attention_short``)
         short = x.dtype == torch.bfloat16 and hd == 64 and S <= 64 and os.environ.get("TS_ENCODER_ATTENTION", "1") != "0"
         mask = None if (no_padding or short) else torch.zeros((B, 1, 1, S), dtype=x.dtype, device=x.device).masked_fill_(
             ~attention_mask[:, None, None, :].to(torch.bool), float("-inf"))

@@ -1,5 +1,5 @@
 """Device time of the encoder-side kernels of libtsearch at the shapes of the encoder-in-loop step (256 sequences x 32 tokens x
-768, bf16): ts_add_layernorm, ts_pool_normalize, ts_embed_layernorm and ts_attention_bf16 (against torch's attention), us per call (hipEvent around 50 calls, best of 5)."""
+768, bf16): ts_add_layernorm, ts_pool_normalize, ts_embed_layernorm and ts_attention_short (against torch's attention), us per call (hipEvent around 50 calls, best of 5)."""
 import ctypes as C
 import json
 import os
@@ -61,7 +61,7 @@ for dt, code in ((torch.bfloat16, 1),):
 H = 12
 qkv = torch.randn((B, S, 3, H, 64), device=dev).to(torch.bfloat16)
 ctx = torch.empty((B, S, H * 64), dtype=torch.bfloat16, device=dev)
-res["attention_bf16"] = timed(lambda: lib.ts_attention_bf16(0, C.c_void_p(qkv.data_ptr()), None, B, S, H, 64, C.c_void_p(ctx.data_ptr()), st))
+res["attention_bf16"] = timed(lambda: lib.ts_attention_short(0, C.c_void_p(qkv.data_ptr()), None, B, S, H, 64, C.c_void_p(ctx.data_ptr()), st))
 qv = [qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3)]
 res["torch_sdpa_bf16"] = timed(lambda: torch.nn.functional.scaled_dot_product_attention(qv[0], qv[1], qv[2]))
 print(json.dumps(res))
