@@ -108,6 +108,7 @@ def test_encoder_call_surface(tiny_encoder):
     assert np.allclose(again, e, atol=1e-5)       # batching / length sorting does not change rows
     assert m.encode([]).shape == (0, 768)
     assert m.get_sentence_embedding_dimension() == 768 and not m.pretrained
+    assert callable(m.similarity) and m.pipeline.similarity_fn_name == "cosine"      # experiments/first_experiment.py:195
 
 
 def test_hashing_tokenizer_is_stable():

@@ -30,6 +30,29 @@ def test_cos_sim_and_semantic_search_match_oracle():
     oracle.check_topk_against_truth(truth, idx, scores, 5)
 
 
+def test_encoder_similarity_is_the_cosine_matrix(encoder):
+    """SentenceEncoder.similarity = SentenceTransformer.similarity as experiments/first_experiment.py:195,205 call it: the cosine
+    matrix of two embedding sets (1-D promoted), a torch tensor; a checkpoint that names the dot product gets that."""
+    import torch
+    a, b = oracle.golden_inputs(300, 5, 768, 17, "cos")
+    got = encoder.similarity(a, b)
+    assert isinstance(got, torch.Tensor) and tuple(got.shape) == (5, 300) and got.dtype == torch.float32
+    assert np.max(np.abs(got.numpy() - oracle.cos_sim(a, b))) <= 1e-5
+    assert tuple(encoder.similarity(a[0], torch.from_numpy(b[:7])).shape) == (1, 7)
+    emb = encoder.encode(["a tree on n vertices has n-1 edges", "every bounded sequence has a convergent subsequence"])
+    self_sim = encoder.similarity(emb, emb).numpy()
+    assert np.allclose(np.diag(self_sim), 1.0, atol=1e-5)
+    old = encoder.pipeline.similarity_fn_name
+    try:
+        encoder.pipeline.similarity_fn_name = "dot"
+        assert np.max(np.abs(encoder.similarity(a, b).numpy() - a.astype(np.float64) @ b.astype(np.float64).T)) <= 1e-4
+        encoder.pipeline.similarity_fn_name = "manhattan"
+        with pytest.raises(NotImplementedError):
+            encoder.similarity(a, b)
+    finally:
+        encoder.pipeline.similarity_fn_name = old
+
+
 def test_fused_pooling_epilogue_matches_torch():
     import ctypes as C
     import torch

@@ -124,6 +124,7 @@ class _Pipeline:
         self.normalize = False                     # a Normalize module: the output is always unit length
         self.prompts: dict = {}
         self.default_prompt_name: Optional[str] = None
+        self.similarity_fn_name: str = "cosine"
 
 
 def read_pipeline(folder: str) -> _Pipeline:
@@ -132,6 +133,7 @@ def read_pipeline(folder: str) -> _Pipeline:
     cst = _read_json(os.path.join(folder, "config_sentence_transformers.json"), {}) or {}
     p.prompts = dict(cst.get("prompts") or {})
     p.default_prompt_name = cst.get("default_prompt_name")
+    p.similarity_fn_name = cst.get("similarity_fn_name") or "cosine"
     modules = _read_json(os.path.join(folder, "modules.json"))
     if modules is None:
         # a plain transformers checkpoint: sentence-transformers wraps it as Transformer + mean Pooling
@@ -337,6 +339,21 @@ class SentenceEncoder:
         if normalize:
             emb = torch.nn.functional.normalize(emb, p=2, dim=1)
         return emb
+
+    def similarity(self, embeddings1, embeddings2) -> torch.Tensor:
+        """``SentenceTransformer.similarity(a, b)`` as the reference's experiments call it (experiments/first_experiment.py:195,
+        205, second_experiment.py): the ``[len(a) x len(b)]`` fp32 matrix of the checkpoint's similarity function - cosine
+        (``util.cos_sim``, the default) or dot product - as a torch tensor, computed by libtsearch (``ts_scores``).  Meant for
+        the small shapes of those scripts; a search is ``TheoremIndex.search``."""
+        from .index import TheoremIndex, _host_rows
+        name = getattr(getattr(self, "pipeline", None), "similarity_fn_name", None) or "cosine"
+        if name not in ("cosine", "dot"):
+            raise NotImplementedError(f"similarity function {name!r}")
+        a, b = _host_rows(embeddings1), _host_rows(embeddings2)
+        if a.shape[1] != b.shape[1]:
+            raise ValueError(f"dimension mismatch: {a.shape[1]} vs {b.shape[1]}")
+        with TheoremIndex.from_embeddings(b, dtype="f32", metric="cos" if name == "cosine" else "ip") as ix:
+            return torch.from_numpy(ix.scores(a))
 
     def encode(self, sentences: Union[str, Iterable[str]], batch_size: int = 32, show_progress_bar: Optional[bool] = None,
                convert_to_numpy: bool = True, convert_to_tensor: bool = False, normalize_embeddings: bool = False,
