@@ -19,6 +19,8 @@ expected outputs.  Nothing of the reference's source text is written out.
 4. ``text_to_embed.json`` - one synthetic paper through the string assembly of
    ``app_create_embeddings.py:48-70`` (the expression is evaluated from the
    parsed reference module, not retyped).
+6. ``showcase.json`` - what ``search_and_display`` of the showcase app (``app_showcase_model.py:79-156``) displays for
+   seven sidebar states (see ``gen_showcase``).
 5. ``callsites.json`` - what the reference's own call-site bodies print / display:
    ``compare_embeddings`` and ``evaluate_retrieval`` (``compare_embeddings.py:14-35,55-92``)
    and ``search_theorems`` (``app_scratchpad.py:120-154``), taken from the parsed files and
@@ -395,6 +397,71 @@ def gen_callsites():
     print("callsites:", out["cases"]["compare_embeddings"]["stdout"].splitlines()[0], "|", titles[0])
 
 
+def gen_showcase():
+    """search_and_display of the showcase app (app_showcase_model.py:79-156: encode -> util.cos_sim -> torch.topk(min(200, N))
+    -> the sidebar's predicates -> display) run as the reference wrote it, with util.cos_sim = the published torch formula, the
+    seeded stand-in model and the recording streamlit.  Two things are set aside, both outside the hot path: the file's one
+    Python-3.12-only f-string (a backslash inside the braces, :149 - this interpreter is 3.10) is back-ported textually to
+    the equivalent concatenation before parsing, and ``clean_latex_for_display`` (UI) is the identity, so that every
+    recorded call is comparable.  Fixture: theorems, filter states, and what each state displayed."""
+    import re
+    import types
+    src = open(os.path.join(REF, "app_showcase_model.py"), encoding="utf-8").read()
+    old = "st.markdown(f\"> {cleaned_ctx.replace('\\n', '\\n> ')}\")"
+    assert src.count(old) == 1, "the 3.12-only f-string of app_showcase_model.py:149 was not found"
+    src = src.replace(old, "st.markdown('> ' + cleaned_ctx.replace('\\n', '\\n> '))")
+    tree = ast.parse(src)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "search_and_display"]
+    assert len(keep) == 1
+    util = types.SimpleNamespace(cos_sim=st_cos_sim)
+    seed, d, n = 47, 96, 60
+    rng = np.random.default_rng(5)
+    types_, tags = ["theorem", "lemma", "proposition", "corollary"], ["math.AG", "math.NT", "math.PR", "math.CO"]
+    authors, sources = ["A. Author", "B. Writer", "C. Prover", "E. Noether"], ["arXiv", "Stacks Project", "ProofWiki"]
+    data = []
+    for j in range(n):
+        srcj = sources[int(rng.integers(0, 3))]
+        item = {"type": types_[int(rng.integers(0, 4))].capitalize() if j % 3 == 0 else types_[int(rng.integers(0, 4))],
+                "primary_math_tag": tags[int(rng.integers(0, 4))],
+                "authors": [authors[i] for i in rng.choice(4, size=int(rng.integers(0, 3)), replace=False)],
+                "source": srcj, "citations": int(rng.integers(0, 300)),
+                "paper_title": f"Paper {j // 3}", "paper_url": f"http://example.org/{j // 3}",
+                "global_context": "" if j % 4 else "**Notations:**\nG is a graph.", "content": f"Statement {j}: $x_{{{j}}} = {j}$.",
+                "text_to_embed": f"Statement {j % 57}"}
+        if srcj == "arXiv":
+            if j % 7:
+                item["year"] = int(rng.integers(1995, 2026))
+            if j % 5:
+                item["journal_published"] = bool(rng.integers(0, 2))
+        data.append(item)
+    base = {"types": [], "tags": [], "authors": [], "sources": list(sources), "citation_range": (0, 10 ** 6), "year_range": None,
+            "journal_status": "All", "top_k": 5}
+    states = {"open": dict(base), "types_tags": dict(base, types=["lemma", "theorem"], tags=["math.AG", "math.NT"], top_k=8),
+              "authors": dict(base, authors=["E. Noether", "C. Prover"], top_k=3),
+              "arxiv_years_journal": dict(base, sources=["arXiv"], year_range=(2005, 2022), journal_status="Journal Article", top_k=20),
+              "preprints_cited": dict(base, journal_status="Preprint Only", citation_range=(50, 200), top_k=4),
+              "nothing_passes": dict(base, types=["corollary"], tags=["math.CO"], authors=["A. Author"], citation_range=(299, 299)),
+              "no_sources": dict(base, sources=[])}
+    model = StubModel(seed, d)
+    db = model.encode([t["text_to_embed"] for t in data], convert_to_tensor=True)
+    out = {"recipe": "as callsites.json; clean_latex_for_display = identity", "seed": seed, "d": d, "theorems_data": data,
+           "query": "Statement 11", "states": {}}
+    for name, f in states.items():
+        st = RecordingStreamlit()
+        ns = {"util": util, "torch": torch, "st": st, "re": re, "clean_latex_for_display": lambda text: text}
+        exec(compile(ast.Module(body=keep, type_ignores=[]), "app_showcase_model.py", "exec"), ns)
+        ns["search_and_display"](out["query"], model, data, db, f)
+        out["states"][name] = {"filters": f, "calls": st.calls}
+    st = RecordingStreamlit()
+    ns = {"util": util, "torch": torch, "st": st, "re": re, "clean_latex_for_display": lambda text: text}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "app_showcase_model.py", "exec"), ns)
+    ns["search_and_display"]("", model, data, db, states["open"])
+    out["empty_query_calls"] = st.calls
+    with open(os.path.join(OUT, "showcase.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("showcase:", {k: len([c for c in v["calls"] if c[0] == "expander"]) for k, v in out["states"].items()})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -404,6 +471,7 @@ def main():
     gen_adversarial()
     gen_text()
     gen_callsites()
+    gen_showcase()
 
 
 if __name__ == "__main__":

@@ -63,3 +63,44 @@ def test_search_theorems_displays_what_the_reference_displays(monkeypatch):
     st2 = RecordingStreamlit()
     app_scratchpad.search_theorems("", model, data, OracleIndex(db), st2)
     assert st2.calls == case["empty_query_calls"]
+
+
+def _showcase_filters(f):
+    f = dict(f)
+    f["citation_range"] = tuple(f["citation_range"])
+    if f["year_range"] is not None:
+        f["year_range"] = tuple(f["year_range"])
+    return f
+
+
+def test_search_and_display_displays_what_the_reference_displays(monkeypatch):
+    """theoremsearch_amd.app_showcase_model.search_and_display against the recorded streamlit calls of the reference's own
+    function (app_showcase_model.py:79-156, tests/golden/showcase.json) for seven sidebar states, an empty query included;
+    the index is stood in for by the oracle over the allowed rows (no GPU here; tests/test_mirrors_gpu.py runs libtsearch)."""
+    from theoremsearch_amd import app_showcase_model
+
+    class OracleIndex:
+        def __init__(self, rows):
+            self.rows, self.n, self.row_offset = rows, rows.shape[0], 0
+
+        def search(self, q, k, mask=None):
+            allowed = np.flatnonzero(mask) if mask is not None else np.arange(self.n)
+            scores = np.full((1, k), -np.inf, np.float32)
+            idx = np.full((1, k), -1, np.int64)
+            if allowed.size:
+                s, i = oracle.search(np.asarray(q).reshape(1, -1), self.rows[allowed], min(k, allowed.size), "cos", "f32")
+                scores[0, :s.shape[1]], idx[0, :s.shape[1]] = s[0], allowed[i[0]]
+            return scores, idx
+
+    case = load_json("showcase.json")
+    model = StubModel(case["seed"], case["d"])
+    data = case["theorems_data"]
+    db = model.encode([t["text_to_embed"] for t in data])
+    monkeypatch.setattr(app_showcase_model, "TheoremIndex", OracleIndex)
+    for name, state in case["states"].items():
+        st = RecordingStreamlit()
+        app_showcase_model.search_and_display(case["query"], model, data, OracleIndex(db), _showcase_filters(state["filters"]), st)
+        assert st.calls == state["calls"], name
+    st = RecordingStreamlit()
+    app_showcase_model.search_and_display("", model, data, OracleIndex(db), _showcase_filters(case["states"]["open"]["filters"]), st)
+    assert st.calls == case["empty_query_calls"]

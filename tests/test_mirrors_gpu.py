@@ -53,6 +53,28 @@ def test_encoder_similarity_is_the_cosine_matrix(encoder):
         encoder.pipeline.similarity_fn_name = old
 
 
+def test_search_and_display_through_libtsearch_displays_what_the_reference_displays():
+    """The showcase app's search function (app_showcase_model.py:79-156) through the filtered search of libtsearch: the
+    recorded streamlit calls of the reference's own function for every sidebar state of tests/golden/showcase.json, with
+    the matrix and with an index kept across calls."""
+    import json
+    from callsites_common import RecordingStreamlit, StubModel
+    from theoremsearch_amd import TheoremIndex, app_showcase_model
+    case = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "showcase.json")))
+    model = StubModel(case["seed"], case["d"])
+    data = case["theorems_data"]
+    db = model.encode([t["text_to_embed"] for t in data])
+    with TheoremIndex.from_embeddings(db, metric="cos") as ix:
+        for name, state in case["states"].items():
+            f = dict(state["filters"], citation_range=tuple(state["filters"]["citation_range"]))
+            if f["year_range"] is not None:
+                f["year_range"] = tuple(f["year_range"])
+            for corpus in (db, ix):
+                st = RecordingStreamlit()
+                app_showcase_model.search_and_display(case["query"], model, data, corpus, f, st)
+                assert st.calls == state["calls"], name
+
+
 def test_fused_pooling_epilogue_matches_torch():
     import ctypes as C
     import torch
