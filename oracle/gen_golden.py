@@ -462,6 +462,29 @@ def gen_showcase():
     print("showcase:", {k: len([c for c in v["calls"] if c[0] == "expander"]) for k, v in out["states"].items()})
 
 
+def gen_paper_filter():
+    """parse_paper_filter / extract_arxiv_id / normalize_title of the production app (streamlit_app.py:44-47,118-143), run as the
+    reference wrote them (function bodies and the ARXIV_ID_RE assignment taken from the parsed file) on a list of inputs."""
+    import re
+    tree = ast.parse(open(os.path.join(REF, "streamlit_app.py"), encoding="utf-8").read())
+    keep = [n for n in tree.body
+            if (isinstance(n, ast.FunctionDef) and n.name in ("extract_arxiv_id", "normalize_title", "parse_paper_filter"))
+            or (isinstance(n, ast.Assign) and any(getattr(t, "id", "") == "ARXIV_ID_RE" for t in n.targets))]
+    assert len(keep) == 4
+    ns = {"re": re}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "streamlit_app.py", "exec"), ns)
+    inputs = ["", None, "2401.12345", "https://arxiv.org/abs/2401.12345v2, Optimal Transport", "arXiv.org/pdf/math-ph/0701012",
+              " Riemann  Hypothesis ,, STRASSE ", "math/0307245, 0704.0001 , hep-th/9901001x", "1234.567", "Título Ünïcode, ARXIV.ORG/ABS/2101.00001",
+              "a,b,a , B", "see https://arxiv.org/abs/1706.03762 and 1810.04805"]
+    out = {"inputs": inputs, "parsed": [], "ids": [ns["extract_arxiv_id"](x) for x in inputs], "titles": [ns["normalize_title"](x) for x in inputs]}
+    for x in inputs:
+        r = ns["parse_paper_filter"](x)
+        out["parsed"].append({"ids": sorted(r["ids"]), "titles": sorted(r["titles"])})
+    with open(os.path.join(OUT, "paper_filter.json"), "w") as f:
+        json.dump(out, f, indent=1, ensure_ascii=False)
+    print("paper_filter:", out["parsed"][3])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -472,6 +495,7 @@ def main():
     gen_text()
     gen_callsites()
     gen_showcase()
+    gen_paper_filter()
 
 
 if __name__ == "__main__":

@@ -52,3 +52,22 @@ def test_sql_where_mask_agrees_with_the_clause_by_clause_restatement(state):
         assert 0.85 < mask.mean() < 0.95          # the rows with a NULL link match neither source clause
     else:
         assert 0 < mask.sum() < len(rows)
+
+
+def test_paper_filter_parsing_is_the_references():
+    """filters.parse_paper_filter / extract_arxiv_id / normalize_title against the outputs of the reference's own functions
+    (streamlit_app.py:118-143, tests/golden/paper_filter.json), and the parsed state drives sql_filter_mask's paper clause."""
+    from conftest import load_json
+    from theoremsearch_amd import filters
+    case = load_json("paper_filter.json")
+    for x, want, wid, wt in zip(case["inputs"], case["parsed"], case["ids"], case["titles"]):
+        got = filters.parse_paper_filter(x)
+        assert {"ids": sorted(got["ids"]), "titles": sorted(got["titles"])} == want, x
+        assert filters.extract_arxiv_id(x) == wid and filters.normalize_title(x) == wt
+    rows = [{"link": "https://arxiv.org/abs/2401.12345", "title": "On Optimal Transport", "citations": 3},
+            {"link": "https://arxiv.org/abs/1706.03762", "title": "Attention", "citations": 3},
+            {"link": None, "title": "Stacks: optimal TRANSPORT of schemes", "citations": 3}]
+    f = {"sources": [], "citation_range": (0, 10), "paper_filter": filters.parse_paper_filter("2401.12345")}
+    assert filters.sql_filter_mask(rows, f).tolist() == [True, False, False]
+    f["paper_filter"] = filters.parse_paper_filter("Optimal Transport")
+    assert filters.sql_filter_mask(rows, f).tolist() == [True, False, True]

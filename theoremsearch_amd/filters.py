@@ -12,6 +12,8 @@ from __future__ import annotations
 
 from typing import Mapping, Sequence
 
+import re
+
 import numpy as np
 
 
@@ -71,6 +73,37 @@ def search_filtered(index, query_emb, theorems_data: Sequence[Mapping], filters:
 
 
 # ---- the in-database form: WHERE clauses of the production app ---------------------------------------------------------
+# the "paper" box of the production app (streamlit_app.py:44-47,118-143): arXiv ids and title fragments, comma-separated
+ARXIV_ID_RE = re.compile(r"(?:arxiv\.org/(?:abs|pdf)/)?((?:\d{4}\.\d{4,5}|[a-z\-]+/\d{7}))", re.IGNORECASE)
+
+
+def extract_arxiv_id(s: str):
+    """The arXiv id inside ``s`` (a URL or the bare id), or None."""
+    if not s:
+        return None
+    m = ARXIV_ID_RE.search(s.strip())
+    return m.group(1) if m else None
+
+
+def normalize_title(s: str) -> str:
+    return (s or "").casefold().strip()
+
+
+def parse_paper_filter(raw: str) -> dict:
+    """``"2401.12345, Optimal Transport"`` -> ``{"ids": {"2401.12345"}, "titles": {"optimal transport"}}``: the
+    ``paper_filter`` entry of the filter state `sql_filter_mask` evaluates (ILIKE on the paper's link / title)."""
+    ids, titles = set(), set()
+    for token in (t.strip() for t in (raw or "").split(",")):
+        if not token:
+            continue
+        arx = extract_arxiv_id(token)
+        if arx:
+            ids.add(arx.lower())
+        else:
+            titles.add(normalize_title(token))
+    return {"ids": ids, "titles": titles}
+
+
 def _ilike(text, needle: str) -> bool:
     """``text ILIKE '%needle%'`` for a non-NULL text (case-insensitive substring)."""
     return needle.lower() in text.lower()
