@@ -104,3 +104,19 @@ def test_search_and_display_displays_what_the_reference_displays(monkeypatch):
     st = RecordingStreamlit()
     app_showcase_model.search_and_display("", model, data, OracleIndex(db), _showcase_filters(case["states"]["open"]["filters"]), st)
     assert st.calls == case["empty_query_calls"]
+
+
+def test_load_and_prepare_data_builds_the_references_records(tmp_path):
+    """app_scratchpad.load_and_prepare_data against the records (and warnings) of the reference's own function
+    (app_scratchpad.py:23-63, tests/golden/scratchpad_data.json): text_to_embed is what the corpus embeddings are made of."""
+    import json
+    from theoremsearch_amd import app_scratchpad
+    case = load_json("scratchpad_data.json")
+    for name, body in case["papers"].items():
+        (tmp_path / name).write_text(json.dumps(body), encoding="utf-8")
+    (tmp_path / "broken.json").write_text(case["broken"])
+    st = RecordingStreamlit()
+    got = app_scratchpad.load_and_prepare_data([str(tmp_path / n) for n in case["order"]], st)
+    assert got == case["records"]
+    assert [[c[0], c[1].replace(str(tmp_path) + "/", "<dir>/")] for c in st.calls] == case["warnings"]
+    assert app_scratchpad.load_and_prepare_data([str(tmp_path / "missing.json")]) == []        # no streamlit: skipped silently
