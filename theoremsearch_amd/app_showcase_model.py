@@ -20,6 +20,37 @@ from .index import TheoremIndex
 
 MODEL_NAME = "math-similarity/Bert-MLM_arXiv-MP-class_zbMath"      # app_showcase_model.py:10
 EMBEDDING_LIBRARY_DIR = "./app_embeds"                               # app_showcase_model.py:11
+ALLOWED_TYPES = ["theorem", "lemma", "proposition", "corollary", "definition", "remark", "assumption"]   # :27-29
+
+
+def load_model(st=None):
+    """``app_showcase_model.py:32-38``: the embedding model, or None with the reason shown through ``st.error`` (when a
+    streamlit module is passed).  One instance serves every session thread (the app wraps this in ``st.cache_resource``)."""
+    from .encoder import SentenceEncoder
+    try:
+        return SentenceEncoder(MODEL_NAME)
+    except Exception as e:                 # noqa: BLE001 - the app shows whatever went wrong and carries on without a model
+        if st is not None:
+            st.error(f"Error loading embedding model: {e}")
+        return None
+
+
+def load_embedding_library(directory, st=None):
+    """``app_showcase_model.py:41-58``: ``(embeddings, theorems_data)`` from ``corpus_embeddings.pt`` + ``theorems_data.pkl``,
+    or ``(None, None)`` with the app's messages through ``st``."""
+    import os
+    from . import app_create_embeddings as ace
+    if not os.path.exists(os.path.join(directory, "corpus_embeddings.pt")) or not os.path.exists(os.path.join(directory, "theorems_data.pkl")):
+        if st is not None:
+            st.error(f"Error: Embedding library not found in '{directory}'.")
+            st.info("Please run the `app_create_embeddings.py` script first to generate the necessary files.")
+        return None, None
+    try:
+        return ace.load_embedding_library(directory)
+    except Exception as e:                 # noqa: BLE001
+        if st is not None:
+            st.error(f"Error loading files from the embedding library: {e}")
+        return None, None
 
 
 def search_and_display(query, model, theorems_data, embeddings_db, filters, st, clean_latex_for_display=lambda text: text,
