@@ -5,9 +5,9 @@
 // contraction of the search kernels (rows x queries), with both sides streamed.
 //
 // Why a kernel of our own: the encoder-in-loop step (BASELINE configs[4]) spends 2.04 of its 5.6 ms in four GEMM shapes
-// (8,192 x {2304, 768, 3072, 768} x {768, 768, 768, 3072}) that the BLAS library runs at 550-860 TF/s because its tiles
-// do not divide them: 258 tiles of 192 x 128 for 256 CUs (two rounds, the second one two tiles), 516 of 192 x 256 (three
-// rounds).  Here the tile is chosen per shape so that the grid is a whole number of rounds (256 x 96 -> 256 tiles for
+// (8,192 x {2304, 768, 3072, 768} x {768, 768, 768, 3072}) that the BLAS library runs at 550-860 TF/s inside that step.  The
+// starting premise - its 192 x 128 / 192 x 256 tiles leaving a tail (258 / 516 tiles for 256 CUs) - holds only if the 192 runs
+// along the tokens; along the output features they divide the shapes exactly (profiles/r03_linear_gemm_ab.txt).  Here the tile is chosen per shape so that the grid is a whole number of rounds (256 x 96 -> 256 tiles for
 // N = 768, 256 x 288 -> 256 tiles for N = 2304, 256 x 192 -> 512 tiles for N = 3072), and the exact erf GELU of the
 // intermediate layer is applied where the accumulators are (one elementwise launch and a 100 MB round trip less per
 // layer).
