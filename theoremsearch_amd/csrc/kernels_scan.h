@@ -64,7 +64,18 @@ __device__ __forceinline__ uint4 stream_load(const uint4* p) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-// dot of one 16-byte chunk with VEC query values, accumulated left to right
+// dot of one 16-byte chunk with VEC query values, accumulated left to right.
+// bf16 rows: v_dot2c_f32_bf16 on the packed pairs as they lie (two products and the running sum per instruction) instead of
+// two conversions and two fmaf - a pass of four queries over a bf16 index is bound by its vector work, not by HBM (3.35 ms
+// for 10M x 768 against 2.3 for the stream).  The queries of a bf16 index are bf16 values held in fp32 (prep_rows_kernel
+// rounds them to the storage type, scan_query_elem widens the caller's bf16 matrix), so their upper halves ARE the operands;
+// the pairs are loop-invariant and the compiler packs them once per query, outside the row loop.
+typedef __bf16 scan_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot2_bf16(u32 rows, float q_lo, float q_hi, float acc) {
+    const u32 qp = (__float_as_uint(q_lo) >> 16) | (__float_as_uint(q_hi) & 0xFFFF0000u);
+    return __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const scan_bf16x2*>(&rows), *reinterpret_cast<const scan_bf16x2*>(&qp), acc,
+                                           false);
+}
 template <int DT>
 __device__ __forceinline__ float chunk_dot(const uint4& v, const float* q, float acc) {
     if (DT == 0) {
@@ -73,14 +84,10 @@ __device__ __forceinline__ float chunk_dot(const uint4& v, const float* q, float
         acc = fmaf(__uint_as_float(v.z), q[2], acc);
         acc = fmaf(__uint_as_float(v.w), q[3], acc);
     } else {
-        acc = fmaf(bf16_lo(v.x), q[0], acc);
-        acc = fmaf(bf16_hi(v.x), q[1], acc);
-        acc = fmaf(bf16_lo(v.y), q[2], acc);
-        acc = fmaf(bf16_hi(v.y), q[3], acc);
-        acc = fmaf(bf16_lo(v.z), q[4], acc);
-        acc = fmaf(bf16_hi(v.z), q[5], acc);
-        acc = fmaf(bf16_lo(v.w), q[6], acc);
-        acc = fmaf(bf16_hi(v.w), q[7], acc);
+        acc = dot2_bf16(v.x, q[0], q[1], acc);
+        acc = dot2_bf16(v.y, q[2], q[3], acc);
+        acc = dot2_bf16(v.z, q[4], q[5], acc);
+        acc = dot2_bf16(v.w, q[6], q[7], acc);
     }
     return acc;
 }
