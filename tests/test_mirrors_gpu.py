@@ -82,10 +82,12 @@ def test_fused_pooling_epilogue_matches_torch():
     lib = _ffi.load()
     g = torch.Generator(device="cpu").manual_seed(3)
     for dtype in (torch.float32, torch.bfloat16):
-        for d in (768, 1024):
-            hidden = torch.randn((37, 19, d), generator=g).to(dtype).cuda()
-            lens = torch.randint(1, 20, (37,), generator=g)
-            mask = (torch.arange(19)[None, :] < lens[:, None]).to(torch.int64).cuda()
+        # widths of the vector form (d / 8 or d / 4 vectors per row: 48 ... 256 -> 5 ... 1 token groups) and one it does not
+        # take (d = 100: not a multiple of the bf16 vector -> the general kernel); a long sequence takes the general kernel too
+        for d, S in ((768, 19), (1024, 19), (384, 19), (100, 7), (256, 1100)):
+            hidden = torch.randn((37, S, d), generator=g).to(dtype).cuda()
+            lens = torch.randint(1, S + 1, (37,), generator=g)
+            mask = (torch.arange(S)[None, :] < lens[:, None]).to(torch.int64).cuda()
             hf, mf = hidden.double(), mask.unsqueeze(-1).double()          # fp64 reference of the same inputs
             refs = {0: (hf * mf).sum(1) / mf.sum(1).clamp(min=1e-9),
                     1: hf[torch.arange(37, device="cuda"), mask.sum(1) - 1], 2: hf[:, 0]}
@@ -94,14 +96,14 @@ def test_fused_pooling_epilogue_matches_torch():
                     want = (torch.nn.functional.normalize(ref, p=2, dim=1) if normalize else ref).float()
                     out = torch.empty((37, d), dtype=torch.float32, device="cuda")
                     _ffi.check(lib.ts_pool_normalize(0, C.c_void_p(hidden.data_ptr()), 1 if dtype == torch.bfloat16 else 0,
-                                                     C.c_void_p(mask.data_ptr()), 37, 19, d, pooling, normalize,
+                                                     C.c_void_p(mask.data_ptr()), 37, S, d, pooling, normalize,
                                                      C.c_void_p(out.data_ptr()), 0, d,
                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
                     torch.cuda.synchronize()
                     assert torch.allclose(out, want, atol=1e-5, rtol=1e-5), (dtype, d, pooling, normalize, (out - want).abs().max().item())
                     outb = torch.empty((37, d), dtype=torch.bfloat16, device="cuda")
                     _ffi.check(lib.ts_pool_normalize(0, C.c_void_p(hidden.data_ptr()), 1 if dtype == torch.bfloat16 else 0,
-                                                     C.c_void_p(mask.data_ptr()), 37, 19, d, pooling, normalize,
+                                                     C.c_void_p(mask.data_ptr()), 37, S, d, pooling, normalize,
                                                      C.c_void_p(outb.data_ptr()), 1, d,
                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
                     torch.cuda.synchronize()
