@@ -71,16 +71,36 @@ class IndexRanking:
         return self.index.rank_of(self.query_emb, docs)[0]
 
 
+class _SharedRanking(np.ndarray):
+    """The similarity matrix `evaluate_retrieval` hands to its six metrics: an ndarray (the metrics take ``sim_matrix``, as
+    in the reference) that remembers the rankings already taken of it - the reference argsorts the same matrix six times
+    (compare_embeddings.py:105,129,152,223,268,327); here the selection runs once per k."""
+
+    def __new__(cls, a):
+        obj = np.asarray(a).view(cls)
+        obj._tops = {}
+        return obj
+
+    def __array_finalize__(self, obj):
+        self._tops = {}                    # a slice or a copy is another matrix: nothing is remembered for it
+
+
 def _top(sim_matrix, k):
     """Indices of the k best docs per query, best first (all docs when k is None)."""
     if isinstance(sim_matrix, IndexRanking):
         if k is None:
             raise ValueError("a full ranking is not materialised for an IndexRanking")
         return sim_matrix.top(k)
+    shared = sim_matrix._tops if isinstance(sim_matrix, _SharedRanking) else None
+    if shared is not None and k in shared:
+        return shared[k]
     s = np.asarray(sim_matrix)
     if k is None or k >= s.shape[1]:
-        return np.argsort(-s, axis=1)
-    _, idx = util.topk(s, k)
+        idx = np.argsort(-s, axis=1)
+    else:
+        _, idx = util.topk(s, k)
+    if shared is not None:
+        shared[k] = idx
     return idx
 
 
@@ -97,7 +117,7 @@ def evaluate_retrieval(model, theorems, queries, qrels, top_k_report=3):
     s_emb = model.encode([item[0] for item in theorems], convert_to_tensor=True)
     q_emb = model.encode([item[0] for item in queries], convert_to_tensor=True)
     print("Creating sim_matrix...")
-    sim_matrix = util.cos_sim(q_emb, s_emb)
+    sim_matrix = _SharedRanking(util.cos_sim(q_emb, s_emb))
     print("Cos-sim matrix dim", sim_matrix.shape)
     print("Ranking concepts...")
     print("=" * 50)

@@ -51,13 +51,14 @@ def topk(scores, k: int) -> Tuple[np.ndarray, np.ndarray]:
     order = np.lexsort((part, -vals), axis=1)
     idx = np.take_along_axis(part, order, axis=1).astype(np.int64)
     vals = np.take_along_axis(vals, order, axis=1)
-    # ties that straddle the partition boundary: prefer the lowest index among equal scores
-    for b in range(s2.shape[0]):
-        kth = vals[b, -1]
-        tied = np.flatnonzero(key[b] == kth)
-        if tied.size > np.count_nonzero(vals[b] == kth):
-            keep = vals[b] > kth
-            need = kk - int(keep.sum())
-            idx[b] = np.concatenate([idx[b][keep], tied[:need]])
-            vals[b] = key[b][idx[b]]
+    # ties that straddle the partition boundary: prefer the lowest index among equal scores (rows where the k-th score
+    # occurs more often in the row than among the selected are found in one vector pass; usually none)
+    kth = vals[:, -1:]
+    straddle = np.flatnonzero((key == kth).sum(axis=1) > (vals == kth).sum(axis=1))
+    for b in straddle:
+        tied = np.flatnonzero(key[b] == kth[b, 0])
+        keep = vals[b] > kth[b, 0]
+        need = kk - int(keep.sum())
+        idx[b] = np.concatenate([idx[b][keep], tied[:need]])
+        vals[b] = key[b][idx[b]]
     return (vals[0], idx[0]) if one else (vals, idx)
