@@ -2,8 +2,9 @@
 """bench.py - queries/sec of brute-force top-10 over an [N x 768] theorem-embedding matrix.
 
 Contract (one JSON line on rank 0):
-  python bench.py --gpus N --steps K --warmup W          (N = 1)
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+  python bench.py --gpus N --steps K --warmup W          (any N: for N > 1 this process starts the N ranks itself as
+                                                          child processes, one per GPU - launch_ranks)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1 under a launcher: the same ranks)
 
 Workload (BASELINE.json): configs[2] "10M x 768 bf16 corpus, batch-256 queries" - the shape the
 north-star target is quoted on; it fits one GPU (15.36 GB).  One step = one batch of 256 queries
@@ -48,6 +49,85 @@ MFMA_RANDOM_DATA_GEMM_TFLOPS = 1247.0   # MI355X_MICROARCH.md "DVFS give-back" i
 def log(rank, *a):
     if rank == 0:
         print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def launch_ranks(n, share_gpu):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: this process starts the N ranks itself - one CHILD
+    process per GPU with the environment `torch.distributed.run` would give it (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_*),
+    the same argv - waits for them, hands rank 0's JSON line to its own stdout and exits with the first non-zero exit
+    code.  The parent never imports torch and never touches HIP (children are started with `subprocess`, nothing is
+    exec'ed over a process that has initialised the GPU).  A rank that dies takes the others with it (they would wait in
+    a collective for ever): the survivors get SIGTERM, then SIGKILL, by pid.
+    SURVEY.md 8e: the reference's only multi-device call is SentenceTransformer.encode_multi_process
+    (ec2/generate_embeddings/embeddings.py:32) - a worker pool started by the library from one `python -m` command."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ncpu = len(os.sched_getaffinity(0))
+    procs, lines = [], []
+    lock = threading.Lock()
+
+    def relay(p):
+        for raw in p.stdout:                       # a rank's stdout: only rank 0 writes there, exactly one JSON line
+            ln = raw.decode("utf-8", "replace")
+            if ln.lstrip().startswith("{"):
+                with lock:
+                    lines.append(ln if ln.endswith("\n") else ln + "\n")
+            elif ln.strip():
+                sys.stderr.write(ln)
+
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "TS_BENCH_LAUNCHED_BY": "bench.py"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, ncpu // n)))
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE)
+        t = threading.Thread(target=relay, args=(p,), daemon=True)
+        t.start()
+        procs.append((p, t))
+
+    def stop_all(sig):
+        for p, _ in procs:
+            if p.poll() is None:
+                try:
+                    p.send_signal(sig)
+                except OSError:
+                    pass
+
+    signal.signal(signal.SIGTERM, lambda *_: (stop_all(signal.SIGTERM), sys.exit(143)))
+    rc = 0
+    try:
+        while any(p.poll() is None for p, _ in procs):
+            for p, _ in procs:
+                if p.poll() not in (None, 0) and rc == 0:
+                    rc = p.returncode
+                    print(f"[bench] rank process {p.pid} exited with {rc}: stopping the other ranks", file=sys.stderr, flush=True)
+                    stop_all(signal.SIGTERM)
+                    t_end = time.time() + 20
+                    while time.time() < t_end and any(q.poll() is None for q, _ in procs):
+                        time.sleep(0.2)
+                    stop_all(signal.SIGKILL)
+            time.sleep(0.1)
+    except KeyboardInterrupt:
+        stop_all(signal.SIGTERM)
+        rc = 130
+    for p, t in procs:
+        p.wait()
+        t.join(timeout=5)
+        if rc == 0 and p.returncode != 0:
+            rc = p.returncode
+    if rc == 0 and len(lines) != 1:
+        print(f"[bench] expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr, flush=True)
+        rc = 1
+    if rc == 0:
+        sys.stdout.write(lines[0])
+        sys.stdout.flush()
+    sys.exit(rc)
 
 
 def run_c1(args, real_stdout):
@@ -176,6 +256,9 @@ def main():
     args = ap.parse_args()
     global D
     D = args.dim
+    if args.workload != "c1" and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around this process: start the ranks as child processes (before torch is imported or HIP touched)
+        return launch_ranks(args.gpus, args.share_gpu)
     # Exactly ONE line goes to stdout (the JSON): libraries print banners there (RCCL prints its version / host /
     # library path on communicator creation), so fd 1 points at stderr until the result line is written.
     sys.stdout.flush()
@@ -189,7 +272,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+            raise SystemExit("--gpus N > 1 inside a launcher that set WORLD_SIZE=1: start `python bench.py --gpus N` bare (it starts "
+                             "its own ranks) or under torch.distributed.run --nproc-per-node N")
         args.gpus = world
 
     import torch
@@ -203,6 +287,9 @@ def main():
         raise SystemExit("bench.py needs a HIP device (libtsearch has no CPU path)")
     if args.share_gpu:
         local_rank = 0
+    if local_rank >= _ffi.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({_ffi.device_count()} visible); "
+                         f"--share-gpu rehearses several ranks on one GPU")
     torch.cuda.set_device(local_rank)
     if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -425,6 +512,14 @@ def main():
                      "ms_per_step": round(dt_s / sustained_steps * 1e3, 4), "kernel_brackets": True,
                      "kernel_ms": round(sp["total_ms"] / max(1, sp["launches"]), 4), "seconds": round(dt_s, 3)}
 
+    # ---- the exchange as the communicator saw it (N > 1): backend, world, one device per rank, and what ONE all-gather of
+    # the packed per-shard top-k costs on the side stream (outside the timed region; every rank takes part) ----------------
+    exchange = None
+    if searcher is not None:
+        exchange = searcher.measure_exchange(nq, K)
+        exchange["launched_by"] = os.environ.get("TS_BENCH_LAUNCHED_BY", "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "env")
+        log(rank, f"exchange: {exchange}")
+
     # ---- how the search ran (one extra search outside the timed region): algorithm, levels, candidates ----------------
     search_stats, stats_algo = None, None
     if not mask_ptr and encoder is None:
@@ -603,6 +698,7 @@ def main():
             "recall_at_10": recall,
             "parity": parity,
             "search_stats": search_stats,
+            "exchange": exchange,
             "sustained": sustained,
             "roofline": roofline,
             "cpu_baseline": cpu,

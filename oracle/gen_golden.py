@@ -485,44 +485,6 @@ def gen_paper_filter():
     print("paper_filter:", out["parsed"][3])
 
 
-def gen_scratchpad_data():
-    """load_and_prepare_data of the scratch app (app_scratchpad.py:23-63), run as the reference wrote it (function body taken
-    from the parsed file, the @st.cache_data decorator dropped, a recording streamlit) on three parsed-paper files written to
-    a temporary directory, one missing file and one that is not JSON.  Fixture: the file contents and the records."""
-    import tempfile
-    tree = ast.parse(open(os.path.join(REF, "app_scratchpad.py"), encoding="utf-8").read())
-    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "load_and_prepare_data"]
-    assert len(fn) == 1
-    fn[0].decorator_list = []
-    st = RecordingStreamlit()
-    ns = {"json": json, "st": st}
-    exec(compile(ast.Module(body=fn, type_ignores=[]), "app_scratchpad.py", "exec"), ns)
-    papers = {
-        "a.json": {"title": "Trees", "url": "http://example.org/a", "global_notations": "$G$ is a graph.",
-                   "global_definitions": "A tree is a connected acyclic graph.", "global_assumptions": "",
-                   "theorems": [{"type": "theorem", "content": "A tree on $n$ vertices has $n-1$ edges."},
-                                {"type": "lemma", "content": "Every tree has a leaf."}]},
-        "b.json": {"url": "http://example.org/b", "global_assumptions": "All rings are commutative.",
-                   "theorems": [{"type": "proposition", "content": "A field has no proper ideals."}]},
-        "c.json": {"title": "Empty", "theorems": []},
-    }
-    with tempfile.TemporaryDirectory() as tmp:
-        names = []
-        for name, body in papers.items():
-            with open(os.path.join(tmp, name), "w", encoding="utf-8") as f:
-                json.dump(body, f)
-            names.append(name)
-        with open(os.path.join(tmp, "broken.json"), "w") as f:
-            f.write("{not json")
-        order = ["a.json", "missing.json", "b.json", "broken.json", "c.json"]
-        records = ns["load_and_prepare_data"]([os.path.join(tmp, n) for n in order])
-        warnings = [[c[0], c[1].replace(tmp + os.sep, "<dir>/")] for c in st.calls]
-    out = {"papers": papers, "broken": "{not json", "order": order, "records": records, "warnings": warnings}
-    with open(os.path.join(OUT, "scratchpad_data.json"), "w") as f:
-        json.dump(out, f, indent=1)
-    print("scratchpad_data:", len(records), "records,", len(warnings), "warnings")
-
-
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -534,7 +496,6 @@ def main():
     gen_callsites()
     gen_showcase()
     gen_paper_filter()
-    gen_scratchpad_data()
 
 
 if __name__ == "__main__":

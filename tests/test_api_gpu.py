@@ -254,6 +254,38 @@ def test_sharded_searcher_device_pipeline_with_changing_queries(ts, pipeline):
         searcher.close()
 
 
+@pytest.mark.parametrize("pipeline", [1, 2])
+def test_sharded_pipeline_reads_a_query_buffer_that_the_caller_rewrites_every_step(ts, pipeline):
+    """ONE device buffer of queries in the index's own form (bf16, a whole launch's worth: read in place, no copy), rewritten
+    on the caller's stream before every call - what an encoder replaying into a static output does (bench.py c5).  With two
+    searches in flight the search runs on a lane stream of its own: the caller's stream must be ordered behind that read,
+    or step i + 1's rewrite lands in the rows step i is still multiplying."""
+    import torch
+    from theoremsearch_amd.distributed import ShardedSearcher
+    n, nq, k = 400_000, 64, 10
+    _, c = oracle.golden_inputs(n, 1, 768, 22, "ip")
+    rng = np.random.default_rng(6)
+    batches = [oracle.bf16_bits_to_f32(oracle.f32_to_bf16_bits(rng.standard_normal((nq, 768)).astype(np.float32))) for _ in range(8)]
+    with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as ix:
+        want = [ix.search(b, k) for b in batches]
+        searcher = ShardedSearcher(index=ix, pipeline=pipeline)
+        dev = [torch.from_numpy(b).cuda().to(torch.bfloat16) for b in batches]
+        qbuf = torch.empty((nq, 768), dtype=torch.bfloat16, device="cuda")
+        torch.cuda.synchronize()
+        main = torch.cuda.Stream()
+        for lo in range(0, len(dev), 4):                    # four result blocks in rotation: four calls, then look
+            got = []
+            for qd in dev[lo:lo + 4]:
+                with torch.cuda.stream(main):
+                    qbuf.copy_(qd, non_blocking=True)       # the rewrite: ordered on the caller's stream only
+                got.append(searcher.search_device(qbuf.data_ptr(), "bf16", nq, k, stream=main))
+            for j, (s, i, done) in enumerate(got):
+                done.synchronize()
+                assert np.array_equal(i.cpu().numpy(), want[lo + j][1]), f"step {lo + j}"
+                assert np.array_equal(s.cpu().numpy(), want[lo + j][0]), f"step {lo + j}"
+        searcher.close()
+
+
 def test_answers_do_not_move_with_the_tile_shares_of_the_full_pass(ts):
     """The full pass takes each workgroup's tile range from a table that the final select moves after every search
     (towards equal finishing times of the XCDs).  Same queries, ten searches in a row: the table moves, the answers may

@@ -1,10 +1,10 @@
 """The mirrors of the reference's call-site bodies against what those bodies themselves printed when executed
 (tests/golden/callsites.json, made by oracle/gen_golden.py from compare_embeddings.py:14-35,55-92 and
-app_scratchpad.py:120-154).  On CPU the score matrix / top-k come from the oracle's numpy restatement (the HIP library
+app_scratchpad.py:120-154; the apps' search functions: the hits they display).  On CPU the score matrix / top-k come from the oracle's numpy restatement (the HIP library
 has no CPU path); tests/test_mirrors_gpu.py repeats the comparison through libtsearch."""
 import numpy as np
 
-from callsites_common import RecordingStreamlit, StubModel, run_compare, run_evaluate
+from callsites_common import StubModel, results_from_calls, results_of, run_compare, run_evaluate
 from conftest import load_json
 from oracle import oracle
 
@@ -38,7 +38,7 @@ def test_evaluate_retrieval_prints_what_the_reference_prints(monkeypatch, capsys
     assert run_evaluate(ce, case, capsys) == case["stdout"]
 
 
-def test_search_theorems_displays_what_the_reference_displays(monkeypatch):
+def test_search_theorems_returns_the_hits_the_reference_displays(monkeypatch):
     from theoremsearch_amd import app_scratchpad
 
     class OracleIndex:                     # stands in for TheoremIndex on a host without a GPU
@@ -53,16 +53,10 @@ def test_search_theorems_displays_what_the_reference_displays(monkeypatch):
     data = case["theorems_data"]
     db = model.encode([t["text_to_embed"] for t in data])
     monkeypatch.setattr(app_scratchpad, "TheoremIndex", OracleIndex)
-    st = RecordingStreamlit()
-    app_scratchpad.search_theorems(case["query"], model, data, OracleIndex(db), st)
-    assert [c[1] for c in st.calls if c[0] == "expander"] == case["expander_titles"]
-    assert st.calls[0] == ["subheader", "Top 5 Most Similar Theorems"]
-    # everything except the LaTeX clean-up of the bodies (UI code, out of scope) is the reference's call sequence
-    ref = [c for c in case["calls"]]
-    assert [c[0] for c in st.calls] == [c[0] for c in ref]
-    st2 = RecordingStreamlit()
-    app_scratchpad.search_theorems("", model, data, OracleIndex(db), st2)
-    assert st2.calls == case["empty_query_calls"]
+    hits = app_scratchpad.search_theorems(case["query"], model, data, OracleIndex(db))
+    want = results_from_calls(case["calls"], data)          # what the reference's own function displayed (app_scratchpad.py:120-154)
+    assert len(want) == 5 and results_of(hits, data) == want
+    assert app_scratchpad.search_theorems("", model, data, OracleIndex(db)) is None     # the reference returns before searching
 
 
 def _showcase_filters(f):
@@ -73,9 +67,9 @@ def _showcase_filters(f):
     return f
 
 
-def test_search_and_display_displays_what_the_reference_displays(monkeypatch):
-    """theoremsearch_amd.app_showcase_model.search_and_display against the recorded streamlit calls of the reference's own
-    function (app_showcase_model.py:79-156, tests/golden/showcase.json) for seven sidebar states, an empty query included;
+def test_search_and_display_returns_the_hits_the_reference_displays(monkeypatch):
+    """theoremsearch_amd.app_showcase_model.search_and_display against the hits the reference's own function displayed
+    (app_showcase_model.py:79-156, recorded in tests/golden/showcase.json) for seven sidebar states, an empty query included;
     the index is stood in for by the oracle over the allowed rows (no GPU here; tests/test_mirrors_gpu.py runs libtsearch)."""
     from theoremsearch_amd import app_showcase_model
 
@@ -97,26 +91,12 @@ def test_search_and_display_displays_what_the_reference_displays(monkeypatch):
     data = case["theorems_data"]
     db = model.encode([t["text_to_embed"] for t in data])
     monkeypatch.setattr(app_showcase_model, "TheoremIndex", OracleIndex)
+    shown = 0
     for name, state in case["states"].items():
-        st = RecordingStreamlit()
-        app_showcase_model.search_and_display(case["query"], model, data, OracleIndex(db), _showcase_filters(state["filters"]), st)
-        assert st.calls == state["calls"], name
-    st = RecordingStreamlit()
-    app_showcase_model.search_and_display("", model, data, OracleIndex(db), _showcase_filters(case["states"]["open"]["filters"]), st)
-    assert st.calls == case["empty_query_calls"]
-
-
-def test_load_and_prepare_data_builds_the_references_records(tmp_path):
-    """app_scratchpad.load_and_prepare_data against the records (and warnings) of the reference's own function
-    (app_scratchpad.py:23-63, tests/golden/scratchpad_data.json): text_to_embed is what the corpus embeddings are made of."""
-    import json
-    from theoremsearch_amd import app_scratchpad
-    case = load_json("scratchpad_data.json")
-    for name, body in case["papers"].items():
-        (tmp_path / name).write_text(json.dumps(body), encoding="utf-8")
-    (tmp_path / "broken.json").write_text(case["broken"])
-    st = RecordingStreamlit()
-    got = app_scratchpad.load_and_prepare_data([str(tmp_path / n) for n in case["order"]], st)
-    assert got == case["records"]
-    assert [[c[0], c[1].replace(str(tmp_path) + "/", "<dir>/")] for c in st.calls] == case["warnings"]
-    assert app_scratchpad.load_and_prepare_data([str(tmp_path / "missing.json")]) == []        # no streamlit: skipped silently
+        hits = app_showcase_model.search_and_display(case["query"], model, data, OracleIndex(db), _showcase_filters(state["filters"]))
+        want = results_from_calls(state["calls"], data)
+        assert results_of(hits, data) == want, name
+        assert (hits is None) == (not state["filters"]["sources"]), name        # no source selected: returns before searching
+        shown += len(want)
+    assert shown >= 10
+    assert app_showcase_model.search_and_display("", model, data, OracleIndex(db), _showcase_filters(case["states"]["open"]["filters"])) is None

@@ -187,30 +187,21 @@ def test_pgvector_text_rows_parse_like_vector_in():
     assert empty.shape == (0, 3) and used == 0
 
 
-def test_showcase_loaders_mirror_the_apps(tmp_path, monkeypatch):
-    """app_showcase_model.load_model / load_embedding_library (app_showcase_model.py:32-58): the model or None with the
-    app's st.error, the library or (None, None) with the app's messages."""
+def test_showcase_loaders(tmp_path, monkeypatch):
+    """app_showcase_model.load_model / load_embedding_library (app_showcase_model.py:32-58): the model or the error that
+    stopped it (the app displays it), the library or (None, None)."""
     import pickle
     import torch
-    from callsites_common import RecordingStreamlit
     from theoremsearch_amd import app_showcase_model as asm
     monkeypatch.delenv("TS_ALLOW_RANDOM_ENCODER", raising=False)
     monkeypatch.delenv("TS_MODEL_DIR", raising=False)
-    st = RecordingStreamlit()
-    assert asm.load_model(st) is None                                   # no checkpoint offline: the app shows the error
-    assert st.calls and st.calls[0][0] == "error" and st.calls[0][1].startswith("Error loading embedding model: ")
-    st = RecordingStreamlit()
-    assert asm.load_embedding_library(str(tmp_path), st) == (None, None)
-    assert st.calls == [["error", f"Error: Embedding library not found in '{tmp_path}'."],
-                        ["info", "Please run the `app_create_embeddings.py` script first to generate the necessary files."]]
+    with pytest.raises(Exception):
+        asm.load_model()                                                # no checkpoint offline
+    assert asm.load_embedding_library(str(tmp_path)) == (None, None)
     emb = torch.arange(12, dtype=torch.float32).reshape(3, 4)
     torch.save(emb, tmp_path / "corpus_embeddings.pt")
     with open(tmp_path / "theorems_data.pkl", "wb") as f:
         pickle.dump([{"type": "theorem"}] * 3, f)
     got, data = asm.load_embedding_library(str(tmp_path))
     assert torch.equal(got, emb) and len(data) == 3
-    (tmp_path / "theorems_data.pkl").write_bytes(b"not a pickle")
-    st = RecordingStreamlit()
-    assert asm.load_embedding_library(str(tmp_path), st) == (None, None)
-    assert st.calls[0][0] == "error" and st.calls[0][1].startswith("Error loading files from the embedding library: ")
-    assert asm.ALLOWED_TYPES[0] == "theorem" and asm.EMBEDDING_LIBRARY_DIR == "./app_embeds"
+    assert asm.EMBEDDING_LIBRARY_DIR == "./app_embeds"

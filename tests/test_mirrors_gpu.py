@@ -53,12 +53,12 @@ def test_encoder_similarity_is_the_cosine_matrix(encoder):
         encoder.pipeline.similarity_fn_name = old
 
 
-def test_search_and_display_through_libtsearch_displays_what_the_reference_displays():
-    """The showcase app's search function (app_showcase_model.py:79-156) through the filtered search of libtsearch: the
-    recorded streamlit calls of the reference's own function for every sidebar state of tests/golden/showcase.json, with
-    the matrix and with an index kept across calls."""
+def test_search_and_display_through_libtsearch_returns_the_hits_the_reference_displays():
+    """The showcase app's search lines (app_showcase_model.py:92-129) through the filtered search of libtsearch: the hits the
+    reference's own function displayed for every sidebar state of tests/golden/showcase.json (rows and :.4f similarities),
+    with the matrix and with an index kept across calls."""
     import json
-    from callsites_common import RecordingStreamlit, StubModel
+    from callsites_common import StubModel, results_from_calls, results_of
     from theoremsearch_amd import TheoremIndex, app_showcase_model
     case = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "showcase.json")))
     model = StubModel(case["seed"], case["d"])
@@ -69,10 +69,9 @@ def test_search_and_display_through_libtsearch_displays_what_the_reference_displ
             f = dict(state["filters"], citation_range=tuple(state["filters"]["citation_range"]))
             if f["year_range"] is not None:
                 f["year_range"] = tuple(f["year_range"])
+            want = results_from_calls(state["calls"], data)
             for corpus in (db, ix):
-                st = RecordingStreamlit()
-                app_showcase_model.search_and_display(case["query"], model, data, corpus, f, st)
-                assert st.calls == state["calls"], name
+                assert results_of(app_showcase_model.search_and_display(case["query"], model, data, corpus, f), data) == want, name
 
 
 def test_fused_pooling_epilogue_matches_torch():
@@ -405,11 +404,11 @@ def test_view_handles_search_the_same_rows_concurrently():
 
 # ---- call-site bodies of the reference, executed by oracle/gen_golden.py -> tests/golden/callsites.json ----------------
 def test_callsite_mirrors_reproduce_the_reference_output_through_the_hip_path(capsys):
-    """compare_embeddings / evaluate_retrieval / search_theorems through libtsearch print and display exactly what the
-    reference's own function bodies did on the same model outputs (exact score ties included)."""
+    """compare_embeddings / evaluate_retrieval through libtsearch print exactly what the reference's own function bodies
+    printed on the same model outputs (exact score ties included); search_theorems returns the hits the reference displayed."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    from callsites_common import RecordingStreamlit, StubModel, run_compare, run_evaluate
+    from callsites_common import StubModel, results_from_calls, results_of, run_compare, run_evaluate
     from conftest import load_json
     from theoremsearch_amd import app_scratchpad, compare_embeddings as ce
     cases = load_json("callsites.json")["cases"]
@@ -419,14 +418,11 @@ def test_callsite_mirrors_reproduce_the_reference_output_through_the_hip_path(ca
     model = StubModel(case["seed"], case["d"])
     data = case["theorems_data"]
     db = model.encode([t["text_to_embed"] for t in data])
-    st = RecordingStreamlit()
-    app_scratchpad.search_theorems(case["query"], model, data, db, st)          # the matrix, as the app passes it
-    assert [c[1] for c in st.calls if c[0] == "expander"] == case["expander_titles"]
+    want = results_from_calls(case["calls"], data)                               # the five hits the reference displayed
+    assert results_of(app_scratchpad.search_theorems(case["query"], model, data, db), data) == want   # the matrix, as the app passes it
     import theoremsearch_amd as ts
     with ts.TheoremIndex.from_embeddings(db, metric="cos") as ix:               # or an index kept across calls
-        st2 = RecordingStreamlit()
-        app_scratchpad.search_theorems(case["query"], model, data, ix, st2)
-        assert st2.calls == st.calls
+        assert results_of(app_scratchpad.search_theorems(case["query"], model, data, ix), data) == want
 
 
 def test_encode_multi_process_replicas_on_the_gpu(encoder):
@@ -638,3 +634,29 @@ def test_bench_under_torch_distributed_run_with_two_ranks_sharing_the_gpu():
     assert doc["n_gpus"] == 2 and doc["steps"] == 3 and doc["recall_at_10"] == 1.0 and doc["parity"]["violations"] == 0
     assert doc["config"]["rows"] == 600000 and "x2" in doc["config"]["parallelism"]
     assert doc["sustained"]["steps"] == 4 and doc["roofline"]["kernel_ms"] > 0 and doc["cpu_baseline"] is None
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_is_around():
+    """`python bench.py --gpus 2` bare (no torch.distributed.run around it, WORLD_SIZE unset): the process starts the two
+    ranks as child processes itself, relays rank 0's single JSON line and its exit code; the line names what the
+    communicator saw (backend, world, one device per rank) and what one all-gather of the packed top-k costs."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--rows", "600000", "--nq", "64",
+           "--steps", "3", "--warmup", "1", "--sustained-steps", "4"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 2 and doc["steps"] == 3 and doc["recall_at_10"] == 1.0 and doc["parity"]["violations"] == 0
+    ex = doc["exchange"]
+    assert ex["world"] == 2 and ex["backend"] == "gloo" and ex["native"] is False and ex["launched_by"] == "bench.py"
+    assert ex["allgather_us"] > 0 and len(ex["devices"]) == 2 and sorted(d_[0] for d_ in ex["devices"]) == [0, 1]
+    assert ex["distinct_gpus"] == 1                      # the rehearsal: both ranks on the box's one GPU
+    # a rank that fails takes the job down with a non-zero exit code and no JSON line
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rows", "600000", "--nq", "64", "--steps", "1",
+                          "--warmup", "0"], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert bad.returncode != 0 and not bad.stdout.strip(), (bad.returncode, bad.stdout)   # rank 1 has no GPU of its own here

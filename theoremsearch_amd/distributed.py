@@ -229,7 +229,9 @@ class ShardedSearcher:
         stream, or with ``pipeline`` > 1 on the stream of the handle whose turn it is), then the exchange + merge on a
         side stream, so that they overlap the next call's search (``overlap=False``: everything on ``stream``).  Returns
         ``(scores, idx, done)``: merged global results as device tensors ``[nq x k]`` (four blocks in rotation: valid
-        until the fourth-next call) and the ``torch.cuda.Event`` that marks them complete.
+        until the fourth-next call) and the ``torch.cuda.Event`` that marks them complete.  The query buffer may be
+        rewritten by work enqueued on ``stream`` after this call returns (with ``pipeline`` > 1 the caller's stream is made
+        to wait for the lane's read of it); work on OTHER streams must wait for ``done``.
         Marker packets cost the search's stream a few microseconds each (a 1.25M-row shard's step is 0.5 ms), so the
         search's stream carries none of this class's: the side stream waits on the library's own end-of-call event
         (``ts_index_wait_order``), and the wait for the block's previous reader is skipped when that reader is known
@@ -250,6 +252,11 @@ class ShardedSearcher:
         blk, off = packed_bytes(nq, k), packed_idx_off(nq, k)
         base = b["mine"][p].data_ptr()
         ix.search_device(q_ptr, q_dtype, nq, k, base, base + off, lane.cuda_stream, algo=algo, mask_ptr=mask_ptr)
+        if own_stream:
+            # the search may read the caller's query buffer in place (queries in the index's own form): what the caller
+            # enqueues next on ITS stream - the next batch's encoder writing the same buffer - must come after that read.
+            # A wait on the handle's end-of-call event, not a marker packet on the lane.
+            _ffi.check(lib.ts_index_wait_order(ix.handle, C.c_void_p(main.cuda_stream)))
         side = self._side if overlap else main
         if overlap:
             _ffi.check(lib.ts_index_wait_order(ix.handle, C.c_void_p(side.cuda_stream)))   # behind the search just enqueued
@@ -275,6 +282,61 @@ class ShardedSearcher:
         b["done"][p].record(side)
         b["used"][p] = True
         return b["fin_s"][p], b["fin_i"][p], b["done"][p]
+
+    def measure_exchange(self, nq: int, k: int, iters: int = 50) -> dict:
+        """What the collective of `search_device` saw, and what one costs: ``iters`` back-to-back all-gathers of a packed
+        block of this shape on the side stream (after 5 untimed ones), timed with events on that stream (gloo: host clock).
+        ``world`` is the communicator's own size, ``devices`` one ``(rank, device index, PCI bus id)`` per rank gathered
+        through that same communicator - N distinct bus ids are N GPUs.  Collective: every rank must call it."""
+        import time
+        import torch
+        b = self._device_buffers(nq, k)
+        blk = packed_bytes(nq, k)
+        side = self._side
+        torch.cuda.synchronize(self.index.device)
+        us = None
+        if self.world > 1:
+            def one():
+                if self.exchange == "native":
+                    from . import _ffi
+                    _ffi.check(_ffi.load().ts_comm_allgather(self._comm, C.c_void_p(b["mine"][0].data_ptr()),
+                                                             C.c_void_p(b["all"][0].data_ptr()), blk, C.c_void_p(side.cuda_stream)))
+                elif self.backend == "nccl":
+                    with torch.cuda.stream(side):
+                        self.dist.all_gather_into_tensor(b["all"][0], b["mine"][0], group=self.group)
+                else:
+                    host = torch.empty(b["all"][0].shape, dtype=torch.uint8)
+                    self.dist.all_gather_into_tensor(host, b["mine"][0].cpu(), group=self.group)
+            for _ in range(5):
+                one()
+            side.synchronize()
+            if self.backend == "nccl" or self.exchange == "native":
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(side)
+                for _ in range(iters):
+                    one()
+                e1.record(side)
+                e1.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / iters
+            else:
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    one()
+                us = (time.perf_counter() - t0) * 1e6 / iters
+        try:
+            bus = torch.cuda.get_device_properties(self.index.device).pci_bus_id
+        except Exception:                           # noqa: BLE001 - an older torch without the field
+            bus = None
+        mine = (self.rank, int(self.index.device), bus)
+        devices = [mine]
+        if self.world > 1:
+            devices = [None] * self.world
+            self.dist.all_gather_object(devices, mine, group=self.group)
+        return {"backend": self.backend or "none", "world": int(self.dist.get_world_size(self.group)) if self.dist.is_initialized() else 1,
+                "native": self.exchange == "native", "collective": "all_gather of the packed per-shard top-k",
+                "bytes_per_rank": blk, "allgather_us": None if us is None else round(us, 2), "allgather_iters": iters if us is not None else 0,
+                "devices": [list(d_) for d_ in devices],
+                "distinct_gpus": len({(d_[1], d_[2]) for d_ in devices})}
 
     # -- host arrays in, host arrays out -----------------------------------------------------------------------------
     def search(self, queries: np.ndarray, k: int, mask: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
