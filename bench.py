@@ -612,7 +612,10 @@ def main():
         # what the index multiplied in the step that is checked: the static output of that step's graph, or a fresh forward
         g_ = enc_graphs.get(id(lanes[(step_no[0] - 1) % len(lanes)]))
         e_ = g_[1] if g_ is not None else encode_queries()
-        q_host = e_.view(torch.int16).cpu().numpy().view(np.uint16) if e_.dtype == torch.bfloat16 else oracle.f32_to_bf16_bits(e_.cpu().numpy())
+        if bf16:       # what a bf16 index multiplied: the encoder's bf16 output as it lies, or its fp32 output rounded as the library rounds it
+            q_host = e_.view(torch.int16).cpu().numpy().view(np.uint16) if e_.dtype == torch.bfloat16 else oracle.f32_to_bf16_bits(e_.float().cpu().numpy())
+        else:
+            q_host = e_.float().cpu().numpy()
     if not args.no_recall:
         qf = oracle.bf16_bits_to_f32(q_host) if bf16 else q_host
         truth = oracle.ChunkedTruth(qf, res_i, K)

@@ -26,6 +26,8 @@
  *     is ordered behind that call by the library (the handle's scratch buffers are shared); for
  *     that the library records an event at the END of every call on the stream of that call and never touches
  *     that stream again: a caller-owned stream may be destroyed as soon as the caller's own work on it is done.
+ *     A call made while its stream is being captured into a HIP graph records no such event: the caller orders replays of
+ *     that graph against other calls on the handle itself.
  *   - device queries may be read in place (no copy is made when they already have the form the kernels multiply):
  *     they must stay unchanged until the work the call enqueued has run.
  *   - one handle may be used from several threads (the Streamlit apps share one model and one
@@ -39,6 +41,10 @@
 
 #ifdef __cplusplus
 extern "C" {
+#endif
+/* the library itself is built with hidden visibility: what this header declares is what it exports */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
 #endif
 
 #define TS_VERSION 100 /* 0.1.0 */
@@ -349,6 +355,9 @@ int ts_timer_stop(ts_timer *t, void *stream);
 int ts_timer_elapsed_ms(ts_timer *t, float *ms); /* synchronises on the stop event */
 int ts_timer_destroy(ts_timer *t);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,12 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
 // ---- wave helpers ---------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
 __device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
     u32 lo = __shfl((int)(u32)v, src, 64);
     u32 hi = __shfl((int)(u32)(v >> 32), src, 64);
@@ -112,7 +118,7 @@ __device__ __forceinline__ void bitonic_sort_desc(u64* keys, int n, int tid, int
     __syncthreads();
 }
 
-// One workgroup, after a full pass (block 0 of the launch that follows it - the exact re-run's, tsearch_api.hip): the workgroups of the pass are dispatched round-robin over the 8 XCDs, and the XCDs
+// One workgroup, after a full pass (block 0 of the launch that follows it - the exact re-run's, search.hip): the workgroups of the pass are dispatched round-robin over the 8 XCDs, and the XCDs
 // of one device run it at rates a few per cent apart (per-XCD clock under the shared power budget), so with equal shares
 // the launch waits for the slowest XCD.  Shares move towards equal finishing times: share_w *= 1 + 0.7 (T / t_x(w) - 1),
 // t_x = mean time of the workgroups with w % 8 = x, T = mean of the t_x; boundaries are rounded, monotone, and keep a

@@ -1,0 +1,123 @@
+// libtsearch.so - C ABI (include/tsearch.h), part 3: the encoder-side kernels: pooling + L2
+// normalisation + cast, residual add + LayerNorm, the input layer, short-sequence attention.
+#include "host.h"
+#include "kernels_attention.h"
+#include "kernels_encoder.h"
+
+extern "C" int ts_pool_normalize(int device, const void* hidden, int h_dtype, const int64_t* attention_mask, int64_t n,
+                                 int32_t seq, int32_t d, int pooling, int normalize, void* out, int out_dtype, int64_t out_ld,
+                                 void* stream) {
+    if (!hidden || !attention_mask || !out) return fail(TS_ERR_INVALID, "NULL argument");
+    if ((h_dtype != TS_F32 && h_dtype != TS_BF16) || (out_dtype != TS_F32 && out_dtype != TS_BF16))
+        return fail(TS_ERR_INVALID, "dtype");
+    if (n < 0 || seq < 1 || d < 1 || d > 4096 || out_ld < d) return fail(TS_ERR_INVALID, "bad shape (d must be <= 4096)");
+    if (pooling < TS_POOL_MEAN || pooling > TS_POOL_CLS) return fail(TS_ERR_INVALID, "pooling %d", pooling);
+    if (n == 0) return TS_OK;
+    TS_TRY(check_device(device));
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)n);
+    // the encoders' shapes take the vector form (16-byte loads, tokens dealt over thread groups); anything else the general one
+    const int vec = h_dtype == TS_BF16 ? 8 : 4;
+    const bool vform = d % vec == 0 && d / vec <= 256 && seq <= kPoolVecSeq && ((uintptr_t)hidden & 15) == 0;
+#define TS_POOL_LAUNCH(H, O)                                                                                                  \
+    do {                                                                                                                      \
+        if (vform) pool_normalize_vec_kernel<H, O><<<grid, 256, 0, st>>>(hidden, attention_mask, seq, d, pooling, normalize, out, out_ld); \
+        else pool_normalize_kernel<H, O><<<grid, 256, 0, st>>>(hidden, attention_mask, seq, d, pooling, normalize, out, out_ld); \
+    } while (0)
+    if (h_dtype == TS_F32 && out_dtype == TS_F32) TS_POOL_LAUNCH(0, 0);
+    else if (h_dtype == TS_F32) TS_POOL_LAUNCH(0, 1);
+    else if (out_dtype == TS_F32) TS_POOL_LAUNCH(1, 0);
+    else TS_POOL_LAUNCH(1, 1);
+#undef TS_POOL_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return TS_OK;
+}
+
+extern "C" int ts_add_layernorm(int device, const void* a, const void* b, const void* gamma, const void* beta, float eps, int64_t rows,
+                                int32_t d, int dtype, void* out, void* stream) {
+    if (!a || !b || !gamma || !beta || !out) return fail(TS_ERR_INVALID, "NULL argument");
+    if (dtype != TS_F32 && dtype != TS_BF16) return fail(TS_ERR_INVALID, "dtype %d", dtype);
+    const int vec = dtype == TS_BF16 ? 8 : 4;
+    if (rows < 0 || d < vec || d % vec || d > 64 * kLnMax * vec)
+        return fail(TS_ERR_INVALID, "d = %d must be a multiple of %d and at most %d", d, vec, 64 * kLnMax * vec);
+    if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out) & 15) != 0)
+        return fail(TS_ERR_INVALID, "buffers must be 16-byte aligned");
+    if (rows == 0) return TS_OK;
+    TS_TRY(check_device(device));
+    HIP_TRY(hipSetDevice(device));
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    const int per_lane = (d / vec + 63) / 64;              // 16-byte accesses per lane
+    hipStream_t st = (hipStream_t)stream;
+#define TS_LN_LAUNCH(DT_)                                                                                        \
+    do {                                                                                                         \
+        if (per_lane <= 1) add_layernorm_kernel<DT_, 1><<<grid, 256, 0, st>>>(a, b, gamma, beta, eps, rows, d, out); \
+        else if (per_lane <= 2) add_layernorm_kernel<DT_, 2><<<grid, 256, 0, st>>>(a, b, gamma, beta, eps, rows, d, out); \
+        else add_layernorm_kernel<DT_, 4><<<grid, 256, 0, st>>>(a, b, gamma, beta, eps, rows, d, out);           \
+    } while (0)
+    if (dtype == TS_F32) TS_LN_LAUNCH(0);
+    else TS_LN_LAUNCH(1);
+#undef TS_LN_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return TS_OK;
+}
+
+extern "C" int ts_embed_layernorm(int device, const int64_t* ids, const int64_t* type_ids, const void* word, const void* pos,
+                                  const void* type, int64_t n_word, int64_t n_pos, int64_t n_type, const void* gamma, const void* beta,
+                                  float eps, int64_t tokens, int32_t seq, int32_t d, int dtype, void* out, void* stream) {
+    if (!ids || !word || !pos || !type || !gamma || !beta || !out) return fail(TS_ERR_INVALID, "NULL argument");
+    if (dtype != TS_F32 && dtype != TS_BF16) return fail(TS_ERR_INVALID, "dtype %d", dtype);
+    const int vec = dtype == TS_BF16 ? 8 : 4;
+    if (tokens < 0 || seq < 1 || d < vec || d % vec || d > 64 * kLnMax * vec)
+        return fail(TS_ERR_INVALID, "d = %d must be a multiple of %d and at most %d; seq >= 1", d, vec, 64 * kLnMax * vec);
+    if (n_word < 1 || n_pos < 1 || n_type < 1) return fail(TS_ERR_INVALID, "empty embedding table");
+    if ((((uintptr_t)word | (uintptr_t)pos | (uintptr_t)type | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out) & 15) != 0)
+        return fail(TS_ERR_INVALID, "tables and output must be 16-byte aligned");
+    if (tokens == 0) return TS_OK;
+    TS_TRY(check_device(device));
+    HIP_TRY(hipSetDevice(device));
+    const unsigned grid = (unsigned)((tokens + 3) / 4);
+    const int per_lane = (d / vec + 63) / 64;
+    hipStream_t st = (hipStream_t)stream;
+#define TS_EMB_LAUNCH(DT_, LN_)                                                                                              \
+    embed_layernorm_kernel<DT_, LN_><<<grid, 256, 0, st>>>(ids, type_ids, word, pos, type, n_word, n_pos, n_type, gamma, beta, eps, \
+                                                          tokens, seq, d, out)
+    if (dtype == TS_F32) {
+        if (per_lane <= 1) TS_EMB_LAUNCH(0, 1);
+        else if (per_lane <= 2) TS_EMB_LAUNCH(0, 2);
+        else TS_EMB_LAUNCH(0, 4);
+    } else {
+        if (per_lane <= 1) TS_EMB_LAUNCH(1, 1);
+        else if (per_lane <= 2) TS_EMB_LAUNCH(1, 2);
+        else TS_EMB_LAUNCH(1, 4);
+    }
+#undef TS_EMB_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return TS_OK;
+}
+
+extern "C" int ts_attention_short(int device, const void* qkv, const int64_t* attention_mask, int32_t batch, int32_t seq, int32_t heads,
+                                 int32_t head_dim, void* out, void* stream) {
+    if (!qkv || !out) return fail(TS_ERR_INVALID, "NULL argument");
+    if (batch < 0 || seq < 1 || heads < 1) return fail(TS_ERR_INVALID, "batch = %d, seq = %d, heads = %d", batch, seq, heads);
+    if (head_dim != 64 || seq > kAttnMaxSeq)
+        return fail(TS_ERR_UNSUPPORTED, "head size %d / %d tokens: this kernel serves head size 64 and at most %d tokens", head_dim, seq,
+                    kAttnMaxSeq);
+    if ((((uintptr_t)qkv | (uintptr_t)out) & 15) != 0) return fail(TS_ERR_INVALID, "qkv and out must be 16-byte aligned");
+    if (batch == 0) return TS_OK;
+    TS_TRY(check_device(device));
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)(((int64_t)batch * heads + 3) / 4);
+    const unsigned short* in = (const unsigned short*)qkv;
+    unsigned short* o = (unsigned short*)out;
+    switch ((seq + 15) / 16) {
+        case 1: attention_short_kernel<1><<<grid, 256, 0, st>>>(in, attention_mask, batch, seq, heads, o); break;
+        case 2: attention_short_kernel<2><<<grid, 256, 0, st>>>(in, attention_mask, batch, seq, heads, o); break;
+        case 3: attention_short_kernel<3><<<grid, 256, 0, st>>>(in, attention_mask, batch, seq, heads, o); break;
+        default: attention_short_kernel<4><<<grid, 256, 0, st>>>(in, attention_mask, batch, seq, heads, o); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return TS_OK;
+}
+

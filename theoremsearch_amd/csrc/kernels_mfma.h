@@ -22,7 +22,7 @@
 //     the epilogue is a per-lane compare against that query's threshold.  Scores that pass go to a
 //     lane-private list in global memory (plain stores, no atomics: a returning atomic would drain
 //     the DMA queue); a lane whose private list is full spills to the query's shared list.
-//     Thresholds come from the previous, sparser level (mfma_search in tsearch_api.hip).
+//     Thresholds come from the previous, sparser level (mfma_search in search_mfma.hip).
 //   * every workgroup walks its own contiguous range of tiles.
 //
 // LDS image of a unit: 24 (16) pieces of 1 KiB; piece (kb, p) = K-block kb (64 elements = 128 B per row)

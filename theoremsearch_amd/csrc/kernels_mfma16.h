@@ -45,7 +45,7 @@ constexpr int kMfma16PrivCap = 16;   // entries of a lane-private candidate list
 // (its counted waits would ask for one piece more than intended), and the final select gathers one list per query
 // instead of 4 * gridDim.x private ones.  What an appended candidate still costs is the path's own ~150 instructions on a
 // wave the other three wait for at the next barrier: ~0.3 us of one CU per candidate, whatever N - 10 % of a 1.25M-row
-// shard's pass at 160 candidates per query, which is why the threshold estimate aims at 6 k of them (tsearch_api.hip).
+// shard's pass at 160 candidates per query, which is why the threshold estimate aims at 6 k of them (search_mfma.hip).
 constexpr int kMfma16StageCap = 192;                                 // entries per wave (~40 expected at k = 10)
 constexpr int kMfma16StageBytes = 4 * kMfma16StageCap * 16 + 16;     // + one counter per wave
 

@@ -11,12 +11,6 @@
 
 namespace ts {
 
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
 // One wave per row.  SRC/DST: 0 = f32, 1 = bf16 bits.  Writes dst[row][0..ld) (zeros past d).
 // dst_f32_copy (optional): the same prepared values widened to fp32, stride ld (query buffers).
 template <int SRC, int DST, bool NORMALIZE>
@@ -55,362 +49,6 @@ __global__ void __launch_bounds__(256) prep_rows_kernel(const void* __restrict__
                 ((unsigned short*)dst)[row * ld + c] = b;
                 if (dst_f32_copy) dst_f32_copy[row * ld + c] = bf16_to_f32(b);
             }
-        }
-    }
-}
-
-// Encoder epilogue: pooling over the sequence + L2 normalisation + cast, one workgroup per sequence.
-// Columns are spread over the threads (coalesced reads of every token row); the squared norm is reduced
-// in fp64 through LDS like the index rows.
-template <int HDT, int ODT>
-__global__ void __launch_bounds__(256) pool_normalize_kernel(const void* __restrict__ hidden, const int64_t* __restrict__ mask,
-                                                              int seq, int d, int pooling, int normalize, void* __restrict__ out,
-                                                              int64_t out_ld) {
-    __shared__ double red[4];
-    __shared__ int s_count, s_last;
-    const int64_t row = blockIdx.x;
-    const int64_t* m = mask + row * seq;
-    if (threadIdx.x == 0) {
-        int cnt = 0, last = 0;
-        for (int t = 0; t < seq; ++t)
-            if (m[t] != 0) {
-                ++cnt;
-                last = t;
-            }
-        s_count = cnt;
-        s_last = last;
-    }
-    __syncthreads();
-    const int count = s_count, last = s_last;
-    constexpr int kMaxPerThread = 16;  // d <= 4096
-    float val[kMaxPerThread];
-    double ss = 0.0;
-#pragma unroll
-    for (int j = 0; j < kMaxPerThread; ++j) {
-        const int c = threadIdx.x + j * 256;
-        float v = 0.0f;
-        if (c < d) {
-            auto load = [&](int t) -> float {
-                const int64_t off = (row * seq + t) * (int64_t)d + c;
-                return (HDT == 0) ? ((const float*)hidden)[off] : bf16_to_f32(((const unsigned short*)hidden)[off]);
-            };
-            if (pooling == 0) {
-                float acc = 0.0f;
-                for (int t = 0; t < seq; ++t)
-                    if (m[t] != 0) acc += load(t);
-                v = acc / fmaxf((float)count, 1e-9f);
-            } else {
-                v = load(pooling == 1 ? last : 0);
-            }
-            ss += (double)v * (double)v;
-        }
-        val[j] = v;
-    }
-    float denom = 1.0f;
-    if (normalize) {
-        ss = wave_sum_f64(ss);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
-        __syncthreads();
-        const double total = red[0] + red[1] + red[2] + red[3];
-        denom = fmaxf((float)sqrt(total), 1e-12f);
-    }
-#pragma unroll
-    for (int j = 0; j < kMaxPerThread; ++j) {
-        const int c = threadIdx.x + j * 256;
-        if (c < d) {
-            const float v = normalize ? (float)((double)val[j] / (double)denom) : val[j];
-            if (ODT == 0) ((float*)out)[row * out_ld + c] = v;
-            else ((unsigned short*)out)[row * out_ld + c] = f32_to_bf16(v);
-        }
-    }
-}
-
-// The same epilogue for the shapes the encoders have (d a multiple of the 16-byte vector, at most 256 vectors per row; seq <=
-// kPoolVecSeq): 16-byte loads, the tokens dealt over the G = 256 / (vectors per row) thread groups so that every thread has
-// seq / G independent loads in flight, the mask counted by the whole workgroup.  The kernel above walks the tokens with one
-// 2-byte load per thread and token behind a serial scan of the mask by thread 0: 32 us for 256 x 32 x 768 bf16 (12.6 MB),
-// this one is bound by the read.  Partial sums are combined in group order (deterministic).
-constexpr int kPoolVecSeq = 1024;
-template <int HDT, int ODT>
-__global__ void __launch_bounds__(256) pool_normalize_vec_kernel(const void* __restrict__ hidden, const int64_t* __restrict__ mask,
-                                                                  int seq, int d, int pooling, int normalize, void* __restrict__ out,
-                                                                  int64_t out_ld) {
-    constexpr int VEC = HDT == 0 ? 4 : 8;
-    __shared__ float part[256 * VEC];
-    __shared__ unsigned char s_mask[kPoolVecSeq];
-    __shared__ double red[4];
-    __shared__ int s_count, s_last;
-    const int64_t row = blockIdx.x;
-    const int64_t* m = mask + row * seq;
-    if (threadIdx.x == 0) {
-        s_count = 0;
-        s_last = 0;
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < seq; t += 256) {
-        const bool on = m[t] != 0;
-        s_mask[t] = on ? 1 : 0;
-        if (on) {
-            atomicAdd(&s_count, 1);
-            atomicMax(&s_last, t);
-        }
-    }
-    __syncthreads();
-    const int count = s_count, last = s_last;
-    const int cw = d / VEC;                       // vectors per row
-    const int G = 256 / cw;                       // token groups
-    const int g = threadIdx.x / cw, c = threadIdx.x - g * cw;
-    float acc[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) acc[e] = 0.0f;
-    auto add = [&](int t) {
-        const uint4 v = *((const uint4*)((const unsigned char*)hidden + ((row * seq + t) * (int64_t)d) * (HDT == 0 ? 4 : 2)) + c);
-        if (HDT == 0) {
-            acc[0] += __uint_as_float(v.x); acc[1] += __uint_as_float(v.y); acc[2] += __uint_as_float(v.z); acc[3] += __uint_as_float(v.w);
-        } else {
-            acc[0] += bf16_lo(v.x); acc[1] += bf16_hi(v.x); acc[2] += bf16_lo(v.y); acc[3] += bf16_hi(v.y);
-            acc[4 % VEC] += bf16_lo(v.z); acc[5 % VEC] += bf16_hi(v.z); acc[6 % VEC] += bf16_lo(v.w); acc[7 % VEC] += bf16_hi(v.w);
-        }
-    };
-    if (g < G) {
-        if (pooling == 0) {
-            for (int t = g; t < seq; t += G)
-                if (s_mask[t]) add(t);
-        } else if (g == 0) {
-            add(pooling == 1 ? last : 0);
-        }
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) part[(g * cw + c) * VEC + e] = acc[e];
-    }
-    __syncthreads();
-    float val[VEC];
-    double ss = 0.0;
-    const bool owner = g == 0;                    // threads 0 .. cw - 1 own one vector of the result each
-    if (owner) {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            float v = part[c * VEC + e];
-            if (pooling == 0) {
-                for (int gg = 1; gg < G; ++gg) v += part[(gg * cw + c) * VEC + e];
-                v = v / fmaxf((float)count, 1e-9f);
-            }
-            val[e] = v;
-            ss += (double)v * (double)v;
-        }
-    }
-    float denom = 1.0f;
-    if (normalize) {
-        ss = wave_sum_f64(ss);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
-        __syncthreads();
-        const double total = red[0] + red[1] + red[2] + red[3];
-        denom = fmaxf((float)sqrt(total), 1e-12f);
-    }
-    if (owner) {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const float v = normalize ? (float)((double)val[e] / (double)denom) : val[e];
-            if (ODT == 0) ((float*)out)[row * out_ld + c * VEC + e] = v;
-            else ((unsigned short*)out)[row * out_ld + c * VEC + e] = f32_to_bf16(v);
-        }
-    }
-}
-
-// Residual add + LayerNorm of the encoder (BertSelfOutput / BertOutput: LayerNorm(dense_out + input)), one kernel
-// instead of torch's add and layer_norm launches (25 of each per BERT-base forward): out = (x - mean) * rstd * gamma + beta
-// with x = a + b taken in fp32 (torch rounds the sum to the storage type first; this keeps it in fp32), mean and variance
-// over the row in fp32 (two passes over registers: mean first, then the centred squares).  One wave per row, 8 elements
-// (bf16) or 4 (fp32) per 16-byte access; d a multiple of that, at most 64 * kLnMax accesses per row.
-// LN = 16-byte accesses per lane (1, 2 or 4, the smallest that covers the row): the BERT-base width (96 accesses per row)
-// takes 2 and a third of the registers of the 4-access form, so every row of a launch is resident at once.
-constexpr int kLnMax = 4;
-template <int DT, int LN = kLnMax>
-__global__ void __launch_bounds__(256) add_layernorm_kernel(const void* __restrict__ a, const void* __restrict__ b,
-                                                             const void* __restrict__ gamma, const void* __restrict__ beta, float eps,
-                                                             int64_t rows, int d, void* __restrict__ out) {
-    constexpr int VEC = DT == 0 ? 4 : 8;
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const int nchunk = d / VEC;
-    float x[LN][VEC];
-    auto unpack = [](const uint4& v, float* f) {
-        if (DT == 0) {
-            f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
-        } else {
-            f[0] = bf16_lo(v.x); f[1] = bf16_hi(v.x); f[2] = bf16_lo(v.y); f[3] = bf16_hi(v.y);
-            f[4] = bf16_lo(v.z); f[5] = bf16_hi(v.z); f[6] = bf16_lo(v.w); f[7] = bf16_hi(v.w);
-        }
-    };
-    const uint4* pa = (const uint4*)a + row * nchunk;
-    const uint4* pb = (const uint4*)b + row * nchunk;
-    // every load of the row - the two operands, gamma and beta - is requested before the first use: one memory round trip
-    uint4 ra[LN], rb[LN], rg[LN], re[LN];
-#pragma unroll
-    for (int j = 0; j < LN; ++j) {
-        const int c = lane + 64 * j;
-        if (c < nchunk) {
-            ra[j] = pa[c];
-            rb[j] = pb[c];
-            rg[j] = ((const uint4*)gamma)[c];
-            re[j] = ((const uint4*)beta)[c];
-        }
-    }
-    float sum = 0.0f;
-#pragma unroll
-    for (int j = 0; j < LN; ++j) {
-        const int c = lane + 64 * j;
-        if (c < nchunk) {
-            float fa[VEC], fb[VEC];
-            unpack(ra[j], fa);
-            unpack(rb[j], fb);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                x[j][e] = fa[e] + fb[e];
-                sum += x[j][e];
-            }
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-    const float mean = sum / (float)d;
-    float sq = 0.0f;
-#pragma unroll
-    for (int j = 0; j < LN; ++j) {
-        const int c = lane + 64 * j;
-        if (c < nchunk) {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const float t = x[j][e] - mean;
-                sq += t * t;
-            }
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
-    const float rstd = rsqrtf(sq / (float)d + eps);
-    uint4* po = (uint4*)out + row * nchunk;
-#pragma unroll
-    for (int j = 0; j < LN; ++j) {
-        const int c = lane + 64 * j;
-        if (c < nchunk) {
-            float g[VEC], be[VEC], y[VEC];
-            unpack(rg[j], g);
-            unpack(re[j], be);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) y[e] = (x[j][e] - mean) * rstd * g[e] + be[e];
-            uint4 o;
-            if (DT == 0) {
-                o = make_uint4(__float_as_uint(y[0]), __float_as_uint(y[1]), __float_as_uint(y[2]), __float_as_uint(y[3]));
-            } else {
-                o.x = (u32)f32_to_bf16(y[0]) | ((u32)f32_to_bf16(y[1]) << 16);
-                o.y = (u32)f32_to_bf16(y[2]) | ((u32)f32_to_bf16(y[3]) << 16);
-                o.z = (u32)f32_to_bf16(y[4]) | ((u32)f32_to_bf16(y[5]) << 16);
-                o.w = (u32)f32_to_bf16(y[6]) | ((u32)f32_to_bf16(y[7]) << 16);
-            }
-            po[c] = o;
-        }
-    }
-}
-
-// The encoder's input layer (BertEmbeddings: word + token-type + position embedding, LayerNorm) as one kernel instead of
-// three gathers, two adds and a layer_norm launch (66 us per forward of 8,192 tokens in PyTorch): one wave per token, the
-// three table rows, gamma and beta requested before the first use, the sum, the mean and the variance in fp32 (torch rounds
-// each partial sum to the storage type; this keeps them in fp32).  Token i has position i % seq.  Ids are clamped to the
-// tables (torch raises on an id outside its table; a kernel cannot).
-template <int DT, int LN>
-__global__ void __launch_bounds__(256) embed_layernorm_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ type_ids,
-                                                               const void* __restrict__ word, const void* __restrict__ pos,
-                                                               const void* __restrict__ type, int64_t n_word, int64_t n_pos,
-                                                               int64_t n_type, const void* __restrict__ gamma,
-                                                               const void* __restrict__ beta, float eps, int64_t tokens, int seq, int d,
-                                                               void* __restrict__ out) {
-    constexpr int VEC = DT == 0 ? 4 : 8;
-    const int lane = threadIdx.x & 63;
-    const int64_t tok = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (tok >= tokens) return;
-    const int nchunk = d / VEC;
-    auto unpack = [](const uint4& v, float* f) {
-        if (DT == 0) {
-            f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
-        } else {
-            f[0] = bf16_lo(v.x); f[1] = bf16_hi(v.x); f[2] = bf16_lo(v.y); f[3] = bf16_hi(v.y);
-            f[4 % VEC] = bf16_lo(v.z); f[5 % VEC] = bf16_hi(v.z); f[6 % VEC] = bf16_lo(v.w); f[7 % VEC] = bf16_hi(v.w);
-        }
-    };
-    const int64_t wid = min(max(ids[tok], (int64_t)0), n_word - 1);
-    const int64_t tid = type_ids ? min(max(type_ids[tok], (int64_t)0), n_type - 1) : 0;
-    const int64_t pid = min(tok % seq, n_pos - 1);
-    const uint4* pw = (const uint4*)word + wid * nchunk;
-    const uint4* pt = (const uint4*)type + tid * nchunk;
-    const uint4* pp = (const uint4*)pos + pid * nchunk;
-    uint4 rw[LN], rt[LN], rp[LN], rg[LN], re[LN];
-#pragma unroll
-    for (int j = 0; j < LN; ++j) {
-        const int c = lane + 64 * j;
-        if (c < nchunk) {
-            rw[j] = pw[c];
-            rt[j] = pt[c];
-            rp[j] = pp[c];
-            rg[j] = ((const uint4*)gamma)[c];
-            re[j] = ((const uint4*)beta)[c];
-        }
-    }
-    float x[LN][VEC];
-    float sum = 0.0f;
-#pragma unroll
-    for (int j = 0; j < LN; ++j) {
-        const int c = lane + 64 * j;
-        if (c < nchunk) {
-            float fw[VEC], ft[VEC], fp[VEC];
-            unpack(rw[j], fw);
-            unpack(rt[j], ft);
-            unpack(rp[j], fp);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                x[j][e] = (fw[e] + ft[e]) + fp[e];          // BertEmbeddings' order: inputs + token type, then + position
-                sum += x[j][e];
-            }
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-    const float mean = sum / (float)d;
-    float sq = 0.0f;
-#pragma unroll
-    for (int j = 0; j < LN; ++j) {
-        const int c = lane + 64 * j;
-        if (c < nchunk) {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const float t = x[j][e] - mean;
-                sq += t * t;
-            }
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
-    const float rstd = rsqrtf(sq / (float)d + eps);
-    uint4* po = (uint4*)out + tok * nchunk;
-#pragma unroll
-    for (int j = 0; j < LN; ++j) {
-        const int c = lane + 64 * j;
-        if (c < nchunk) {
-            float g[VEC], be[VEC], y[VEC];
-            unpack(rg[j], g);
-            unpack(re[j], be);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) y[e] = (x[j][e] - mean) * rstd * g[e] + be[e];
-            uint4 o;
-            if (DT == 0) {
-                o = make_uint4(__float_as_uint(y[0]), __float_as_uint(y[1]), __float_as_uint(y[2]), __float_as_uint(y[3]));
-            } else {
-                o.x = (u32)f32_to_bf16(y[0]) | ((u32)f32_to_bf16(y[1]) << 16);
-                o.y = (u32)f32_to_bf16(y[2]) | ((u32)f32_to_bf16(y[3]) << 16);
-                o.z = (u32)f32_to_bf16(y[4 % VEC]) | ((u32)f32_to_bf16(y[5 % VEC]) << 16);
-                o.w = (u32)f32_to_bf16(y[6 % VEC]) | ((u32)f32_to_bf16(y[7 % VEC]) << 16);
-            }
-            po[c] = o;
         }
     }
 }

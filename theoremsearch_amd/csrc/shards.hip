@@ -1,3 +1,73 @@
+// libtsearch.so - C ABI (include/tsearch.h), part 4: merging partial top-k lists and the row-sharded search over RCCL.
+#include "host.h"
+#include "kernels_select.h"
+
+extern "C" int ts_merge_topk(int device, const float* scores, const int64_t* idx, int32_t nparts, int32_t nq, int32_t k_in,
+                             int32_t k_out, float* out_scores, int64_t* out_idx, int on_device, void* stream) {
+    if (!scores || !idx || !out_scores || !out_idx) return fail(TS_ERR_INVALID, "NULL argument");
+    if (nparts < 1 || nq < 0 || k_in < 1 || k_out < 1 || k_out > TS_MAX_K)
+        return fail(TS_ERR_INVALID, "bad merge shape");
+    if ((int64_t)nparts * k_in > kMergeMax)
+        return fail(TS_ERR_UNSUPPORTED, "nparts * k_in = %lld exceeds %d", (long long)nparts * k_in, kMergeMax);
+    if (nq == 0) return TS_OK;
+    TS_TRY(check_device(device));
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    MergeArgs a;
+    a.nparts = nparts; a.nq = nq; a.k_in = k_in; a.k_out = k_out;
+    a.part_stride = a.part_stride_idx = (int64_t)nq * k_in;
+    const size_t nin = (size_t)nparts * nq * k_in, nout = (size_t)nq * k_out;
+    if (on_device) {
+        a.scores = scores; a.idx = idx; a.out_scores = out_scores; a.out_idx = out_idx;
+        launch_merge(a, st);
+        HIP_TRY(hipGetLastError());
+        return TS_OK;
+    }
+    // one temporary block (freed on every return path): ids in | ids out | scores in | scores out
+    DevBuf tmp;
+    HIP_TRY(tmp.alloc(nin * 12 + nout * 12));
+    int64_t* di = tmp.as<int64_t>();
+    int64_t* doi = di + nin;
+    float* ds = (float*)(doi + nout);
+    float* dos = ds + nin;
+    HIP_TRY(hipMemcpyAsync(ds, scores, nin * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(di, idx, nin * 8, hipMemcpyHostToDevice, st));
+    a.scores = ds; a.idx = di; a.out_scores = dos; a.out_idx = doi;
+    launch_merge(a, st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_scores, dos, nout * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out_idx, doi, nout * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return TS_OK;
+}
+
+extern "C" int ts_merge_topk_packed(int device, const void* packed, int64_t part_stride_bytes, int64_t idx_offset_bytes,
+                                    int32_t nparts, int32_t nq, int32_t k_in, int32_t k_out, float* out_scores,
+                                    int64_t* out_idx, void* stream) {
+    if (!packed || !out_scores || !out_idx) return fail(TS_ERR_INVALID, "NULL argument");
+    if (nparts < 1 || nq < 0 || k_in < 1 || k_out < 1 || k_out > TS_MAX_K) return fail(TS_ERR_INVALID, "bad merge shape");
+    if ((int64_t)nparts * k_in > kMergeMax)
+        return fail(TS_ERR_UNSUPPORTED, "nparts * k_in = %lld exceeds %d", (long long)nparts * k_in, kMergeMax);
+    if (part_stride_bytes % 8 || idx_offset_bytes % 8 || idx_offset_bytes < (int64_t)nq * k_in * 4 ||
+        part_stride_bytes < idx_offset_bytes + (int64_t)nq * k_in * 8)
+        return fail(TS_ERR_INVALID, "bad packed layout (stride %lld, idx offset %lld)", (long long)part_stride_bytes,
+                    (long long)idx_offset_bytes);
+    if (nq == 0) return TS_OK;
+    TS_TRY(check_device(device));
+    HIP_TRY(hipSetDevice(device));
+    MergeArgs a;
+    a.nparts = nparts; a.nq = nq; a.k_in = k_in; a.k_out = k_out;
+    a.scores = (const float*)packed;
+    a.idx = (const int64_t*)((const char*)packed + idx_offset_bytes);
+    a.part_stride = part_stride_bytes / 4;
+    a.part_stride_idx = part_stride_bytes / 8;
+    a.out_scores = out_scores;
+    a.out_idx = out_idx;
+    launch_merge(a, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return TS_OK;
+}
+
 // Row-sharded search behind the C ABI (SURVEY.md section 8b "ts_shards_*", section 8e): the exchange of the per-shard
 // top-k runs over RCCL inside this library, so the search path needs neither torch.distributed nor MPI.
 //
@@ -6,7 +76,7 @@
 //   ts_shards_*  one PROCESS driving all the GPUs of the node (ncclCommInitAll, one stream per device) - what a serving
 //                process (the Streamlit app) would hold.
 //
-// Included at the end of tsearch_api.hip (it uses ts_index and the merge kernel).  RCCL is bound with dlopen at the
+// RCCL is bound with dlopen at the
 // first use: libtsearch.so itself has no link-time dependency on it, and a process that already carries a copy of RCCL
 // (PyTorch-ROCm bundles one) reuses that copy instead of loading a second one.
 #include <dlfcn.h>

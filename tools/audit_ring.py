@@ -9,7 +9,7 @@ order (LDS returns in order; `lgkmcnt(N)` retires all but the youngest N), and r
 vector register an outstanding ds_read_b128 is still to write.  The walk is linear in the text and runs twice, so that
 what a loop leaves in flight at its end is seen by its head.
 
-    python tools/audit_ring.py theoremsearch_amd/csrc/build/tsearch_api-hip-amdgcn-amd-amdhsa-gfx950.s
+    python tools/audit_ring.py theoremsearch_amd/csrc/build/asm/launch_mfma16-hip-amdgcn-amd-amdhsa-gfx950.s
 """
 import re
 import sys
