@@ -38,6 +38,9 @@ WORKLOADS = {
     "c3": (10_000_000, "bf16", 256),
     "c4": (50_000_000, "bf16", 256),
     "c5": (10_000_000, "bf16", 256),   # encoder-in-loop: sentence-encoder forward feeds the C3 index
+    # the production table of the reference: theorem_embedding_qwen, vector(1024) (streamlit_app.py:49,55, rds_schema.sql:50-56);
+    # not a BASELINE.json config - the same batch-256 search at d = 1024 (--dim defaults to 1024 here)
+    "c3q": (10_000_000, "bf16", 256),
 }
 D = 768   # overridden by --dim (diagnostic: the production table of the reference is vector(1024), rds_schema.sql:50)
 K = 10
@@ -49,6 +52,111 @@ MFMA_RANDOM_DATA_GEMM_TFLOPS = 1247.0   # MI355X_MICROARCH.md "DVFS give-back" i
 def log(rank, *a):
     if rank == 0:
         print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+class PowerSampler:
+    """Package power and shader clock of one GPU, sampled from a side thread while a leg runs (the sustained leg, never the
+    contract's timed K steps): the amdgpu hwmon files of the device (`power1_average` / `power1_input` in microwatts,
+    `power1_cap`, `freq1_input` in Hz) every 50 ms, or - where the files cannot be read - `rocm-smi --showpower
+    --showclocks --json` as often as it answers.  No GPU call, no effect on the stream being timed.
+    Evidence for DESIGN.md section 3.2: the full pass of configs[2] holds the package at its power limit while the shader
+    clock sits well below its maximum."""
+
+    def __init__(self, pci_bus_id=None, device_index=0):
+        import glob
+        self.device_index = device_index
+        self.samples = []          # (t, watts, sclk_mhz)
+        self.cap_w = None
+        self.source = None
+        self._stop = False
+        self._thread = None
+        self._hw = None
+        cands = []
+        if pci_bus_id:
+            cands += glob.glob(f"/sys/bus/pci/devices/{pci_bus_id.lower()}/hwmon/hwmon*")
+        if not cands:
+            cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
+            if len(cards) == 1 or (cards and not pci_bus_id):
+                cands = cards[device_index:device_index + 1] or cards[:1]
+        for hw in cands:
+            for name in ("power1_average", "power1_input"):
+                if os.access(os.path.join(hw, name), os.R_OK):
+                    self._hw, self._pfile = hw, os.path.join(hw, name)
+                    self.source = f"hwmon {name}"
+                    break
+            if self._hw:
+                break
+        if self._hw:
+            try:
+                self.cap_w = int(open(os.path.join(self._hw, "power1_cap")).read()) / 1e6
+            except (OSError, ValueError):
+                self.cap_w = None
+
+    def _read_hwmon(self):
+        w = int(open(self._pfile).read()) / 1e6
+        try:
+            mhz = int(open(os.path.join(self._hw, "freq1_input")).read()) / 1e6
+        except (OSError, ValueError):
+            mhz = None
+        return w, mhz
+
+    def _read_smi(self):
+        import subprocess
+        out = subprocess.run(["rocm-smi", "-d", str(self.device_index), "--showpower", "--showclocks", "--showmaxpower", "--json"],
+                             capture_output=True, text=True, timeout=10).stdout
+        card = next(iter(json.loads(out).values()))
+        w = mhz = None
+        for k_, v in card.items():
+            kl = k_.lower()
+            try:
+                if "power" in kl and "max" in kl:
+                    self.cap_w = float(v)
+                elif "power" in kl and "(w)" in kl:
+                    w = float(v)
+                elif kl.startswith("sclk clock speed"):
+                    mhz = float(str(v).strip("()").lower().replace("mhz", ""))
+            except ValueError:
+                pass
+        if w is None:
+            raise RuntimeError("rocm-smi reported no power")
+        return w, mhz
+
+    def _run(self):
+        read = self._read_hwmon if self._hw else self._read_smi
+        if not self._hw:
+            self.source = "rocm-smi --showpower --showclocks"
+        while not self._stop:
+            try:
+                w, mhz = read()
+                self.samples.append((time.time(), w, mhz))
+            except Exception:                      # noqa: BLE001 - a sampler that cannot read stops quietly
+                if not self.samples:
+                    self.source = None
+                return
+            time.sleep(0.05)
+
+    def __enter__(self):
+        import threading
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        self._thread.join(timeout=15)
+        return False
+
+    def summary(self, t0, t1):
+        """Mean over the samples taken inside [t0 + 20 %, t1] (the clock needs a moment to settle under load)."""
+        lo = t0 + 0.2 * (t1 - t0)
+        inside = [s_ for s_ in self.samples if lo <= s_[0] <= t1]
+        if not inside:
+            return None
+        ws = [s_[1] for s_ in inside]
+        fs = [s_[2] for s_ in inside if s_[2]]
+        return {"avg_w": round(sum(ws) / len(ws), 1), "max_w": round(max(ws), 1), "cap_w": self.cap_w,
+                "sclk_mhz": round(sum(fs) / len(fs), 0) if fs else None, "samples": len(inside), "source": self.source,
+                "during": "the sustained leg (back-to-back steps behind the timed region)"}
 
 
 def launch_ranks(n, share_gpu):
@@ -219,8 +327,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--gen-threads", type=int, default=0)
-    ap.add_argument("--dim", type=int, default=768, help="embedding dimension (diagnostic; BASELINE configs use 768)")
+    ap.add_argument("--dim", type=int, default=0, help="embedding dimension (default 768, the BASELINE configs'; c3q: 1024)")
     ap.add_argument("--seq-len", type=int, default=32, help="c5: tokens per synthetic query")
+    ap.add_argument("--encoder", default="bert", choices=["bert", "qwen"],
+                    help="c5: random-init stand-in of math-similarity/Bert-MLM_arXiv-MP-class_zbMath (BERT-base shape, 768-d: the "
+                         "BASELINE config) or of Qwen/Qwen3-Embedding-0.6B (the production embedder, streamlit_app.py:55: 28 layers, "
+                         "1024-d, grouped-query attention, last-token pooling; the index is then 10M x 1024)")
     ap.add_argument("--force-dist", action="store_true", help="debug: run the exchange + merge path even with one rank")
     ap.add_argument("--exchange", default="auto", choices=["auto", "native", "torch"],
                     help="N > 1: collective of the per-shard top-k: native = ncclAllGather inside libtsearch (ts_comm_*), "
@@ -255,7 +367,7 @@ def main():
     ap.add_argument("--zero-corpus", action="store_true", help="diagnostic: all-zero corpus (power probe)")
     args = ap.parse_args()
     global D
-    D = args.dim
+    D = args.dim or (1024 if (args.workload == "c3q" or (args.workload == "c5" and args.encoder == "qwen")) else 768)
     if args.workload != "c1" and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher around this process: start the ranks as child processes (before torch is imported or HIP touched)
         return launch_ranks(args.gpus, args.share_gpu)
@@ -370,7 +482,11 @@ def main():
             tunable.set_max_tuning_duration(30)
             tunable.set_max_tuning_iterations(20)
             tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"ts_tunableop_rank{rank}.csv"))
-        encoder = SentenceEncoder(allow_random_init=True)
+        enc_name = "Qwen/Qwen3-Embedding-0.6B" if args.encoder == "qwen" else "math-similarity/Bert-MLM_arXiv-MP-class_zbMath"
+        encoder = SentenceEncoder(enc_name, allow_random_init=True)
+        if encoder.embedding_dim != D:
+            raise SystemExit(f"the {args.encoder} encoder embeds into {encoder.embedding_dim} dimensions, the index has {D}")
+        log(rank, f"encoder: {type(encoder.model).__name__} ({enc_name}, random init), fused forward: {type(encoder._fused).__name__}")
         g = torch.Generator(device="cpu").manual_seed(5678)
         tok_ids = torch.randint(1000, 30000, (nq, args.seq_len), generator=g).cuda()
         tok_ids[:, 0], tok_ids[:, -1] = 101, 102
@@ -483,18 +599,33 @@ def main():
 
     # ---- sustained: the same step, `--sustained-steps` more of them back to back (the timed region above is the
     # contract's K steps - 63 ms at the default; a second of back-to-back passes lets the clock settle) -----------------
-    sustained = None
+    sustained, power = None, None
     sustained_steps = args.sustained_steps if (args.sustained_steps > 0 or bracket_timed) else max(20, args.steps)
     if sustained_steps > 0 and args.workload != "c1":
         barrier()
         for h in prof_handles:
             h.profile_enable(True)
+        try:
+            props = torch.cuda.get_device_properties(local_rank)
+            bus = f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
+        except Exception:                          # noqa: BLE001
+            bus = None
+        sampler = PowerSampler(bus, local_rank) if rank == 0 else None
+        tw0 = time.time()
         t1 = time.perf_counter()
-        for _ in range(sustained_steps):
-            step()
-        torch.cuda.synchronize()
+        if sampler is not None:
+            with sampler:
+                for _ in range(sustained_steps):
+                    step()
+                torch.cuda.synchronize()
+        else:
+            for _ in range(sustained_steps):
+                step()
+            torch.cuda.synchronize()
+        tw1 = time.time()
         barrier()
         dt_s = time.perf_counter() - t1
+        power = sampler.summary(tw0, tw1) if sampler is not None else None
         sp = {"launches": 0, "total_ms": 0.0, "rows_per_launch": 0}
         for h in prof_handles:
             p_ = h.profile_read()
@@ -553,10 +684,9 @@ def main():
                                                   "this command (tools/run_profiles.sh), not an observation of this run"}
         except Exception:
             traffic = None
-    kernel_name = {"mfma": "mfma16_topk_kernel" if (D == 768 or not bf16) else "mfma_topk_kernel",
-                   "scan": "scan_kernel"}.get(stats_algo or ("scan" if mask_ptr and nq <= 4 else None), "unknown")
+    kernel_name = {"mfma": "mfma16_topk_kernel", "scan": "scan_kernel"}.get(stats_algo or ("scan" if mask_ptr and nq <= 4 else None), "unknown")
     if stats_algo is None and encoder is not None:
-        kernel_name = "mfma16_topk_kernel" if D == 768 else "mfma_topk_kernel"
+        kernel_name = "mfma16_topk_kernel"
     # ---- the ceiling of this pass on THIS device, measured on the resident corpus right here (tools/microbench/
     # mfma_stream_ceiling.hip: the product's tile loop without epilogue / candidates, its DMA stream alone, its matrix work
     # alone, and the same MFMA count with operands in registers = the random-data matrix rate under this device's power cap)
@@ -591,6 +721,7 @@ def main():
                 "mfma_frac_of_measured_gemm_rate": (round(tflops / ceiling["measured_gemm_tflops"], 4) if ceiling else None),
                 "mfma_frac_of_guide_gemm_rate": round(tflops / MFMA_RANDOM_DATA_GEMM_TFLOPS, 4) if bf16 else None,
                 "ceiling": ceiling,
+                "power": power,
                 "traffic": traffic,
                 "kernel_ms": round(kern_ms, 4), "launches_per_step": launches_per_step,
                 "kernel_ms_from": "hipEvent brackets over the timed region" if bracket_timed else
@@ -689,12 +820,13 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "queries/sec, brute-force top-10 over N x 768 theorem embeddings",
+            "metric": f"queries/sec, brute-force top-10 over N x {D} theorem embeddings",
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"{rows_total}x{D} {dtype} corpus, batch-{nq} queries, top-{K} "
-                                   f"(BASELINE.json configs[{ {'c1': 0, 'c2': 1, 'c2b': 1, 'c3': 2, 'c4': 3, 'c5': 4}[args.workload] }])" + (f", encoder forward in the loop ({args.seq_len} tokens/query, random-init BERT-base shape)" if encoder is not None else ""),
+                                   + (f"(BASELINE.json configs[{ {'c1': 0, 'c2': 1, 'c2b': 1, 'c3': 2, 'c4': 3, 'c5': 4}[args.workload] }])" if args.workload != "c3q" else
+                                      "(the reference's production table shape, theorem_embedding_qwen vector(1024): streamlit_app.py:49, rds_schema.sql:50-56; not a BASELINE.json config)") + (f", encoder forward in the loop ({args.seq_len} tokens/query, random-init " + ("Qwen3-Embedding-0.6B shape: the production embedder, streamlit_app.py:55)" if args.encoder == "qwen" else "BERT-base shape)") if encoder is not None else ""),
                        "rows": rows_total, "dim": D, "batch": nq, "k": K, "searches_in_flight": P,
                        **({"mask_frac": args.mask_frac} if args.mask_frac > 0 else {}),
                        "parallelism": f"corpus row-sharded x{world}" + ((", gloo rehearsal on one GPU" if args.share_gpu else (", ncclAllGather of per-shard top-k inside libtsearch (ts_comm)" if searcher.exchange == "native" else ", torch.distributed all-gather of per-shard top-k (RCCL)")) if use_dist else "")},

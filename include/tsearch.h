@@ -333,6 +333,27 @@ int ts_embed_layernorm(int device, const int64_t *ids, const int64_t *type_ids, 
 int ts_attention_short(int device, const void *qkv, const int64_t *attention_mask, int32_t batch, int32_t seq, int32_t heads,
                       int32_t head_dim, void *out, void *stream);
 
+/* The decoder-style encoder the production app embeds with (Qwen/Qwen3-Embedding-0.6B, streamlit_app.py:55;
+ * ec2/generate_embeddings/embedders.py:1-4): RMSNorm, rotary positions, grouped-query attention, gated MLP.  Three kernels for
+ * what its layers do around the GEMMs; each follows the roundings of the torch modules it replaces.
+ *
+ * ts_add_rmsnorm: s = a + b (rounded to `dtype`; b may be NULL: s = a), out_norm = gamma * round(s * rsqrt(mean(s^2) + eps))
+ * over rows of d elements (Qwen3DecoderLayer's residual add followed by the next Qwen3RMSNorm); out_sum (may be NULL) receives
+ * s, the new residual.  d as for ts_add_layernorm; buffers 16-byte aligned; out_sum may alias a or b. */
+int ts_add_rmsnorm(int device, const void *a, const void *b, const void *gamma, float eps, int64_t rows, int32_t d, int dtype,
+                   void *out_sum, void *out_norm, void *stream);
+/* Per-head RMSNorm of queries and keys + rotary position embedding, in place on the fused projection's output
+ * (Qwen3Attention: q_norm / k_norm over the head, apply_rotary_pos_emb).  qkv: device [tokens][(q_heads + 2 kv_heads) * 128]
+ * (query heads, key heads, value heads; values untouched); q_weight, k_weight: device [128]; cos_table, sin_table: device
+ * [seq][128] of `dtype` (fp32 angles cast to the model's type, as Qwen3RotaryEmbedding does); token t has position t % seq.
+ * head_dim must be 128 (TS_ERR_UNSUPPORTED otherwise). */
+int ts_qk_norm_rope(int device, void *qkv, const void *q_weight, const void *k_weight, const void *cos_table, const void *sin_table,
+                    float eps, int64_t tokens, int32_t seq, int32_t q_heads, int32_t kv_heads, int32_t head_dim, int dtype,
+                    void *stream);
+/* Gated-MLP activation (Qwen3MLP: SiLU(gate_proj(x)) * up_proj(x)) on the output of ONE GEMM over the stacked gate / up
+ * weights: gate_up device [rows][2 * inter] (gate columns, then up columns) -> out device [rows][inter]. */
+int ts_swiglu(int device, const void *gate_up, int64_t rows, int32_t inter, int dtype, void *out, void *stream);
+
 /* ---- kernel timing inside the library ----------------------------------------------------------
  * With profiling enabled, every launch of the dominant kernel of a search (the full-corpus pass of
  * the MFMA path, or the scan kernel) is bracketed by a hipEvent pair on the stream it runs on.

@@ -189,3 +189,20 @@ def test_encode_multi_process_notices_a_dead_replica(tmp_path):
         assert not any(p.is_alive() for p, _, _ in pool["workers"])
     finally:
         enc.stop_multi_process_pool(pool)
+
+
+def test_the_qwen3_stand_in_is_a_qwen3_shaped_model():
+    """allow_random_init for the production embedder's name (streamlit_app.py:55) builds a Qwen3Model of the published shape
+    (1024 wide, 16 query / 8 key-value heads of 128, gated MLP 3072, RMSNorm, rotary positions) with last-token pooling -
+    not a BERT of that width; its forward on CPU is the model's own (the fused one needs the HIP kernels)."""
+    enc = SentenceEncoder("Qwen/Qwen3-Embedding-0.6B", allow_random_init=True, num_layers=2, device="cpu")
+    cfg = enc.model.config
+    assert type(enc.model).__name__ == "Qwen3Model" and enc._fused is None
+    assert (cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.intermediate_size) == (1024, 16, 8, 128, 3072)
+    assert enc.pooling == "lasttoken" and enc.embedding_dim == 1024
+    texts = ["a tree on n vertices has n - 1 edges", "x", "every bounded monotone sequence converges"]
+    a = enc.encode(texts, normalize_embeddings=True)
+    assert a.shape == (3, 1024) and np.allclose((a * a).sum(1), 1.0, atol=1e-5)
+    # causal + right padding: a sentence's embedding does not depend on what it is batched with
+    b = enc.encode(texts[1:2], normalize_embeddings=True)
+    assert np.allclose(a[1], b[0], atol=1e-5)

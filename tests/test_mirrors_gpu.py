@@ -660,3 +660,144 @@ def test_bench_starts_its_own_ranks_when_no_launcher_is_around():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rows", "600000", "--nq", "64", "--steps", "1",
                           "--warmup", "0"], capture_output=True, text=True, timeout=300, cwd=root, env=env)
     assert bad.returncode != 0 and not bad.stdout.strip(), (bad.returncode, bad.stdout)   # rank 1 has no GPU of its own here
+
+
+# ---- the decoder-style encoder of the production app (Qwen3-Embedding shape): kernels around its GEMMs --------------------
+def test_add_rmsnorm_kernel_matches_the_module_chain():
+    """ts_add_rmsnorm against Qwen3DecoderLayer's own chain on the same inputs - `residual + x` rounded to the storage type,
+    Qwen3RMSNorm (fp32 inside, rounded, times the weight) - bit for bit in bf16 and to fp32 noise in fp32; against fp64; without
+    the addend (a plain norm) and in place over the residual."""
+    import ctypes as C
+    import torch
+    from transformers.models.qwen3.modeling_qwen3 import Qwen3RMSNorm
+    from theoremsearch_amd import _ffi
+    lib = _ffi.load()
+    g = torch.Generator(device="cpu").manual_seed(14)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for dtype, code, tol in ((torch.bfloat16, 1, 2e-2), (torch.float32, 0, 2e-5)):
+        for d in (1024, 768, 2048 if dtype == torch.bfloat16 else 512):
+            rows = 777
+            a = (torch.randn((rows, d), generator=g) * 1.7).to(dtype).cuda()
+            b = torch.randn((rows, d), generator=g).to(dtype).cuda()
+            norm = Qwen3RMSNorm(d, eps=1e-6).to("cuda", dtype=dtype)
+            with torch.no_grad():
+                norm.weight.copy_((1.0 + 0.2 * torch.randn(d, generator=g)).to(dtype))
+                want_sum = a + b
+                want = norm(want_sum)
+                plain = norm(a)
+            out_sum, out = torch.empty_like(a), torch.empty_like(a)
+            _ffi.check(lib.ts_add_rmsnorm(0, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(norm.weight.data_ptr()), 1e-6,
+                                          rows, d, code, C.c_void_p(out_sum.data_ptr()), C.c_void_p(out.data_ptr()), st))
+            out_plain = torch.empty_like(a)
+            _ffi.check(lib.ts_add_rmsnorm(0, C.c_void_p(a.data_ptr()), None, C.c_void_p(norm.weight.data_ptr()), 1e-6, rows, d, code, None,
+                                          C.c_void_p(out_plain.data_ptr()), st))
+            torch.cuda.synchronize()
+            assert torch.equal(out_sum, want_sum), (dtype, d)
+            if dtype == torch.bfloat16:      # the module's roundings, followed step by step: at most one bf16 ulp where an fp32 sum differs
+                assert (out.float() - want.float()).abs().max().item() <= 2 ** -6 * want.float().abs().max().item()
+                assert (out != want).float().mean().item() < 1e-3 and (out_plain != plain).float().mean().item() < 1e-3
+            else:
+                assert torch.allclose(out, want, atol=1e-5, rtol=1e-5) and torch.allclose(out_plain, plain, atol=1e-5, rtol=1e-5)
+            s64 = want_sum.double()
+            ref = s64 * torch.rsqrt((s64 * s64).mean(-1, keepdim=True) + 1e-6) * norm.weight.double()
+            assert torch.allclose(out.double(), ref, atol=tol, rtol=tol)
+            _ffi.check(lib.ts_add_rmsnorm(0, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(norm.weight.data_ptr()), 1e-6,
+                                          rows, d, code, C.c_void_p(a.data_ptr()), C.c_void_p(out_plain.data_ptr()), st))   # residual in place
+            torch.cuda.synchronize()
+            assert torch.equal(a, want_sum) and torch.equal(out_plain, out)
+    with pytest.raises(_ffi.TSearchError):
+        _ffi.check(lib.ts_add_rmsnorm(0, C.c_void_p(a.data_ptr()), None, C.c_void_p(norm.weight.data_ptr()), 1e-6, 4, 10, 1, None,
+                                      C.c_void_p(out.data_ptr()), None))
+
+
+def test_qk_norm_rope_and_swiglu_kernels_match_the_modules():
+    """ts_qk_norm_rope against Qwen3Attention's own q_norm / k_norm + apply_rotary_pos_emb (values untouched), ts_swiglu
+    against Qwen3MLP's act_fn(gate) * up, on the same tensors."""
+    import ctypes as C
+    import torch
+    from transformers.models.qwen3.modeling_qwen3 import Qwen3RMSNorm, apply_rotary_pos_emb
+    from theoremsearch_amd import _ffi
+    lib = _ffi.load()
+    g = torch.Generator(device="cpu").manual_seed(15)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    B, S, hq, hkv, hd = 5, 37, 16, 8, 128
+    for dtype, code in ((torch.bfloat16, 1), (torch.float32, 0)):
+        qkv = (torch.randn((B, S, (hq + 2 * hkv) * hd), generator=g) * 1.3).to(dtype).cuda()
+        qn, kn = Qwen3RMSNorm(hd, eps=1e-6).to("cuda", dtype=dtype), Qwen3RMSNorm(hd, eps=1e-6).to("cuda", dtype=dtype)
+        with torch.no_grad():
+            qn.weight.copy_((1.0 + 0.3 * torch.randn(hd, generator=g)).to(dtype))
+            kn.weight.copy_((1.0 + 0.3 * torch.randn(hd, generator=g)).to(dtype))
+        inv = 1.0 / (1e6 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+        ang = torch.arange(S, dtype=torch.float32)[:, None] * inv[None, :]
+        emb = torch.cat((ang, ang), dim=-1)
+        cos, sin = emb.cos().to(dtype).cuda(), emb.sin().to(dtype).cuda()           # [S x 128], cast as Qwen3RotaryEmbedding does
+        with torch.no_grad():
+            q = qn(qkv[..., :hq * hd].view(B, S, hq, hd)).transpose(1, 2)
+            k = kn(qkv[..., hq * hd:(hq + hkv) * hd].view(B, S, hkv, hd)).transpose(1, 2)
+            wq, wk = apply_rotary_pos_emb(q, k, cos[None], sin[None])
+        got = qkv.clone()
+        _ffi.check(lib.ts_qk_norm_rope(0, C.c_void_p(got.data_ptr()), C.c_void_p(qn.weight.data_ptr()), C.c_void_p(kn.weight.data_ptr()),
+                                       C.c_void_p(cos.data_ptr()), C.c_void_p(sin.data_ptr()), 1e-6, B * S, S, hq, hkv, hd, code, st))
+        torch.cuda.synchronize()
+        gq = got[..., :hq * hd].view(B, S, hq, hd).transpose(1, 2)
+        gk = got[..., hq * hd:(hq + hkv) * hd].view(B, S, hkv, hd).transpose(1, 2)
+        assert torch.equal(got[..., (hq + hkv) * hd:], qkv[..., (hq + hkv) * hd:])                 # the values
+        tol = 2 ** -6 if dtype == torch.bfloat16 else 1e-5
+        for have, want in ((gq, wq), (gk, wk)):
+            assert (have.float() - want.float()).abs().max().item() <= tol * max(1.0, want.float().abs().max().item())
+            if dtype == torch.bfloat16:
+                assert (have != want).float().mean().item() < 2e-3                                   # the same roundings, step by step
+        with pytest.raises(_ffi.TSearchError) as e:
+            _ffi.check(lib.ts_qk_norm_rope(0, C.c_void_p(got.data_ptr()), C.c_void_p(qn.weight.data_ptr()), C.c_void_p(kn.weight.data_ptr()),
+                                           C.c_void_p(cos.data_ptr()), C.c_void_p(sin.data_ptr()), 1e-6, B * S, S, hq, hkv, 64, code, st))
+        assert e.value.code == -5
+        rows, inter = 1001, 3072
+        gu = (torch.randn((rows, 2 * inter), generator=g) * 2.0).to(dtype).cuda()
+        want = torch.nn.functional.silu(gu[:, :inter]) * gu[:, inter:]
+        out = torch.empty((rows, inter), dtype=dtype, device="cuda")
+        _ffi.check(lib.ts_swiglu(0, C.c_void_p(gu.data_ptr()), rows, inter, code, C.c_void_p(out.data_ptr()), st))
+        torch.cuda.synchronize()
+        assert (out.float() - want.float()).abs().max().item() <= tol * max(1.0, want.float().abs().max().item())
+        if dtype == torch.bfloat16:
+            assert (out != want).float().mean().item() < 2e-3
+
+
+def test_fused_qwen3_forward_matches_the_models_own():
+    """FusedQwen3Forward (stacked projections + ts_add_rmsnorm + ts_qk_norm_rope + ts_swiglu) against Qwen3Model's own forward on
+    the same random-init weights: hidden states to bf16 noise, sentence embeddings (last-token pooling) to cosine > 0.9995; padded
+    batches (causal + padding mask) and unpadded ones (causal only); fp32 to 2e-4; TS_ENCODER_FUSED=0 keeps the model's own."""
+    import torch
+    from theoremsearch_amd.encoder import FusedQwen3Forward, SentenceEncoder
+    name = "Qwen/Qwen3-Embedding-0.6B"
+    enc = SentenceEncoder(name, num_layers=3, allow_random_init=True)
+    assert isinstance(enc._fused, FusedQwen3Forward) and enc.pooling == "lasttoken" and enc.embedding_dim == 1024
+    texts = [f"lemma {i}: every finite group of order {i} " + "is solvable " * (i % 5) for i in range(40)]
+    tok = {k: v.cuda() for k, v in enc._tokenize(texts).items()}
+    assert not bool(tok["attention_mask"].all())                                  # ragged lengths: the padded path
+    with torch.inference_mode():
+        want = enc.model(input_ids=tok["input_ids"], attention_mask=tok["attention_mask"]).last_hidden_state.float()
+        got = enc.forward_hidden(tok["input_ids"], tok["attention_mask"]).float()
+    real = tok["attention_mask"].bool()
+    assert (want - got)[real].abs().max().item() < 0.25 and (want - got)[real].abs().mean().item() < 0.02
+    same = tok["input_ids"][:, :6].contiguous()                                   # every row full: causal only, no mask tensor
+    ones = torch.ones_like(same)
+    with torch.inference_mode():
+        w2 = enc.model(input_ids=same, attention_mask=ones).last_hidden_state.float()
+        g2 = enc.forward_hidden(same, ones, no_padding=True).float()
+    assert (w2 - g2).abs().max().item() < 0.25 and (w2 - g2).abs().mean().item() < 0.02
+    fused = enc.encode(texts, normalize_embeddings=True, convert_to_numpy=True)
+    os.environ["TS_ENCODER_FUSED"] = "0"
+    try:
+        plain_enc = SentenceEncoder(name, num_layers=3, allow_random_init=True)
+    finally:
+        del os.environ["TS_ENCODER_FUSED"]
+    assert plain_enc._fused is None
+    plain = plain_enc.encode(texts, normalize_embeddings=True, convert_to_numpy=True)
+    assert np.min(np.sum(fused * plain, axis=1)) > 0.9995
+    f32 = SentenceEncoder(name, num_layers=2, allow_random_init=True, dtype=torch.float32)
+    assert isinstance(f32._fused, FusedQwen3Forward)
+    e32 = {k: v.cuda() for k, v in f32._tokenize(texts[:9]).items()}
+    with torch.inference_mode():
+        w32 = f32.model(input_ids=e32["input_ids"], attention_mask=e32["attention_mask"]).last_hidden_state
+        g32 = f32.forward_hidden(e32["input_ids"], e32["attention_mask"])
+    assert (w32 - g32)[e32["attention_mask"].bool()].abs().max().item() < 5e-4

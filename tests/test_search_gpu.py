@@ -199,6 +199,49 @@ def test_mfma_d1024_and_query_blocks(ts):
             check(q[:nq], c, "cos", "bf16", 7, s, i)
 
 
+@pytest.mark.parametrize("nq", [193, 256])
+def test_paired_full_pass_at_d1024_answers_like_two_launches(ts, nq):
+    """bf16 x 1024 (the production table, rds_schema.sql:50-56) holds 192 queries per workgroup; 193 .. 256 queries run as ONE
+    launch of workgroup pairs (each half of a pair multiplies 128 of the queries against the same tiles) instead of two
+    launches of 128: the same answers bit for bit, against the oracle, with a row mask, on other grids, as the tile shares
+    move over repeated searches, and for device queries read in place."""
+    import torch
+    n = 330_000
+    q, c = oracle.golden_inputs(n, nq, 1024, 7100 + nq, "ip")
+    with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as ix:
+        ix.set_option("TS_MFMA_PAIR", 0)
+        s0, i0, st0 = ix.search(q, 10, algo="mfma", return_stats=True)
+        check(q, c, "ip", "bf16", 10, s0, i0)
+        ix.set_option("TS_MFMA_PAIR", None)
+        for rep in range(4):                                   # the feedback partition moves the pairs' tile shares
+            s1, i1, st1 = ix.search(q, 10, algo="mfma", return_stats=True)
+            assert st1["fallback_queries"] == 0 and st1["algo"] == 2, st1
+            assert np.array_equal(i1, i0) and np.array_equal(s1, s0), rep
+        for grid in (64, 208):                                 # 208 = 13 groups of 16; 64: 32 pairs
+            ix.set_option("TS_MFMA_GRID", grid)
+            s2, i2 = ix.search(q, 10, algo="mfma")
+            assert np.array_equal(i2, i0) and np.array_equal(s2, s0), grid
+        ix.set_option("TS_MFMA_GRID", 200)                     # not a multiple of 16: no pairs, two launches
+        s2, i2 = ix.search(q, 10, algo="mfma")
+        assert np.array_equal(i2, i0) and np.array_equal(s2, s0)
+        ix.set_option("TS_MFMA_GRID", None)
+        mask = np.random.default_rng(3).random(n) < 0.4
+        sm, im = ix.search(q, 10, mask=mask, algo="mfma")
+        keep = np.flatnonzero(mask)
+        qp, cp = oracle.prepared_inputs(q, c, "ip", "bf16")
+        stats = oracle.check_topk_against_truth(oracle.scores_fp64(qp, cp[keep]), np.searchsorted(keep, im), sm, 10)
+        assert stats["recall"] == 1.0 and mask[im].all()
+        if nq == 256:                                          # the storage form, a whole launch's worth: read in place
+            qd = torch.from_numpy(q).cuda().to(torch.bfloat16)
+            out_s = torch.empty((nq, 10), dtype=torch.float32, device="cuda")
+            out_i = torch.empty((nq, 10), dtype=torch.int64, device="cuda")
+            st = torch.cuda.Stream()
+            ix.search_device(qd.data_ptr(), "bf16", nq, 10, out_s.data_ptr(), out_i.data_ptr(), st.cuda_stream, algo="mfma")
+            st.synchronize()
+            want_s, want_i = ix.search(oracle.bf16_bits_to_f32(oracle.f32_to_bf16_bits(q)), 10, algo="mfma")
+            assert np.array_equal(out_i.cpu().numpy(), want_i) and np.array_equal(out_s.cpu().numpy(), want_s)
+
+
 @pytest.mark.parametrize("kind", ["outliers", "light_tail", "shifted"])
 def test_estimated_threshold_is_verified_not_trusted(ts, kind):
     # The full pass's threshold is extrapolated from one sample (Gaussian tail).  Distributions that break the

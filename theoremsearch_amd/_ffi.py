@@ -104,6 +104,11 @@ _SIGNATURES = {
     "ts_embed_layernorm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                      C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_int32, C.c_int32, C.c_int, C.c_void_p, C.c_void_p]),
     "ts_attention_short": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "ts_add_rmsnorm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_int32, C.c_int, C.c_void_p,
+                                 C.c_void_p, C.c_void_p]),
+    "ts_qk_norm_rope": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_int32,
+                                  C.c_int32, C.c_int32, C.c_int32, C.c_int, C.c_void_p]),
+    "ts_swiglu": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_void_p, C.c_void_p]),
     "ts_index_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "ts_index_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "ts_index_probe_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -121,3 +121,68 @@ extern "C" int ts_attention_short(int device, const void* qkv, const int64_t* at
     return TS_OK;
 }
 
+
+extern "C" int ts_add_rmsnorm(int device, const void* a, const void* b, const void* gamma, float eps, int64_t rows, int32_t d, int dtype,
+                              void* out_sum, void* out_norm, void* stream) {
+    if (!a || !gamma || !out_norm) return fail(TS_ERR_INVALID, "NULL argument");
+    if (dtype != TS_F32 && dtype != TS_BF16) return fail(TS_ERR_INVALID, "dtype %d", dtype);
+    const int vec = dtype == TS_BF16 ? 8 : 4;
+    if (rows < 0 || d < vec || d % vec || d > 64 * kLnMax * vec)
+        return fail(TS_ERR_INVALID, "d = %d must be a multiple of %d and at most %d", d, vec, 64 * kLnMax * vec);
+    if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)gamma | (uintptr_t)out_sum | (uintptr_t)out_norm) & 15) != 0)
+        return fail(TS_ERR_INVALID, "buffers must be 16-byte aligned");
+    if (rows == 0) return TS_OK;
+    TS_TRY(check_device(device));
+    HIP_TRY(hipSetDevice(device));
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    const int per_lane = (d / vec + 63) / 64;
+    hipStream_t st = (hipStream_t)stream;
+#define TS_RMS_LAUNCH(DT_)                                                                                               \
+    do {                                                                                                                 \
+        if (per_lane <= 1) add_rmsnorm_kernel<DT_, 1><<<grid, 256, 0, st>>>(a, b, gamma, eps, rows, d, out_sum, out_norm); \
+        else if (per_lane <= 2) add_rmsnorm_kernel<DT_, 2><<<grid, 256, 0, st>>>(a, b, gamma, eps, rows, d, out_sum, out_norm); \
+        else add_rmsnorm_kernel<DT_, 4><<<grid, 256, 0, st>>>(a, b, gamma, eps, rows, d, out_sum, out_norm);             \
+    } while (0)
+    if (dtype == TS_F32) TS_RMS_LAUNCH(0);
+    else TS_RMS_LAUNCH(1);
+#undef TS_RMS_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return TS_OK;
+}
+
+extern "C" int ts_qk_norm_rope(int device, void* qkv, const void* q_weight, const void* k_weight, const void* cos_table,
+                               const void* sin_table, float eps, int64_t tokens, int32_t seq, int32_t q_heads, int32_t kv_heads,
+                               int32_t head_dim, int dtype, void* stream) {
+    if (!qkv || !q_weight || !k_weight || !cos_table || !sin_table) return fail(TS_ERR_INVALID, "NULL argument");
+    if (dtype != TS_F32 && dtype != TS_BF16) return fail(TS_ERR_INVALID, "dtype %d", dtype);
+    if (tokens < 0 || seq < 1 || q_heads < 1 || kv_heads < 1) return fail(TS_ERR_INVALID, "bad shape");
+    if (head_dim != 128) return fail(TS_ERR_UNSUPPORTED, "head size %d: this kernel serves head size 128 (Qwen3)", head_dim);
+    if (tokens == 0) return TS_OK;
+    TS_TRY(check_device(device));
+    HIP_TRY(hipSetDevice(device));
+    const int64_t items = tokens * (q_heads + kv_heads);
+    const unsigned grid = (unsigned)((items + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == TS_F32) qk_norm_rope_kernel<0><<<grid, 256, 0, st>>>(qkv, q_weight, k_weight, cos_table, sin_table, eps, tokens, seq, q_heads, kv_heads);
+    else qk_norm_rope_kernel<1><<<grid, 256, 0, st>>>(qkv, q_weight, k_weight, cos_table, sin_table, eps, tokens, seq, q_heads, kv_heads);
+    HIP_TRY(hipGetLastError());
+    return TS_OK;
+}
+
+extern "C" int ts_swiglu(int device, const void* gate_up, int64_t rows, int32_t inter, int dtype, void* out, void* stream) {
+    if (!gate_up || !out) return fail(TS_ERR_INVALID, "NULL argument");
+    if (dtype != TS_F32 && dtype != TS_BF16) return fail(TS_ERR_INVALID, "dtype %d", dtype);
+    const int vec = dtype == TS_BF16 ? 8 : 4;
+    if (rows < 0 || inter < vec || inter % vec) return fail(TS_ERR_INVALID, "inter = %d must be a multiple of %d", inter, vec);
+    if ((((uintptr_t)gate_up | (uintptr_t)out) & 15) != 0) return fail(TS_ERR_INVALID, "buffers must be 16-byte aligned");
+    if (rows == 0) return TS_OK;
+    TS_TRY(check_device(device));
+    HIP_TRY(hipSetDevice(device));
+    const int64_t total = rows * (inter / vec);
+    const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 16384);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == TS_F32) swiglu_kernel<0><<<grid, 256, 0, st>>>(gate_up, rows, inter, out);
+    else swiglu_kernel<1><<<grid, 256, 0, st>>>(gate_up, rows, inter, out);
+    HIP_TRY(hipGetLastError());
+    return TS_OK;
+}

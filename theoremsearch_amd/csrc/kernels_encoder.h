@@ -363,5 +363,163 @@ __global__ void __launch_bounds__(256) embed_layernorm_kernel(const int64_t* __r
     }
 }
 
+// ---- the decoder-style encoder (Qwen3-Embedding: RMSNorm, rotary positions, grouped-query attention, gated MLP) ------------
+// The production embedder of the reference is Qwen/Qwen3-Embedding-0.6B (streamlit_app.py:55, ec2/generate_embeddings/
+// embedders.py:1-4: 28 layers, 1024 wide, 16 query / 8 key-value heads of 128, SwiGLU 3072).  Around its GEMMs PyTorch runs,
+// per layer: two RMSNorms of six launches each (to fp32, pow, mean, add + rsqrt, mul, cast + mul), two residual adds, the
+// per-head RMSNorm of queries and keys (twelve launches), the rotary embedding (ten) and SiLU x up (two).  Three kernels
+// take their place; each follows the roundings of the modules it replaces (noted per kernel), so the hidden states agree
+// with the model's own forward to the last bf16 bit wherever fp32 sums agree.
+
+template <int DT>
+__device__ __forceinline__ void enc_unpack(const uint4& v, float* f) {
+    if (DT == 0) {
+        f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+    } else {
+        f[0] = bf16_lo(v.x); f[1] = bf16_hi(v.x); f[2] = bf16_lo(v.y); f[3] = bf16_hi(v.y);
+        f[4] = bf16_lo(v.z); f[5] = bf16_hi(v.z); f[6] = bf16_lo(v.w); f[7] = bf16_hi(v.w);
+    }
+}
+template <int DT>
+__device__ __forceinline__ uint4 enc_pack(const float* y) {
+    if (DT == 0) return make_uint4(__float_as_uint(y[0]), __float_as_uint(y[1]), __float_as_uint(y[2]), __float_as_uint(y[3]));
+    uint4 o;
+    o.x = (u32)f32_to_bf16(y[0]) | ((u32)f32_to_bf16(y[1]) << 16);
+    o.y = (u32)f32_to_bf16(y[2]) | ((u32)f32_to_bf16(y[3]) << 16);
+    o.z = (u32)f32_to_bf16(y[4 % (DT == 0 ? 4 : 8)]) | ((u32)f32_to_bf16(y[5 % (DT == 0 ? 4 : 8)]) << 16);
+    o.w = (u32)f32_to_bf16(y[6 % (DT == 0 ? 4 : 8)]) | ((u32)f32_to_bf16(y[7 % (DT == 0 ? 4 : 8)]) << 16);
+    return o;
+}
+// round to the storage type and back: where the replaced module chain materialises a tensor of that type
+template <int DT>
+__device__ __forceinline__ float enc_round(float v) { return DT == 0 ? v : bf16_to_f32(f32_to_bf16(v)); }
+
+// Residual add + RMSNorm (Qwen3DecoderLayer: `hidden = residual + sublayer(hidden)` followed by the next RMSNorm):
+//   s    = a + b          rounded to the storage type (torch materialises the sum)       -> out_sum (optional: the new residual)
+//   y    = s * rsqrt(mean(s^2) + eps)   in fp32, rounded to the storage type (Qwen3RMSNorm: `hidden_states.to(input_dtype)`)
+//   out  = gamma * y      rounded to the storage type                                      -> out_norm
+// b may be NULL (a plain RMSNorm: the first norm of the first layer).  One wave per row, LN 16-byte accesses per lane.
+template <int DT, int LN>
+__global__ void __launch_bounds__(256) add_rmsnorm_kernel(const void* a, const void* b, const void* __restrict__ gamma, float eps,
+                                                           int64_t rows, int d, void* out_sum, void* out_norm) {
+    constexpr int VEC = DT == 0 ? 4 : 8;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = d / VEC;
+    const uint4* pa = (const uint4*)a + row * nchunk;
+    const uint4* pb = b ? (const uint4*)b + row * nchunk : nullptr;
+    uint4 ra[LN], rb[LN], rg[LN];
+#pragma unroll
+    for (int j = 0; j < LN; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nchunk) {
+            ra[j] = pa[c];
+            if (pb) rb[j] = pb[c];
+            rg[j] = ((const uint4*)gamma)[c];
+        }
+    }
+    float x[LN][VEC];
+    float sq = 0.0f;
+#pragma unroll
+    for (int j = 0; j < LN; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nchunk) {
+            float fa[VEC], fb[VEC];
+            enc_unpack<DT>(ra[j], fa);
+            if (pb) enc_unpack<DT>(rb[j], fb);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                x[j][e] = pb ? enc_round<DT>(fa[e] + fb[e]) : fa[e];
+                sq += x[j][e] * x[j][e];
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    const float rstd = rsqrtf(sq / (float)d + eps);
+    uint4* ps = out_sum ? (uint4*)out_sum + row * nchunk : nullptr;
+    uint4* po = (uint4*)out_norm + row * nchunk;
+#pragma unroll
+    for (int j = 0; j < LN; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nchunk) {
+            float g[VEC], y[VEC];
+            enc_unpack<DT>(rg[j], g);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) y[e] = g[e] * enc_round<DT>(x[j][e] * rstd);
+            if (ps) ps[c] = enc_pack<DT>(x[j]);
+            po[c] = enc_pack<DT>(y);
+        }
+    }
+}
+
+// Per-head RMSNorm of queries and keys + rotary position embedding, in place on the fused projection's output
+// (Qwen3Attention.forward: q_norm(q_proj(x).view(.., heads, 128)), k_norm(..), apply_rotary_pos_emb):
+//   qkv   [tokens][(hq + 2 hkv) * 128]: query heads, key heads, value heads (values untouched)
+//   y     = w * round(x * rsqrt(mean_128(x^2) + eps))                      (Qwen3RMSNorm over the head, fp32 inside)
+//   out_i = round(round(y_i * cos_i) + round(rot_i * sin_i)),  rot = (-y[64..127], y[0..63])     (rotate_half; torch rounds
+//           each product and the sum to the storage type)
+// cos / sin: [seq][128] of the storage type (Qwen3RotaryEmbedding: fp32 angles, cast to x.dtype), token t has position
+// t % seq.  Head size 128 only.  One wave per (token, head): lane l holds elements l and l + 64 - the two partners of the
+// rotation - so the rotation needs no exchange between lanes.
+template <int DT>
+__global__ void __launch_bounds__(256) qk_norm_rope_kernel(void* qkv, const void* __restrict__ wq, const void* __restrict__ wk,
+                                                            const void* __restrict__ cos_t, const void* __restrict__ sin_t, float eps,
+                                                            int64_t tokens, int seq, int hq, int hkv) {
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int heads = hq + hkv;                          // the heads this kernel touches (queries, then keys)
+    if (item >= tokens * heads) return;
+    const int64_t tok = item / heads;
+    const int h = (int)(item - tok * heads);
+    const int pos = (int)(tok % seq);
+    const int64_t width = (int64_t)(hq + 2 * hkv) * 128;
+    auto ld = [&](const void* p, int64_t i) -> float {
+        return DT == 0 ? ((const float*)p)[i] : bf16_to_f32(((const unsigned short*)p)[i]);
+    };
+    const int64_t base = tok * width + (int64_t)h * 128;
+    const void* w = h < hq ? wq : wk;
+    const float x0 = ld(qkv, base + lane), x1 = ld(qkv, base + lane + 64);
+    float sq = x0 * x0 + x1 * x1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    const float rstd = rsqrtf(sq / 128.0f + eps);
+    const float y0 = enc_round<DT>(ld(w, lane) * enc_round<DT>(x0 * rstd));
+    const float y1 = enc_round<DT>(ld(w, lane + 64) * enc_round<DT>(x1 * rstd));
+    const float c0 = ld(cos_t, (int64_t)pos * 128 + lane), c1 = ld(cos_t, (int64_t)pos * 128 + lane + 64);
+    const float s0 = ld(sin_t, (int64_t)pos * 128 + lane), s1 = ld(sin_t, (int64_t)pos * 128 + lane + 64);
+    const float o0 = enc_round<DT>(y0 * c0) + enc_round<DT>(-y1 * s0);
+    const float o1 = enc_round<DT>(y1 * c1) + enc_round<DT>(y0 * s1);
+    if (DT == 0) {
+        ((float*)qkv)[base + lane] = o0;
+        ((float*)qkv)[base + lane + 64] = o1;
+    } else {
+        ((unsigned short*)qkv)[base + lane] = f32_to_bf16(o0);
+        ((unsigned short*)qkv)[base + lane + 64] = f32_to_bf16(o1);
+    }
+}
+
+// Gated MLP activation (Qwen3MLP: act_fn(gate_proj(x)) * up_proj(x), act_fn = SiLU) on the fused projection's output:
+//   gate_up [rows][2 * inter]: gate columns, then up columns;   out [rows][inter] = round(round(silu(gate)) * up)
+// (torch rounds SiLU's result to the storage type before the product).  16 bytes per lane.
+template <int DT>
+__global__ void __launch_bounds__(256) swiglu_kernel(const void* __restrict__ gate_up, int64_t rows, int inter, void* __restrict__ out) {
+    constexpr int VEC = DT == 0 ? 4 : 8;
+    const int per_row = inter / VEC;
+    const int64_t total = rows * per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / per_row;
+        const int c = (int)(i - r * per_row);
+        const uint4 g4 = ((const uint4*)gate_up)[r * 2 * per_row + c];
+        const uint4 u4 = ((const uint4*)gate_up)[r * 2 * per_row + per_row + c];
+        float g[VEC], u[VEC], y[VEC];
+        enc_unpack<DT>(g4, g);
+        enc_unpack<DT>(u4, u);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) y[e] = enc_round<DT>(g[e] / (1.0f + __expf(-g[e]))) * u[e];
+        ((uint4*)out)[i] = enc_pack<DT>(y);
+    }
+}
 
 }  // namespace ts

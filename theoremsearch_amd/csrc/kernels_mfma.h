@@ -105,6 +105,11 @@ struct MfmaArgs {
     // and the time each workgroup took (100 MHz ticks) - the final select moves the boundaries for the next search
     const int64_t* part;
     unsigned* wg_ticks;
+    // full pass of the 16x16 kernel, d = 1024 at more than 192 queries: PAIRS of workgroups share a tile range, each half of
+    // the pair holding 64 * NB of the queries (workgroups w and w + 8 of a group of 16: the same XCD under round-robin
+    // dispatch, so the second reader of a tile finds it in that XCD's L2 / the memory-side cache); part / wg_ticks are
+    // then indexed by pair
+    int pair;
 };
 
 __device__ __forceinline__ float mfma_level_thr(const MfmaArgs& a, int qid) {

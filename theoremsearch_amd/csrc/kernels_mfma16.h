@@ -228,12 +228,17 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
-    const int G = gridDim.x;
-    const int nwriters = 4 * G;
+    // paired full pass (MfmaArgs::pair): workgroups w and w + 8 of every group of 16 walk the same tiles with the two halves
+    // of the query batch; `wg` numbers the pairs
+    const bool paired = !SPARSE && a.pair != 0;
+    const int wg = paired ? (int)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) : (int)blockIdx.x;
+    const int qhalf = paired ? (int)((blockIdx.x >> 3) & 1) : 0;
+    const int G = paired ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+    const int nwriters = 4 * gridDim.x;
     const int writer = 4 * blockIdx.x + kq;
     int qid[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) qid[b] = (b * 4 + wave) * 16 + r16;
+    for (int b = 0; b < NB; ++b) qid[b] = qhalf * 64 * NB + (b * 4 + wave) * 16 + r16;
 
     mfma_level_begin(a);
     uint4* stage = (uint4*)(smem + dims::kLds) + wave * kMfma16StageCap;          // this wave's staged candidates
@@ -242,10 +247,10 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     // Tile range of this workgroup: equal shares, or the table the previous search's final select left (the XCDs of one
     // device run this pass at rates 3-4 % apart; the launch ends with its slowest workgroup)
     const unsigned long long wg_start = (!SPARSE && a.wg_ticks) ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    const int64_t t0 = (!SPARSE && a.part) ? a.part[blockIdx.x] : (a.ntiles * (int64_t)blockIdx.x) / G;
-    const int nt = (int)(((!SPARSE && a.part) ? a.part[blockIdx.x + 1] : (a.ntiles * (int64_t)(blockIdx.x + 1)) / G) - t0);
+    const int64_t t0 = (!SPARSE && a.part) ? a.part[wg] : (a.ntiles * (int64_t)wg) / G;
+    const int nt = (int)(((!SPARSE && a.part) ? a.part[wg + 1] : (a.ntiles * (int64_t)(wg + 1)) / G) - t0);
     if (nt <= 0) {
-        if (!SPARSE && a.wg_ticks && threadIdx.x == 0) a.wg_ticks[blockIdx.x] = 0;
+        if (!SPARSE && a.wg_ticks && threadIdx.x == 0 && qhalf == 0) a.wg_ticks[wg] = 0;
         if (!kStaged) {
 #pragma unroll
             for (int b = 0; b < NB; ++b) a.pcount[(int64_t)qid[b] * nwriters + writer] = 0;
@@ -254,6 +259,48 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     }
     const int nu = kUnits * nt;
 
+    // The stream starts first: the DMA prologue goes out before the query fragments are fetched, so that the first units
+    // cross the chip while 393 KB of fragments per workgroup come out of L2 (both are vector-memory operations: they
+    // return in order, the one vmcnt(0) below certifies this wave's pieces of every prologue unit and its fragments).
+    // DMA source of this lane (as kernels_mfma.h): row 8w + (lane >> 3) of the tile, swizzled chunk of K-block 0 of the unit
+    const int drow = 8 * wave + (lane >> 3);
+    const int dchunk = (lane & 7) ^ ((drow >> 1) & 7);
+    const int64_t tile_bytes = (int64_t)kTileRows * Deq * 2;
+    const int64_t run_jump = tile_bytes * ((int64_t)a.run * a.tile_stride - a.run + 1);
+    const int64_t g0 = (t0 / a.run) * a.run * a.tile_stride + t0 % a.run;
+    const unsigned char* tile_src = (const unsigned char*)a.corpus + (int64_t)drow * (Deq * 2) + dchunk * 16 + g0 * tile_bytes;
+    int issue_run_pos = (int)(t0 % a.run);
+    int issue_u = 0, issue_ui = 0, issue_slot = 0;
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned lds0 = lds_base + wave * 1024;
+
+    // operand read offsets inside a unit image: row block rb, k-step s -> (s >> 1) * 4096 + rb * 2048 + xo[s & 1]
+    const int lane_off = (r16 >> 3) * 1024 + (r16 & 7) * 128;
+    const int sw = (r16 >> 1) & 7;
+    int xo[2];
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) xo[sp] = lane_off + (((4 * sp + kq) ^ sw) << 4);
+
+#define TS16_ISSUED()                                                                 \
+    do {                                                                              \
+        if (++issue_ui == kUnits) {                                                   \
+            issue_ui = 0;                                                             \
+            tile_src += (issue_run_pos + 1 == a.run) ? run_jump : tile_bytes;         \
+            issue_run_pos = (issue_run_pos + 1 == a.run) ? 0 : issue_run_pos + 1;     \
+        }                                                                             \
+        ++issue_u;                                                                    \
+        issue_slot = (issue_slot + 1 == kSlots) ? 0 : issue_slot + 1;                 \
+    } while (0)
+
+    // at least two: the fragment reads at the end of unit u already fetch the head of unit u + 1, which is certified at the
+    // start of unit u only if it was issued a unit earlier
+    const int ahead = (a.ahead >= 2 && a.ahead < kSlots) ? a.ahead : kSlots - 1;
+    for (int i = 0; i < ahead && issue_u < nu && !kNoDma; ++i) {
+        const unsigned char* src = tile_src + issue_ui * (kUnitK * 2);
+#pragma unroll
+        for (int j = 0; j < kPieces; ++j) lds_dma16(src + j * 128, lds0 + issue_slot * kUnitBytes + j * 4096);
+        TS16_ISSUED();
+    }
     // query fragments: fragment f = b * kSteps + ks holds q[qid[b]][32 ks + 8 kq .. + 8]
     bf16x8 qv[kQV], qa[kFrags > kQV ? kFrags - kQV : 1];
 #pragma unroll
@@ -279,48 +326,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
 #pragma unroll
     for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(thr[b]));
 
-    // DMA source of this lane (as kernels_mfma.h): row 8w + (lane >> 3) of the tile, swizzled chunk of K-block 0 of the unit
-    const int drow = 8 * wave + (lane >> 3);
-    const int dchunk = (lane & 7) ^ ((drow >> 1) & 7);
-    const int64_t tile_bytes = (int64_t)kTileRows * Deq * 2;
-    const int64_t run_jump = tile_bytes * ((int64_t)a.run * a.tile_stride - a.run + 1);
-    const int64_t g0 = (t0 / a.run) * a.run * a.tile_stride + t0 % a.run;
-    const unsigned char* tile_src = (const unsigned char*)a.corpus + (int64_t)drow * (Deq * 2) + dchunk * 16 + g0 * tile_bytes;
-    int issue_run_pos = (int)(t0 % a.run);
-    int issue_u = 0, issue_ui = 0, issue_slot = 0;
-    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
-    const unsigned lds0 = lds_base + wave * 1024;
-
-    // operand read offsets inside a unit image: row block rb, k-step s -> (s >> 1) * 4096 + rb * 2048 + xo[s & 1]
-    const int lane_off = (r16 >> 3) * 1024 + (r16 & 7) * 128;
-    const int sw = (r16 >> 1) & 7;
-    int xo[2];
-#pragma unroll
-    for (int sp = 0; sp < 2; ++sp) xo[sp] = lane_off + (((4 * sp + kq) ^ sw) << 4);
-
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-#define TS16_ISSUED()                                                                 \
-    do {                                                                              \
-        if (++issue_ui == kUnits) {                                                   \
-            issue_ui = 0;                                                             \
-            tile_src += (issue_run_pos + 1 == a.run) ? run_jump : tile_bytes;         \
-            issue_run_pos = (issue_run_pos + 1 == a.run) ? 0 : issue_run_pos + 1;     \
-        }                                                                             \
-        ++issue_u;                                                                    \
-        issue_slot = (issue_slot + 1 == kSlots) ? 0 : issue_slot + 1;                 \
-    } while (0)
-
-    // at least two: the fragment reads at the end of unit u already fetch the head of unit u + 1, which is certified at the
-    // start of unit u only if it was issued a unit earlier
-    const int ahead = (a.ahead >= 2 && a.ahead < kSlots) ? a.ahead : kSlots - 1;
-    for (int i = 0; i < ahead && issue_u < nu && !kNoDma; ++i) {
-        const unsigned char* src = tile_src + issue_ui * (kUnitK * 2);
-#pragma unroll
-        for (int j = 0; j < kPieces; ++j) lds_dma16(src + j * 128, lds0 + issue_slot * kUnitBytes + j * 4096);
-        TS16_ISSUED();
-    }
-    wait_keep_units<kPieces>(issue_u - 1);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
@@ -625,8 +631,8 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
 #pragma unroll
         for (int b = 0; b < NB; ++b) a.pcount[(int64_t)qid[b] * nwriters + writer] = cnt[b];
     }
-    if (!SPARSE && a.wg_ticks && threadIdx.x == 0)
-        a.wg_ticks[blockIdx.x] = (unsigned)(__builtin_amdgcn_s_memrealtime() - wg_start);
+    if (!SPARSE && a.wg_ticks && threadIdx.x == 0 && qhalf == 0)
+        a.wg_ticks[wg] = (unsigned)(__builtin_amdgcn_s_memrealtime() - wg_start);
     if (VARIANT == 5 && a.dbg && lane == 0) {
         unsigned long long* d = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 4;
         d[0] = cycle_stamp() - t_all0;

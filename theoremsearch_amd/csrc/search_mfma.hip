@@ -87,7 +87,18 @@ static std::vector<Level> plan_levels(const Knobs& kn, int64_t n, int kk, bool s
 
 // Queries one launch of the MFMA kernel serves for this index / batch: d = 768 holds two query groups per wave
 // (256 queries; one group = half the matrix work when the batch is <= 128), d = 1024 one (128 queries).
+// bf16 x 1024 (the production table, rds_schema.sql:50-56: vector(1024)) holds 3 blocks of 16 queries per wave: 192 per
+// workgroup.  A batch of 193 .. 256 queries runs as ONE launch of workgroup PAIRS (MfmaArgs::pair): both workgroups of a pair
+// walk the same tiles with 128 queries each, two blocks per wave, so the corpus crosses HBM once for the whole batch (the
+// pair's second read of a tile is served by the XCD's L2 / the memory-side cache) instead of once per 128 queries.
+static int mfma_grid(const ts_index* ix) { return std::max(1, std::min(ix->knobs.get(K_MFMA_GRID, ix->cu_count), 2048)); }
+static bool mfma_pairs(const ts_index* ix, int nq) {
+    return ix->dtype == TS_BF16 && ix->d == 1024 && nq > 192 && use_shape16(ix) && two_level_search(ix) &&
+           ix->knobs.get(K_MFMA_PAIR, 1) != 0 && mfma_grid(ix) % 16 == 0;
+}
+
 int mfma_block_queries(const ts_index* ix, int nq) {
+    if (mfma_pairs(ix, nq)) return 256;
     if (ix->dtype == TS_F32) {
         if (ix->d == 1024) return 64;                          // one block of 16 queries x 4 waves
         if (use_shape16(ix)) return nq <= 64 ? 64 : 128;       // one or two blocks per wave (d = 384, 512, 768)
@@ -115,7 +126,8 @@ int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* out_idx
     const int variant = ix->knobs.get(K_MFMA_VARIANT, 0);
     const bool shape16 = use_shape16(ix);
     const int groups = shape16 ? 0 : mfma_block_queries(ix, nq) / 128;
-    const int nb16 = shape16 ? mfma_block_queries(ix, nq) / 64 : 0;
+    const bool pair = mfma_pairs(ix, nq);
+    const int nb16 = pair ? 2 : (shape16 ? mfma_block_queries(ix, nq) / 64 : 0);
     if (!ix->attr_done) {
         HIP_TRY(hipFuncSetAttribute((const void*)level_select_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelLds));
         HIP_TRY(hipFuncSetAttribute((const void*)level_select_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelLds));
@@ -129,7 +141,8 @@ int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* out_idx
     // guaranteed chain (TS_MFMA_STAT=0).
     const bool dense_sample = ix->knobs.get(K_MFMA_SAMPLE, 1) != 0;
     if (dense_sample && !ix->sample) HIP_TRY(hipMalloc((void**)&ix->sample, (size_t)kMfmaQ * kLevelSortMax * 4));
-    const int grid = std::max(1, std::min(ix->knobs.get(K_MFMA_GRID, ix->cu_count), 2048));
+    const int grid = mfma_grid(ix);
+    const int wgs = pair ? grid / 2 : grid;                 // tile ranges of the full pass: one per workgroup, or one per pair
     // lane-private candidate lists: 2 writers x 32 entries per workgroup and query (32x32 shape) or 4 x 16 (16x16 shape)
     const int nwriters = (shape16 ? 4 : 2) * grid;
     const int priv_cap = shape16 ? kMfma16PrivCap : kMfmaPrivCap;
@@ -172,21 +185,21 @@ int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* out_idx
     // equal finishing times for the next search (kernels_select.h, rebalance_tiles).  The table starts as equal shares and
     // is re-made whenever the grid or the number of tiles changes.
     const int64_t full_tiles = lv.back().ntiles;
-    const bool balance = shape16 && ix->knobs.get(K_MFMA_BALANCE, 1) != 0 && grid >= 8 && grid <= 256 && lv.back().stride == 1 &&
-                         lv.back().run == 1 && full_tiles >= 32 * (int64_t)grid && (variant == 0 || variant == 3);
-    if (balance && (ix->part_g != grid || ix->part_ntiles != full_tiles)) {
-        if (ix->part_g != grid) {
+    const bool balance = shape16 && ix->knobs.get(K_MFMA_BALANCE, 1) != 0 && wgs >= 8 && wgs <= 256 && lv.back().stride == 1 &&
+                         lv.back().run == 1 && full_tiles >= 32 * (int64_t)wgs && (variant == 0 || variant == 3);
+    if (balance && (ix->part_g != wgs || ix->part_ntiles != full_tiles)) {
+        if (ix->part_g != wgs) {
             if (ix->part) HIP_TRY(hipFree(ix->part));
             if (ix->wg_ticks) HIP_TRY(hipFree(ix->wg_ticks));
             ix->part = nullptr; ix->wg_ticks = nullptr; ix->part_g = 0; ix->part_ntiles = -1;
-            HIP_TRY(hipMalloc((void**)&ix->part, (size_t)(grid + 1) * 8));
-            HIP_TRY(hipMalloc((void**)&ix->wg_ticks, (size_t)grid * 4));
-            ix->part_g = grid;
+            HIP_TRY(hipMalloc((void**)&ix->part, (size_t)(wgs + 1) * 8));
+            HIP_TRY(hipMalloc((void**)&ix->wg_ticks, (size_t)wgs * 4));
+            ix->part_g = wgs;
         }
-        std::vector<int64_t> equal((size_t)grid + 1);
-        for (int w = 0; w <= grid; ++w) equal[w] = full_tiles * (int64_t)w / grid;
+        std::vector<int64_t> equal((size_t)wgs + 1);
+        for (int w = 0; w <= wgs; ++w) equal[w] = full_tiles * (int64_t)w / wgs;
         HIP_TRY(hipMemcpyAsync(ix->part, equal.data(), equal.size() * 8, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemsetAsync(ix->wg_ticks, 0, (size_t)grid * 4, st));
+        HIP_TRY(hipMemsetAsync(ix->wg_ticks, 0, (size_t)wgs * 4, st));
         HIP_TRY(hipStreamSynchronize(st));          // `equal` is a local; this happens once per (grid, size)
         ix->part_ntiles = full_tiles;
     }
@@ -268,6 +281,7 @@ int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* out_idx
         a.stat = ix->stat;
         a.part = (balance && full_pass) ? ix->part : nullptr;
         a.wg_ticks = (balance && full_pass) ? ix->wg_ticks : nullptr;
+        a.pair = (pair && full_pass) ? 1 : 0;
         a.dbg = nullptr;
 #ifdef TS_DIAG
         if (variant >= 3) {
@@ -376,7 +390,7 @@ int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* out_idx
     }
     // block 0 of the launch below moves the tile boundaries of the pass just finished for the next search
     ix->rebalance_pending = balance;
-    ix->rebalance_grid = grid;
+    ix->rebalance_grid = wgs;
     // exact fall-back for queries that lost candidates (device-side count; one empty launch when 0)
     if (!in_place) TS_TRY(scan_search(ix, nq, k, out_scores, out_idx, ix->fb_list, ix->fb_count, st));
     else if (ix->dtype == TS_F32) TS_TRY(scan_search(ix, nq, k, out_scores, out_idx, ix->fb_list, ix->fb_count, st, (const float*)qmat));

@@ -44,13 +44,16 @@ from typing import Iterable, List, Optional, Sequence, Union
 import numpy as np
 import torch
 
-# Stand-in architectures for allow_random_init only: name -> (hidden, layers, heads, ffn, pooling, max_seq_length)
+# Stand-in architectures for allow_random_init only (no weights offline): the published shapes of the reference's embedders
+# (ec2/generate_embeddings/embedders.py:1-4, app_create_embeddings.py:8).  family "bert": BertModel; family "qwen3": Qwen3Model
+# (decoder-style: RMSNorm, rotary positions, 16 query / 8 key-value heads of 128, gated MLP, last-token pooling).
 ARCHITECTURES = {
-    "math-similarity/Bert-MLM_arXiv-MP-class_zbMath": (768, 12, 12, 3072, "mean", 512),
-    "google/embeddinggemma-300m": (768, 24, 12, 3072, "mean", 2048),
-    "Qwen/Qwen3-Embedding-0.6B": (1024, 28, 16, 3072, "lasttoken", 8192),
+    "math-similarity/Bert-MLM_arXiv-MP-class_zbMath": dict(family="bert", hidden=768, layers=12, heads=12, ffn=3072, pooling="mean", max_len=512),
+    "google/embeddinggemma-300m": dict(family="bert", hidden=768, layers=24, heads=12, ffn=3072, pooling="mean", max_len=2048),
+    "Qwen/Qwen3-Embedding-0.6B": dict(family="qwen3", hidden=1024, layers=28, heads=16, kv_heads=8, head_dim=128, ffn=3072,
+                                      pooling="lasttoken", max_len=8192, vocab=151669, rope_theta=1000000.0, rms_eps=1e-6),
 }
-DEFAULT_ARCH = (768, 12, 12, 3072, "mean", 512)
+DEFAULT_ARCH = ARCHITECTURES["math-similarity/Bert-MLM_arXiv-MP-class_zbMath"]
 
 _TOKEN_RE = re.compile(r"\\[A-Za-z]+|[A-Za-z]+|\d+|[^\sA-Za-z\d]")
 _POOL_CODES = {"mean": 0, "lasttoken": 1, "cls": 2}      # TS_POOL_* of include/tsearch.h
@@ -218,14 +221,23 @@ class SentenceEncoder:
                     f"$TS_MODEL_DIR); nothing can be downloaded here.  Pass allow_random_init=True (or set "
                     f"TS_ALLOW_RANDOM_ENCODER=1) for the randomly initialised stand-in used by benchmarks and tests - "
                     f"its embeddings are meaningless")
-            from transformers import BertConfig, BertModel
-            hidden, layers, heads, ffn, pooling, max_len = ARCHITECTURES.get(model_name, DEFAULT_ARCH)
-            cfg = BertConfig(vocab_size=30522, hidden_size=hidden, num_hidden_layers=num_layers or layers,
-                             num_attention_heads=heads, intermediate_size=ffn,
-                             max_position_embeddings=min(max_len, 512))
+            arch = ARCHITECTURES.get(model_name, DEFAULT_ARCH)
+            pooling, max_len = arch["pooling"], arch["max_len"]
             gen_state = torch.random.get_rng_state()
             torch.manual_seed(seed)
-            self.model = BertModel(cfg, add_pooling_layer=False)
+            if arch["family"] == "qwen3":
+                from transformers import Qwen3Config, Qwen3Model
+                cfg = Qwen3Config(vocab_size=arch["vocab"], hidden_size=arch["hidden"], num_hidden_layers=num_layers or arch["layers"],
+                                  num_attention_heads=arch["heads"], num_key_value_heads=arch["kv_heads"], head_dim=arch["head_dim"],
+                                  intermediate_size=arch["ffn"], max_position_embeddings=max_len, rms_norm_eps=arch["rms_eps"],
+                                  rope_theta=arch["rope_theta"], attention_bias=False, use_sliding_window=False)
+                self.model = Qwen3Model(cfg)
+            else:
+                from transformers import BertConfig, BertModel
+                cfg = BertConfig(vocab_size=30522, hidden_size=arch["hidden"], num_hidden_layers=num_layers or arch["layers"],
+                                 num_attention_heads=arch["heads"], intermediate_size=arch["ffn"],
+                                 max_position_embeddings=min(max_len, 512))
+                self.model = BertModel(cfg, add_pooling_layer=False)
             torch.random.set_rng_state(gen_state)
             self.tokenizer = HashingTokenizer(cfg.vocab_size, min(max_len, 512))
             self._hf_tokenizer = False
@@ -237,10 +249,14 @@ class SentenceEncoder:
                 dtype = torch.bfloat16 if self.device.type == "cuda" else torch.float32
         self.pooling = self.pipeline.pooling
         self.model.to(self.device, dtype=dtype).eval()
-        # BERT-family models on a GPU run the fused forward (FusedBertForward); TS_ENCODER_FUSED=0 keeps the model's own
+        # BERT-family and Qwen3-family models on a GPU run a fused forward (FusedBertForward / FusedQwen3Forward);
+        # TS_ENCODER_FUSED=0 keeps the model's own
         self._fused = None
-        if os.environ.get("TS_ENCODER_FUSED", "1") != "0" and self.device.type == "cuda" and FusedBertForward.covers(self.model):
-            self._fused = FusedBertForward(self.model)
+        if os.environ.get("TS_ENCODER_FUSED", "1") != "0" and self.device.type == "cuda":
+            if FusedBertForward.covers(self.model):
+                self._fused = FusedBertForward(self.model)
+            elif FusedQwen3Forward.covers(self.model):
+                self._fused = FusedQwen3Forward(self.model)
         for m in self.pipeline.dense:
             m.to(self.device, dtype=torch.float32).eval()
         self.embedding_dim = (self.pipeline.dense[-1][0].out_features if self.pipeline.dense
@@ -487,8 +503,24 @@ class FusedBertForward:
         self.eps = float(cfg.layer_norm_eps)
         from transformers.activations import ACT2FN
         self.act = ACT2FN[cfg.hidden_act] if isinstance(cfg.hidden_act, str) else cfg.hidden_act
+        self._stamp = None
+        self._refresh()
+
+    def _sources(self):
+        """The parameters the stacked projection weights are copies of."""
+        for layer in self.model.encoder.layer:
+            att = layer.attention.self
+            yield from (att.query.weight, att.key.weight, att.value.weight, att.query.bias, att.key.bias, att.value.bias)
+
+    def _refresh(self):
+        """(Re)build the stacked query / key / value weights when the model's own have changed (load_state_dict, .to(dtype),
+        an edit in place): the other weights are live references, the stacked ones are copies."""
+        stamp = tuple((p.data_ptr(), p._version, p.dtype) for p in self._sources())
+        if stamp == self._stamp:
+            return
+        self._stamp = stamp
         self.layers = []
-        for layer in model.encoder.layer:
+        for layer in self.model.encoder.layer:
             att, so = layer.attention.self, layer.attention.output
             self.layers.append({
                 "wqkv": torch.cat([att.query.weight, att.key.weight, att.value.weight], dim=0).contiguous(),
@@ -506,7 +538,8 @@ class FusedBertForward:
         if getattr(cfg, "position_embedding_type", "absolute") != "absolute" or getattr(cfg, "is_decoder", False):
             return False
         p = next(model.parameters())
-        return p.is_cuda and p.dtype in (torch.float32, torch.bfloat16) and cfg.hidden_size % 8 == 0 and cfg.hidden_size <= 1024
+        return (p.is_cuda and p.dtype in (torch.float32, torch.bfloat16) and cfg.hidden_size % 8 == 0 and cfg.hidden_size <= 1024
+                and cfg.hidden_size % cfg.num_attention_heads == 0)
 
     def _embed(self, input_ids: torch.Tensor, token_type_ids: Optional[torch.Tensor]) -> torch.Tensor:
         """BertEmbeddings (word + token type + position, LayerNorm; dropout is the identity in eval) as ONE HIP kernel
@@ -558,6 +591,7 @@ class FusedBertForward:
     def __call__(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, token_type_ids: Optional[torch.Tensor] = None,
                  no_padding: bool = False):
         F = torch.nn.functional
+        self._refresh()
         x = self._embed(input_ids, token_type_ids)
         B, S, H = x.shape
         hd = H // self.heads
@@ -567,8 +601,9 @@ class FusedBertForward:
         # short sequences (one sentence per query: app_showcase_model.py:92) of a bf16 model with 64-wide heads: the attention as
         # ONE wave per (sequence, head), straight from the fused projection to the context layout (``ts_attention_short``)
         short = x.dtype == torch.bfloat16 and hd == 64 and S <= 64 and os.environ.get("TS_ENCODER_ATTENTION", "1") != "0"
+        # (the most negative finite value, not -inf: a sequence without a single token would otherwise soften to NaN)
         mask = None if (no_padding or short) else torch.zeros((B, 1, 1, S), dtype=x.dtype, device=x.device).masked_fill_(
-            ~attention_mask[:, None, None, :].to(torch.bool), float("-inf"))
+            ~attention_mask[:, None, None, :].to(torch.bool), torch.finfo(x.dtype).min)
         key_mask = None if (no_padding or not short) else attention_mask.to(torch.int64).contiguous()
         for L in self.layers:
             qkv = F.linear(x, L["wqkv"], L["bqkv"])
@@ -582,6 +617,135 @@ class FusedBertForward:
             h = self.act(F.linear(x, L["w1"], L["b1"]))
             x = self._add_ln(F.linear(h, L["w2"], L["b2"]), x, L["ln2"])
         return x
+
+
+class FusedQwen3Forward:
+    """The forward of a Qwen3-family encoder (``Qwen3Model``: what ``Qwen/Qwen3-Embedding-0.6B`` is, the embedder of the
+    production app, streamlit_app.py:55) with everything around its GEMMs as kernels of libtsearch:
+
+    * query / key / value projections as ONE GEMM over the stacked weight, gate / up projections as ONE;
+    * ``residual + sublayer`` followed by the next RMSNorm as ONE kernel (``ts_add_rmsnorm``: PyTorch runs an add and six
+      launches per norm, twice per layer);
+    * the per-head RMSNorm of queries and keys + the rotary embedding as ONE kernel, in place (``ts_qk_norm_rope``:
+      twenty-two launches per layer in PyTorch);
+    * ``silu(gate) * up`` as ONE kernel (``ts_swiglu``).
+
+    Same weights, same order of operations, the roundings of the modules replaced; the attention itself is
+    ``scaled_dot_product_attention`` (causal, grouped-query), as the model's own ``sdpa`` path."""
+
+    def __init__(self, model):
+        cfg = model.config
+        self.model, self.cfg = model, cfg
+        self.hq, self.hkv, self.hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        self.eps = float(cfg.rms_norm_eps)
+        self._stamp = None
+        self._gqa_native = True
+        self._refresh()
+
+    def _sources(self):
+        for layer in self.model.layers:
+            att, mlp = layer.self_attn, layer.mlp
+            yield from (att.q_proj.weight, att.k_proj.weight, att.v_proj.weight, mlp.gate_proj.weight, mlp.up_proj.weight)
+
+    def _refresh(self):
+        stamp = tuple((p.data_ptr(), p._version, p.dtype) for p in self._sources())
+        if stamp == self._stamp:
+            return
+        self._stamp = stamp
+        self.layers = []
+        for layer in self.model.layers:
+            att, mlp = layer.self_attn, layer.mlp
+            self.layers.append({
+                "wqkv": torch.cat([att.q_proj.weight, att.k_proj.weight, att.v_proj.weight], dim=0).contiguous(),
+                "wo": att.o_proj.weight, "qn": att.q_norm.weight, "kn": att.k_norm.weight,
+                "wgu": torch.cat([mlp.gate_proj.weight, mlp.up_proj.weight], dim=0).contiguous(), "wd": mlp.down_proj.weight,
+                "ln1": layer.input_layernorm.weight, "ln2": layer.post_attention_layernorm.weight,
+            })
+
+    @staticmethod
+    def covers(model) -> bool:
+        cfg = getattr(model, "config", None)
+        if cfg is None or getattr(cfg, "model_type", "") != "qwen3" or not hasattr(model, "layers"):
+            return False
+        if getattr(cfg, "attention_bias", False) or getattr(cfg, "head_dim", 0) != 128:
+            return False
+        if any(t != "full_attention" for t in (getattr(cfg, "layer_types", None) or [])):
+            return False
+        if getattr(cfg, "hidden_act", "silu") != "silu":
+            return False
+        p = next(model.parameters())
+        vec = 8 if p.dtype == torch.bfloat16 else 4
+        return (p.is_cuda and p.dtype in (torch.float32, torch.bfloat16) and cfg.hidden_size % vec == 0 and
+                cfg.hidden_size <= 256 * vec and cfg.intermediate_size % vec == 0 and
+                cfg.num_attention_heads % cfg.num_key_value_heads == 0)
+
+    def _add_rmsnorm(self, a: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tensor, want_sum: bool):
+        import ctypes as C
+        from . import _ffi
+        d = a.shape[-1]
+        rows = a.numel() // d
+        out = torch.empty_like(a)
+        new_res = torch.empty_like(a) if (want_sum and b is not None) else None
+        _ffi.check(_ffi.load().ts_add_rmsnorm(
+            a.device.index or 0, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()) if b is not None else None,
+            C.c_void_p(gamma.data_ptr()), self.eps, rows, d, 1 if a.dtype == torch.bfloat16 else 0,
+            C.c_void_p(new_res.data_ptr()) if new_res is not None else None, C.c_void_p(out.data_ptr()),
+            C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)))
+        return (new_res if new_res is not None else a), out
+
+    def __call__(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, token_type_ids: Optional[torch.Tensor] = None,
+                 no_padding: bool = False):
+        import ctypes as C
+        from . import _ffi
+        F = torch.nn.functional
+        lib = _ffi.load()
+        self._refresh()
+        m = self.model
+        x = m.embed_tokens(input_ids).contiguous()
+        B, S, H = x.shape
+        dt = 1 if x.dtype == torch.bfloat16 else 0
+        dev = x.device.index or 0
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        pos = torch.arange(S, device=x.device).unsqueeze(0)              # positions count from the left edge, padding included
+        cos, sin = m.rotary_emb(x, pos)                                  # [1 x S x 128] of the model's type
+        cos, sin = cos[0].contiguous(), sin[0].contiguous()
+        mask = None
+        if not no_padding:
+            # causal, and padding keys are never attended to (the most negative finite value: rows of padding stay finite)
+            neg = torch.finfo(x.dtype).min
+            causal = torch.ones((S, S), dtype=torch.bool, device=x.device).tril_()
+            keep = causal[None, None] & attention_mask[:, None, None, :].to(torch.bool)
+            mask = torch.zeros((B, 1, S, S), dtype=x.dtype, device=x.device).masked_fill_(~keep, neg)
+        nq, nkv, hd = self.hq * self.hd, self.hkv * self.hd, self.hd
+        h = self._add_rmsnorm(x, None, self.layers[0]["ln1"], False)[1]
+        for li, L in enumerate(self.layers):
+            qkv = F.linear(h, L["wqkv"])
+            _ffi.check(lib.ts_qk_norm_rope(dev, C.c_void_p(qkv.data_ptr()), C.c_void_p(L["qn"].data_ptr()), C.c_void_p(L["kn"].data_ptr()),
+                                           C.c_void_p(cos.data_ptr()), C.c_void_p(sin.data_ptr()), self.eps, B * S, S, self.hq, self.hkv,
+                                           hd, dt, stream))
+            q = qkv[..., :nq].view(B, S, self.hq, hd).transpose(1, 2)
+            k = qkv[..., nq:nq + nkv].view(B, S, self.hkv, hd).transpose(1, 2)
+            v = qkv[..., nq + nkv:].view(B, S, self.hkv, hd).transpose(1, 2)
+            ctx = None
+            if self._gqa_native:
+                try:
+                    ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, is_causal=mask is None, enable_gqa=True)
+                except (RuntimeError, TypeError):
+                    self._gqa_native = False
+            if ctx is None:
+                rep = self.hq // self.hkv
+                ctx = F.scaled_dot_product_attention(q, k.repeat_interleave(rep, dim=1), v.repeat_interleave(rep, dim=1),
+                                                     attn_mask=mask, is_causal=mask is None)
+            ctx = ctx.transpose(1, 2).reshape(B, S, nq)
+            x, h = self._add_rmsnorm(x, F.linear(ctx, L["wo"]), L["ln2"], True)
+            gu = F.linear(h, L["wgu"])
+            inter = gu.shape[-1] // 2
+            act = torch.empty((B, S, inter), dtype=x.dtype, device=x.device)
+            _ffi.check(lib.ts_swiglu(dev, C.c_void_p(gu.data_ptr()), B * S, inter, dt, C.c_void_p(act.data_ptr()), stream))
+            last = li + 1 == len(self.layers)
+            gamma = m.norm.weight if last else self.layers[li + 1]["ln1"]
+            x, h = self._add_rmsnorm(x, F.linear(act, L["wd"]), gamma, not last)
+        return h
 
 
 def pool_reference(hidden: torch.Tensor, attention_mask: torch.Tensor, mode: str) -> torch.Tensor:
