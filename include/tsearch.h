@@ -327,8 +327,9 @@ int ts_embed_layernorm(int device, const int64_t *ids, const int64_t *type_ids, 
  * head), bf16, straight from the fused query / key / value projection (BertSelfAttention of the sentence-transformer the
  * reference loads, compare_embeddings.py:11-12; a query is one sentence: app_showcase_model.py:92).  qkv: device bf16
  * [batch][seq][3][heads][64] (the output of one GEMM over the concatenated projection weights); attention_mask: device int64
- * [batch][seq], 0 = padding key, or NULL; out: device bf16 [batch][seq][heads * 64].  head_dim must be 64 and seq at most 64
- * (TS_ERR_UNSUPPORTED otherwise: the caller keeps its library attention).  Scores and softmax in fp32, probabilities rounded to
+ * [batch][seq], 0 = padding key, or NULL; out: device bf16 [batch][seq][heads * 64].  head_dim must be 64 and seq at most 128
+ * (TS_ERR_UNSUPPORTED otherwise: the caller keeps its library attention); up to 64 tokens every score tile of a (sequence, head)
+ * is held at once, 65 .. 128 tokens walk the query tiles against K / V fragments held in registers.  Scores and softmax in fp32, probabilities rounded to
  * bf16 for the second product (as flash attention does). */
 int ts_attention_short(int device, const void *qkv, const int64_t *attention_mask, int32_t batch, int32_t seq, int32_t heads,
                       int32_t head_dim, void *out, void *stream);

@@ -32,8 +32,10 @@ def test_no_register_of_the_fragment_ring_is_read_while_its_load_is_in_flight():
         # the register budget the kernel is written for: no scratch, one wave per SIMD
         usage = open(os.path.join(ASM_DIR, "launch_mfma16.resource_usage.txt")).read()
         blocks = usage.split("Function Name: ")
-        mine = [b for b in blocks if b.startswith("_ZN2ts18mfma16_topk_kernelILi768ELi4ELi0ELb0ELb0EEE")]
+        mine = [b for b in blocks if b.startswith("_ZN2ts18mfma16_topk_kernelILi768ELi4ELi0ELb0ELb0ELb0EEE")]
         assert mine, "headline instantiation not found in the resource report"
         assert "ScratchSize [bytes/lane]: 0" in mine[0] and "VGPRs Spill: 0" in mine[0]
+        pair = [b for b in blocks if b.startswith("_ZN2ts18mfma16_topk_kernelILi1024ELi2ELi0ELb0ELb0ELb1EEE")]     # the paired pass of d = 1024
+        assert pair and "ScratchSize [bytes/lane]: 0" in pair[0]
     finally:
         shutil.rmtree(ASM_DIR, ignore_errors=True)   # tens of MB of intermediates: not left in the tree

@@ -541,7 +541,8 @@ def test_embed_layernorm_kernel_matches_the_modules_own(encoder):
 
 def test_short_sequence_attention_kernel_matches_fp64():
     """ts_attention_short = softmax(Q K^T / 8 + key mask) V per (sequence, head) from the fused projection's layout, against the
-    same expression in fp64 on the same bf16 inputs: every tile count (1 .. 64 tokens, ragged lengths), with and without a key
+    same expression in fp64 on the same bf16 inputs: every tile count (1 .. 64 tokens: all score tiles at once; 65 .. 128: one
+    query tile at a time; ragged lengths), with and without a key
     mask (every sequence keeps at least its first token), a head count that does not fill the last workgroup; and against
     torch's scaled_dot_product_attention; longer sequences and other head sizes are refused."""
     import ctypes as C
@@ -550,7 +551,8 @@ def test_short_sequence_attention_kernel_matches_fp64():
     lib = _ffi.load()
     g = torch.Generator(device="cpu").manual_seed(11)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    for B, S, H in ((3, 1, 2), (5, 7, 3), (4, 16, 12), (9, 19, 5), (6, 32, 12), (3, 33, 2), (2, 48, 3), (5, 61, 7), (2, 64, 12)):
+    for B, S, H in ((3, 1, 2), (5, 7, 3), (4, 16, 12), (9, 19, 5), (6, 32, 12), (3, 33, 2), (2, 48, 3), (5, 61, 7), (2, 64, 12),
+                    (3, 65, 5), (2, 80, 12), (5, 81, 3), (2, 96, 7), (3, 100, 2), (2, 112, 6), (4, 127, 3), (3, 128, 12)):
         qkv = (torch.randn((B, S, 3, H, 64), generator=g) * 1.5).to(torch.bfloat16).cuda()
         lens = torch.randint(1, S + 1, (B,), generator=g)
         km = (torch.arange(S)[None, :] < lens[:, None]).to(torch.int64).cuda()
@@ -571,7 +573,7 @@ def test_short_sequence_attention_kernel_matches_fp64():
             ref = torch.nn.functional.scaled_dot_product_attention(*(qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3)), attn_mask=bias)
             ref = ref.transpose(1, 2).reshape(B, S, H * 64)
             assert (out.float() - ref.float()).abs().max().item() <= 4e-2
-    for S, hd in ((65, 64), (16, 32)):
+    for S, hd in ((129, 64), (16, 32)):
         with pytest.raises(_ffi.TSearchError):
             _ffi.check(lib.ts_attention_short(0, C.c_void_p(qkv.data_ptr()), None, 1, S, 1, hd, C.c_void_p(out.data_ptr()), st))
 

@@ -100,9 +100,9 @@ extern "C" int ts_attention_short(int device, const void* qkv, const int64_t* at
                                  int32_t head_dim, void* out, void* stream) {
     if (!qkv || !out) return fail(TS_ERR_INVALID, "NULL argument");
     if (batch < 0 || seq < 1 || heads < 1) return fail(TS_ERR_INVALID, "batch = %d, seq = %d, heads = %d", batch, seq, heads);
-    if (head_dim != 64 || seq > kAttnMaxSeq)
+    if (head_dim != 64 || seq > kAttnRowsMaxSeq)
         return fail(TS_ERR_UNSUPPORTED, "head size %d / %d tokens: this kernel serves head size 64 and at most %d tokens", head_dim, seq,
-                    kAttnMaxSeq);
+                    kAttnRowsMaxSeq);
     if ((((uintptr_t)qkv | (uintptr_t)out) & 15) != 0) return fail(TS_ERR_INVALID, "qkv and out must be 16-byte aligned");
     if (batch == 0) return TS_OK;
     TS_TRY(check_device(device));
@@ -111,12 +111,29 @@ extern "C" int ts_attention_short(int device, const void* qkv, const int64_t* at
     const unsigned grid = (unsigned)(((int64_t)batch * heads + 3) / 4);
     const unsigned short* in = (const unsigned short*)qkv;
     unsigned short* o = (unsigned short*)out;
+    // 65 .. 128 tokens: one query tile at a time (attention_rows_kernel, dynamic LDS: 4 waves x up to 22.5 KB)
+#define TS_ATTN_ROWS(T_)                                                                                                     \
+    do {                                                                                                                     \
+        constexpr int lds_ = 4 * attn_rows_wave_lds(T_);                                                                     \
+        static std::atomic<unsigned long long> attr_{0};                                                                     \
+        const unsigned long long bit_ = 1ull << (device & 63);                                                               \
+        if (!(attr_.load(std::memory_order_acquire) & bit_)) {                                                               \
+            HIP_TRY(hipFuncSetAttribute((const void*)attention_rows_kernel<T_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_)); \
+            attr_.fetch_or(bit_, std::memory_order_release);                                                                 \
+        }                                                                                                                    \
+        attention_rows_kernel<T_><<<grid, 256, lds_, st>>>(in, attention_mask, batch, seq, heads, o);                        \
+    } while (0)
     switch ((seq + 15) / 16) {
         case 1: attention_short_kernel<1><<<grid, 256, 0, st>>>(in, attention_mask, batch, seq, heads, o); break;
         case 2: attention_short_kernel<2><<<grid, 256, 0, st>>>(in, attention_mask, batch, seq, heads, o); break;
         case 3: attention_short_kernel<3><<<grid, 256, 0, st>>>(in, attention_mask, batch, seq, heads, o); break;
-        default: attention_short_kernel<4><<<grid, 256, 0, st>>>(in, attention_mask, batch, seq, heads, o); break;
+        case 4: attention_short_kernel<4><<<grid, 256, 0, st>>>(in, attention_mask, batch, seq, heads, o); break;
+        case 5: TS_ATTN_ROWS(5); break;
+        case 6: TS_ATTN_ROWS(6); break;
+        case 7: TS_ATTN_ROWS(7); break;
+        default: TS_ATTN_ROWS(8); break;
     }
+#undef TS_ATTN_ROWS
     HIP_TRY(hipGetLastError());
     return TS_OK;
 }

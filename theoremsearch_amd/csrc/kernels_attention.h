@@ -183,4 +183,161 @@ __global__ void __launch_bounds__(256) attention_short_kernel(const unsigned sho
     }
 }
 
+// ---- 65 .. 128 tokens: the same wave-per-(sequence, head) form, one 16-query tile at a time --------------------------------
+// Real inputs of the reference are `global_context + statement` (app_create_embeddings.py:48-70), which its own notes call long
+// (notes.md:3); SURVEY.md section 8d names 128 tokens as the second length of the encoder-in-loop measurement.  Holding every
+// score tile of a (sequence, head) at once would take T x T x 4 registers (256 at T = 8); here the K fragments (T x 2) and the
+// V^T fragments (4 x KS) stay in registers for the whole problem and the wave walks the query tiles: scores of ONE tile against
+// all keys (T x 4 registers) -> softmax over registers and quarter-wave shuffles, exactly as above (every key of a row is in
+// hand: no running maximum, no rescaling) -> P tile through wave-private LDS -> O^T tile -> whole 128-byte rows out.
+// LDS per wave: P tile [16][PP] + V^T [64][PP] + O tile [16][72], bf16: 22.5 KB at T = 8; one workgroup (4 waves) per CU.
+constexpr int kAttnRowsMaxSeq = 128;
+constexpr int attn_rows_wave_lds(int T) {
+    const int sp = 16 * T, ks = (sp + 31) / 32, pp = 32 * ks + 8;
+    return 16 * pp * 2 + 64 * pp * 2 + 16 * (64 + 8) * 2;
+}
+
+template <int T>
+__global__ void __launch_bounds__(256) attention_rows_kernel(const unsigned short* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                              int B, int S, int H, unsigned short* __restrict__ out) {
+    constexpr int SP = 16 * T;
+    constexpr int KS = (SP + 31) / 32;
+    constexpr int PP = 32 * KS + 8;
+    constexpr int OP = 64 + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bh = blockIdx.x * 4 + wave;
+    if (bh >= B * H) return;
+    const int b = bh / H, h = bh - b * H;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int64_t tok = (int64_t)3 * H * 64;
+    const unsigned short* base = qkv + (int64_t)b * S * tok + h * 64;
+    unsigned short* sP = (unsigned short*)(attn_smem + (size_t)wave * attn_rows_wave_lds(T));
+    unsigned short* sVT = sP + 16 * PP;
+    unsigned short* sO = sVT + 64 * PP;
+
+    // K fragments of every key tile, the first query tile's fragments and the V rows: all requested before the first use
+    bf16x8 kf[T][2], qf[2];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int row = min(16 * t + r16, S - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) kf[t][ks] = *(const bf16x8*)(base + row * tok + H * 64 + 32 * ks + 8 * g);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(base + min(r16, S - 1) * tok + 32 * ks + 8 * g);
+    constexpr int KP = SP / 2;
+    constexpr int VI = (KP + 7) / 8;
+    uint4 v0[VI], v1[VI];
+#pragma unroll
+    for (int i = 0; i < VI; ++i) {
+        const int kp = (lane >> 3) + 8 * i;
+        const int k0 = min(2 * kp, S - 1), k1 = min(2 * kp + 1, S - 1);
+        v0[i] = *(const uint4*)(base + k0 * tok + 2 * H * 64 + 8 * (lane & 7));
+        v1[i] = *(const uint4*)(base + k1 * tok + 2 * H * 64 + 8 * (lane & 7));
+    }
+    bool keyok[T];
+#pragma unroll
+    for (int kj = 0; kj < T; ++kj) {
+        const int key = 16 * kj + r16;
+        keyok[kj] = key < S && (!mask || mask[(int64_t)b * S + key] != 0);
+    }
+    // keys past the padded sequence inside the last 32-key step: zeros in P (never rewritten: the tile's stores stop at SP) and in V^T
+    for (int i = lane; i < 16 * PP / 8; i += 64) ((uint4*)sP)[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (KS * 32 > SP)
+        for (int i = lane; i < 64 * PP / 8; i += 64) ((uint4*)sVT)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < VI; ++i) {
+        const int kp = (lane >> 3) + 8 * i;
+        if (kp < KP) {
+            const u32 a[4] = {v0[i].x, v0[i].y, v0[i].z, v0[i].w}, c[4] = {v1[i].x, v1[i].y, v1[i].z, v1[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                u32* dst = (u32*)(sVT + (8 * (lane & 7) + 2 * e) * PP + 2 * kp);
+                dst[0] = (a[e] & 0xFFFFu) | (c[e] << 16);
+                *(u32*)((unsigned short*)dst + PP) = (a[e] >> 16) | (c[e] & 0xFFFF0000u);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    bf16x8 vf[4][KS];
+#pragma unroll
+    for (int dj = 0; dj < 4; ++dj)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) vf[dj][ks] = *(const bf16x8*)(sVT + (16 * dj + r16) * PP + 32 * ks + 8 * g);
+
+    constexpr float kScaleLog2e = 0.125f * 1.4426950408889634f;
+    unsigned short* obase = out + (int64_t)b * S * H * 64 + h * 64;
+    const int ntile = (S + 15) / 16;
+#pragma unroll 1
+    for (int qi = 0; qi < ntile; ++qi) {
+        // the next tile's query fragments are on their way while this one is worked on
+        bf16x8 qn[2];
+        const int nrow = min(16 * (qi + 1) + r16, S - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qn[ks] = *(const bf16x8*)(base + nrow * tok + 32 * ks + 8 * g);
+        f32x4 sc[T];
+#pragma unroll
+        for (int kj = 0; kj < T; ++kj) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf[kj][ks], a, 0, 0, 0);
+            sc[kj] = a;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int kj = 0; kj < T; ++kj) m = fmaxf(m, keyok[kj] ? sc[kj][r] : -INFINITY);
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            float e[T], sum = 0.0f;
+#pragma unroll
+            for (int kj = 0; kj < T; ++kj) {
+                e[kj] = keyok[kj] ? exp2f((sc[kj][r] - m) * kScaleLog2e) : 0.0f;
+                sum += e[kj];
+            }
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) sum += __shfl_xor(sum, off, 64);
+            const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;
+#pragma unroll
+            for (int kj = 0; kj < T; ++kj) sP[(4 * g + r) * PP + 16 * kj + r16] = f32_to_bf16(e[kj] * inv);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        bf16x8 pf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) pf[ks] = *(const bf16x8*)(sP + r16 * PP + 32 * ks + 8 * g);
+#pragma unroll
+        for (int dj = 0; dj < 4; ++dj) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dj][ks], pf[ks], a, 0, 0, 0);
+            const u32 lo = (u32)f32_to_bf16(a[0]) | ((u32)f32_to_bf16(a[1]) << 16);
+            const u32 hi = (u32)f32_to_bf16(a[2]) | ((u32)f32_to_bf16(a[3]) << 16);
+            *(uint2*)(sO + r16 * OP + 16 * dj + 4 * g) = make_uint2(lo, hi);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int i = lane; i < 16 * 8; i += 64) {
+            const int q = 16 * qi + (i >> 3), c = i & 7;
+            if (q < S) *(uint4*)(obase + (int64_t)q * H * 64 + 8 * c) = *(const uint4*)(sO + (i >> 3) * OP + 8 * c);
+        }
+        // the O tile has been read and the P tile's fragments are in registers: the next tile may overwrite both
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        qf[0] = qn[0];
+        qf[1] = qn[1];
+    }
+}
+
 }  // namespace ts

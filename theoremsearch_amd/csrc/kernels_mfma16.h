@@ -200,8 +200,11 @@ __device__ __forceinline__ void mfma16_append_block(const f32x4& a0, const f32x4
 // row (16x16x4: 32-cycle issue, 40-cycle dependent latency).  d = 1024: one block of 16 queries per wave (256 registers),
 // 64 queries per launch - the Qwen-sized fp32 tables; d = 768: one or two blocks, 64 or 128 queries per launch (the
 // 32x32x2 kernel of kernels_mfma_f32.h stays selectable: TS_MFMA_F32=32).
-template <int D, int NB, int VARIANT, bool SPARSE, bool F32 = false>
+// PAIR: the paired full pass (MfmaArgs::pair; a template parameter, not a run-time branch: the headline instantiation has no
+// register to spare for the pair's bookkeeping).
+template <int D, int NB, int VARIANT, bool SPARSE, bool F32 = false, bool PAIR = false>
 __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a) {
+    static_assert(!PAIR || (!SPARSE && !F32), "pairs exist for the bf16 full pass");
     constexpr int Deq = F32 ? 2 * D : D;                 // row length in 2-byte elements
     using dims = Mfma16Dims<Deq>;
     constexpr bool kNoEpi = VARIANT == 1 || VARIANT == 7;
@@ -230,10 +233,9 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     const int r16 = lane & 15, kq = lane >> 4;
     // paired full pass (MfmaArgs::pair): workgroups w and w + 8 of every group of 16 walk the same tiles with the two halves
     // of the query batch; `wg` numbers the pairs
-    const bool paired = !SPARSE && a.pair != 0;
-    const int wg = paired ? (int)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) : (int)blockIdx.x;
-    const int qhalf = paired ? (int)((blockIdx.x >> 3) & 1) : 0;
-    const int G = paired ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+    const int wg = PAIR ? (int)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) : (int)blockIdx.x;
+    const int qhalf = PAIR ? (int)((blockIdx.x >> 3) & 1) : 0;
+    const int G = PAIR ? (int)(gridDim.x >> 1) : (int)gridDim.x;
     const int nwriters = 4 * gridDim.x;
     const int writer = 4 * blockIdx.x + kq;
     int qid[NB];

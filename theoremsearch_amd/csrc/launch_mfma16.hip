@@ -55,8 +55,29 @@ static int launch_mfma16(bool full_pass, int variant, int grid, hipStream_t st, 
 }
 
 
+// The paired full pass of d = 1024 (MfmaArgs::pair): 128 queries per workgroup, two workgroups per tile range.
+static int launch_mfma16_pair(int grid, hipStream_t st, const MfmaArgs& a) {
+    constexpr int lds = Mfma16Dims<1024>::kLds + kMfma16StageBytes;
+    static std::atomic<unsigned long long> attr_done{0};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<1024, 2, 0, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_done.fetch_or(bit, std::memory_order_release);
+    }
+    if (grid % 16 != 0) return fail(TS_ERR_INTERNAL, "the paired pass needs a grid of whole groups of 16 workgroups, not %d", grid);
+    mfma16_topk_kernel<1024, 2, 0, false, false, true><<<grid, kMfmaThreads, lds, st>>>(a);
+    HIP_TRY(hipGetLastError());
+    return TS_OK;
+}
+
 // d = 384 / 512 / 768 / 1024, nb = query blocks of 16 per wave (64 * nb queries per launch; d = 1024: at most 3)
 int launch_pass_mfma16(int d, int nb, bool full_pass, int variant, int grid, hipStream_t st, const MfmaArgs& a) {
+    if (a.pair) {
+        if (d != 1024 || nb != 2 || !full_pass) return fail(TS_ERR_INTERNAL, "paired pass asked for d = %d, %d blocks per wave", d, nb);
+        return launch_mfma16_pair(grid, st, a);
+    }
 #define TS_NB_SWITCH(D_)                                                          \
     switch (nb) {                                                                 \
         case 1: return launch_mfma16<D_, 1>(full_pass, variant, grid, st, a);     \

@@ -489,7 +489,7 @@ class FusedBertForward:
     * ``LayerNorm(dense_out + input)`` as ONE HIP kernel (``ts_add_layernorm``) instead of an add and a layer_norm launch
       (18 + 7 us of device time twice per layer);
     * the input layer (three embedding gathers, two adds, LayerNorm) as ONE HIP kernel (``ts_embed_layernorm``);
-    * for bf16 models with 64-wide heads and at most 64 tokens, the attention as ONE wave per (sequence, head)
+    * for bf16 models with 64-wide heads and at most 128 tokens, the attention as ONE wave per (sequence, head)
       (``ts_attention_short``; ``TS_ENCODER_ATTENTION=0`` keeps ``scaled_dot_product_attention``).
 
     Same weights, same order of operations, exact erf GELU (whatever ``config.hidden_act`` names); the attention is
@@ -600,7 +600,7 @@ class FusedBertForward:
         # padding (every sequence as long as the batch: 50 instead of 60 us per layer for projections + attention)
         # short sequences (one sentence per query: app_showcase_model.py:92) of a bf16 model with 64-wide heads: the attention as
         # ONE wave per (sequence, head), straight from the fused projection to the context layout (``ts_attention_short``)
-        short = x.dtype == torch.bfloat16 and hd == 64 and S <= 64 and os.environ.get("TS_ENCODER_ATTENTION", "1") != "0"
+        short = x.dtype == torch.bfloat16 and hd == 64 and S <= 128 and os.environ.get("TS_ENCODER_ATTENTION", "1") != "0"
         # (the most negative finite value, not -inf: a sequence without a single token would otherwise soften to NaN)
         mask = None if (no_padding or short) else torch.zeros((B, 1, 1, S), dtype=x.dtype, device=x.device).masked_fill_(
             ~attention_mask[:, None, None, :].to(torch.bool), torch.finfo(x.dtype).min)
