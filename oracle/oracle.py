@@ -45,9 +45,33 @@ EPS = np.float32(1e-12)
 # bf16 helpers (round-to-nearest-even, NaN kept a NaN)
 # ----------------------------------------------------------------------------
 
-def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
-    """fp32 -> bf16 bit patterns (uint16), round-to-nearest-even; NaN stays NaN."""
-    x = np.ascontiguousarray(x, dtype=np.float32)
+def _threads() -> int:
+    import os
+    try:
+        return max(1, min(16, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        return max(1, min(16, os.cpu_count() or 1))
+
+
+def _by_row_blocks(fn, x: np.ndarray, out: np.ndarray, rows: int = 16384) -> np.ndarray:
+    """``out[r0:r1] = fn(x[r0:r1])`` over blocks of rows, on a few threads for large inputs (numpy's elementwise loops
+    release the GIL; a 2.5M x 768 corpus is ten passes over 7.7 GB otherwise)."""
+    n = x.shape[0] if x.ndim >= 1 else 0
+    if x.ndim < 2 or x.size < (1 << 22):
+        out[...] = fn(x)
+        return out
+    blocks = [(r0, min(n, r0 + rows)) for r0 in range(0, n, rows)]
+
+    def one(b):
+        out[b[0]:b[1]] = fn(x[b[0]:b[1]])
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(_threads()) as ex:
+        list(ex.map(one, blocks))
+    return out
+
+
+def _bf16_bits_block(x: np.ndarray) -> np.ndarray:
     u = x.view(np.uint32)
     rounded = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)).astype(np.uint16)
     nan = np.isnan(x)
@@ -56,14 +80,22 @@ def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
     return rounded
 
 
+def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    """fp32 -> bf16 bit patterns (uint16), round-to-nearest-even; NaN stays NaN."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    return _by_row_blocks(_bf16_bits_block, x, np.empty(x.shape, dtype=np.uint16))
+
+
 def bf16_bits_to_f32(b: np.ndarray) -> np.ndarray:
     b = np.ascontiguousarray(b, dtype=np.uint16)
-    return (b.astype(np.uint32) << np.uint32(16)).view(np.float32)
+    return _by_row_blocks(lambda v: (v.astype(np.uint32) << np.uint32(16)).view(np.float32), b, np.empty(b.shape, dtype=np.float32))
 
 
 def round_to_bf16(x: np.ndarray) -> np.ndarray:
     """fp32 values rounded to the nearest bf16, returned as fp32."""
-    return bf16_bits_to_f32(f32_to_bf16_bits(x))
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    return _by_row_blocks(lambda v: (_bf16_bits_block(v).astype(np.uint32) << np.uint32(16)).view(np.float32), x,
+                          np.empty(x.shape, dtype=np.float32))
 
 
 # ----------------------------------------------------------------------------
@@ -87,10 +119,13 @@ def l2_normalize(x: np.ndarray) -> np.ndarray:
     oracle fixes this one.  A zero row stays zero.
     """
     x = _as_2d(x).astype(np.float32, copy=False)
-    ss = np.einsum("ij,ij->i", x, x, dtype=np.float64)
-    norm = np.sqrt(ss).astype(np.float32)
-    denom = np.maximum(norm, EPS)
-    return (x / denom[:, None]).astype(np.float32)
+
+    def block(v):
+        ss = np.einsum("ij,ij->i", v, v, dtype=np.float64)
+        denom = np.maximum(np.sqrt(ss).astype(np.float32), EPS)
+        return (v / denom[:, None]).astype(np.float32)
+
+    return _by_row_blocks(block, x, np.empty(x.shape, dtype=np.float32))
 
 
 def dot_scores(q: np.ndarray, c: np.ndarray) -> np.ndarray:
@@ -107,7 +142,13 @@ def cos_sim(a, b) -> np.ndarray:
 
 def scores_fp64(q: np.ndarray, c: np.ndarray) -> np.ndarray:
     """fp64 "truth" inner products of the same (possibly bf16-rounded) inputs."""
-    return _as_2d(q).astype(np.float64) @ _as_2d(c).astype(np.float64).T
+    q64, c = _as_2d(q).astype(np.float64), _as_2d(c)
+    if c.size < (1 << 22):
+        return q64 @ c.astype(np.float64).T
+    out = np.empty((q64.shape[0], c.shape[0]), dtype=np.float64)       # block by block: no fp64 copy of the whole corpus
+    for r0 in range(0, c.shape[0], 65536):
+        out[:, r0:r0 + 65536] = q64 @ c[r0:r0 + 65536].astype(np.float64).T
+    return out
 
 
 # ----------------------------------------------------------------------------
@@ -158,8 +199,8 @@ def search(q: np.ndarray, c: np.ndarray, k: int, metric: str = "ip",
     dtype "bf16": corpus rows and queries are rounded to bf16 (after the
     normalisation) and the product is taken in fp32 on the rounded values.
     """
-    q = _as_2d(q).astype(np.float32)
-    c = _as_2d(c).astype(np.float32)
+    q = _as_2d(q).astype(np.float32, copy=False)
+    c = _as_2d(c).astype(np.float32, copy=False)
     if metric == "cos":
         q, c = l2_normalize(q), l2_normalize(c)
     elif metric != "ip":
@@ -173,8 +214,8 @@ def search(q: np.ndarray, c: np.ndarray, k: int, metric: str = "ip",
 
 def prepared_inputs(q, c, metric="ip", dtype="f32"):
     """The exact operand values ``search`` multiplies (for fp64 truth checks)."""
-    q = _as_2d(q).astype(np.float32)
-    c = _as_2d(c).astype(np.float32)
+    q = _as_2d(q).astype(np.float32, copy=False)
+    c = _as_2d(c).astype(np.float32, copy=False)
     if metric == "cos":
         q, c = l2_normalize(q), l2_normalize(c)
     if dtype == "bf16":
@@ -245,8 +286,15 @@ def check_topk_against_truth(truth_scores: np.ndarray, got_idx: np.ndarray,
         if kk == 0:          # nothing to rank (empty corpus): the answer is all padding
             assert np.all(gi[b] == -1), f"query {b}: padding must be -1"
             continue
-        order = np.lexsort((np.arange(N), -row))
-        ext = order[: min(N, kk + 64)]
+        # the kk + 64 best rows in canonical order (score descending, index ascending): every row that reaches the
+        # m-th best score is a candidate (ties at the cut included), and only those are sorted
+        m = min(N, kk + 64)
+        if m < N:
+            cut = -np.partition(-row, m - 1)[m - 1]
+            cands = np.flatnonzero(row >= cut)
+        else:
+            cands = np.arange(N)
+        ext = cands[np.lexsort((cands, -row[cands]))][:m]
         gs_row = None if got_scores is None else _as_2d(got_scores)[b]
         p, h = _check_one_query(b, ext, row[ext], lambda j: row[j], gi[b, :kk], gs_row, kk, k, gap, score_tol)
         pinned_total += p
@@ -603,6 +651,34 @@ def golden_inputs(N: int, B: int, d: int, seed: int, metric: str):
         c *= s
         q *= s
     return q, c
+
+
+def fast_inputs(N: int, B: int, d: int, seed: int, metric: str):
+    """`golden_inputs`' recipe with the corpus drawn block by block from independent streams on a few threads: for the
+    large cases of the GPU tests, which no committed fixture depends on (one stream takes 8 s for 310,000 x 768)."""
+    from concurrent.futures import ThreadPoolExecutor
+    c = np.empty((N, d), dtype=np.float32)
+    blocks = [(r0, min(N, r0 + 32768)) for r0 in range(0, N, 32768)]
+
+    def one(b):
+        rng = np.random.default_rng([seed, 0, b[0]])
+        rng.standard_normal(out=c[b[0]:b[1]], dtype=np.float32)
+        if metric == "cos":
+            c[b[0]:b[1]] *= rng.uniform(0.25, 4.0, size=(b[1] - b[0], 1)).astype(np.float32)
+        else:
+            c[b[0]:b[1]] *= np.float32(1.0 / math.sqrt(d))
+
+    with ThreadPoolExecutor(_threads()) as ex:
+        list(ex.map(one, blocks))
+    q = np.random.default_rng([seed, 1]).standard_normal((B, d), dtype=np.float32)
+    if metric != "cos":
+        q *= np.float32(1.0 / math.sqrt(d))
+    return q, c
+
+
+def inputs(N: int, B: int, d: int, seed: int, metric: str):
+    """Seeded test inputs: the fixtures' own generator for small cases, the threaded one from 2^24 corpus values up."""
+    return fast_inputs(N, B, d, seed, metric) if N * d >= (1 << 24) else golden_inputs(N, B, d, seed, metric)
 
 
 # ----------------------------------------------------------------------------

@@ -45,7 +45,7 @@ def one_case(rng, big: bool, case: int = 0, watchdog: bool = True) -> str:
     if watchdog:
         faulthandler.dump_traceback_later(300 if big else 120, exit=True)
     t0 = time.time()
-    q, c = oracle.golden_inputs(n, nq, d, seed, metric)
+    q, c = oracle.inputs(n, nq, d, seed, metric)
     if rng.random() < 0.15 and n > 100:              # duplicates: exact ties
         c[rng.integers(0, n, 20)] = c[0]
     if big and rng.random() < 0.5:              # a cluster near the queries: heavy upper tail

@@ -30,7 +30,7 @@ def check(q, c, metric, dtype, k, scores, idx):
 def test_append_grows_the_index_and_searches_like_a_rebuild(ts, dtype, metric):
     """New slogan_ids of the upsert pipeline (ec2/generate_embeddings/__main__.py:85-99: INSERT ... ON CONFLICT DO
     UPDATE) are appended; the grown index answers bit for bit like one built from all the rows at once."""
-    q, c = oracle.golden_inputs(40_000, 9, 768, 5, metric)
+    q, c = oracle.inputs(40_000, 9, 768, 5, metric)
     with ts.TheoremIndex.from_embeddings(c[:1000], dtype=dtype, metric=metric) as ix:
         assert ix.append(c[1000:1003]) == 1000            # fits the padding of the first allocation
         assert ix.append(c[1003:20_000]) == 1003          # forces a move to a larger allocation
@@ -51,7 +51,7 @@ def test_append_grows_the_index_and_searches_like_a_rebuild(ts, dtype, metric):
 
 def test_append_is_refused_while_views_exist_and_on_derived_indexes(ts):
     from theoremsearch_amd import _ffi
-    q, c = oracle.golden_inputs(2000, 2, 768, 6, "ip")
+    q, c = oracle.inputs(2000, 2, 768, 6, "ip")
     with ts.TheoremIndex.from_embeddings(c[:300], metric="ip") as ix:
         v = ix.view()
         with pytest.raises(_ffi.TSearchError) as e:
@@ -75,7 +75,7 @@ def test_append_is_refused_while_views_exist_and_on_derived_indexes(ts):
 
 def test_append_device_rows_with_row_offset(ts):
     import torch
-    q, c = oracle.golden_inputs(5000, 3, 768, 8, "cos")
+    q, c = oracle.inputs(5000, 3, 768, 8, "cos")
     with ts.TheoremIndex(0, 768, dtype="bf16", metric="cos", row_offset=1_000_000) as ix:
         dev = torch.from_numpy(c).cuda()
         s = torch.cuda.Stream()
@@ -92,7 +92,7 @@ def test_attach_device_rows_zero_copy(ts):
     import torch
     from theoremsearch_amd import _ffi
     n, d = 100_000, 768
-    q, c = oracle.golden_inputs(n, 40, d, 31, "ip")
+    q, c = oracle.inputs(n, 40, d, 31, "ip")
     cap = (n + 255) // 256 * 256
     dev = torch.zeros((cap, d), dtype=torch.bfloat16, device="cuda")
     dev[:n] = torch.from_numpy(c).cuda().to(torch.bfloat16)            # RNE, like the library's own rounding
@@ -117,7 +117,7 @@ def test_calls_on_different_streams_share_the_scratch_safely(ts):
     """Two searches enqueued back to back on two different streams of one handle, device outputs: the second must not
     overwrite scratch the first still reads (per-handle scratch across streams)."""
     import torch
-    q, c = oracle.golden_inputs(120_000, 256, 768, 9, "ip")
+    q, c = oracle.inputs(120_000, 256, 768, 9, "ip")
     with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as ix:
         want_s, want_i = ix.search(q, 10)
         qa = torch.from_numpy(q).cuda()
@@ -158,7 +158,7 @@ def test_upload_reads_rows_produced_on_the_default_stream(ts):
 
 def test_options_are_per_handle(ts):
     from theoremsearch_amd import _ffi
-    q, c = oracle.golden_inputs(70_000, 40, 768, 4, "ip")
+    q, c = oracle.inputs(70_000, 40, 768, 4, "ip")
     with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as a, \
             ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as b:
         a.set_option("TS_MFMA_STAT", 0)                     # the chain of guaranteed bounds: more levels
@@ -179,7 +179,7 @@ def test_shards_on_one_device_answer_like_the_whole_index(ts, ngpu):
     RCCL refuses two ranks on one GPU), routed uploads, packed per-shard results, merge: bit-identical to one index."""
     from theoremsearch_amd.distributed import Shards
     n, k = 90_001, 10
-    q, c = oracle.golden_inputs(n, 33, 768, 12, "ip")
+    q, c = oracle.inputs(n, 33, 768, 12, "ip")
     c[70_000] = c[5]                                        # an exact tie across shards: the lower global id ranks first
     with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as whole:
         want_s, want_i = whole.search(q, k)
@@ -202,7 +202,7 @@ def test_comm_of_one_rank_runs_the_rccl_exchange(ts):
     from theoremsearch_amd import _ffi
     _ffi.prefer_torch_rccl()
     lib = _ffi.load()
-    q, c = oracle.golden_inputs(50_000, 17, 768, 13, "cos")
+    q, c = oracle.inputs(50_000, 17, 768, 13, "cos")
     ident = C.create_string_buffer(128)
     _ffi.check(lib.ts_comm_unique_id(ident, 128))
     comm = C.c_void_p()
@@ -231,7 +231,7 @@ def test_sharded_searcher_device_pipeline_with_changing_queries(ts, pipeline):
     import torch
     from theoremsearch_amd.distributed import ShardedSearcher
     n, nq, k = 150_000, 64, 10
-    _, c = oracle.golden_inputs(n, 1, 768, 21, "ip")
+    _, c = oracle.inputs(n, 1, 768, 21, "ip")
     rng = np.random.default_rng(5)
     batches = [rng.standard_normal((nq, 768)).astype(np.float32) for _ in range(6)]
     with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as ix:
@@ -263,7 +263,7 @@ def test_sharded_pipeline_reads_a_query_buffer_that_the_caller_rewrites_every_st
     import torch
     from theoremsearch_amd.distributed import ShardedSearcher
     n, nq, k = 400_000, 64, 10
-    _, c = oracle.golden_inputs(n, 1, 768, 22, "ip")
+    _, c = oracle.inputs(n, 1, 768, 22, "ip")
     rng = np.random.default_rng(6)
     batches = [oracle.bf16_bits_to_f32(oracle.f32_to_bf16_bits(rng.standard_normal((nq, 768)).astype(np.float32))) for _ in range(8)]
     with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as ix:
@@ -290,7 +290,7 @@ def test_answers_do_not_move_with_the_tile_shares_of_the_full_pass(ts):
     """The full pass takes each workgroup's tile range from a table that the final select moves after every search
     (towards equal finishing times of the XCDs).  Same queries, ten searches in a row: the table moves, the answers may
     not; an append changes the number of tiles and the table starts again from equal shares."""
-    q, c = oracle.golden_inputs(400_000, 200, 768, 909, "ip")
+    q, c = oracle.inputs(400_000, 200, 768, 909, "ip")
     with ts.TheoremIndex(300_000, 768, dtype="bf16", metric="ip") as ix:
         ix.upload(c[:300_000], 0)
         s0, i0, st = ix.search(q, 10, algo="mfma", return_stats=True)
@@ -366,7 +366,7 @@ def test_a_callers_stream_may_be_destroyed_after_its_own_sync(ts):
     """the library must not touch a caller's stream after the call that was given it has returned - the next
     call (on another stream), ts_index_synchronize and ts_index_destroy only use the order event."""
     import torch
-    q, c = oracle.golden_inputs(50_000, 64, 768, 41, "ip")
+    q, c = oracle.inputs(50_000, 64, 768, 41, "ip")
     qd = torch.from_numpy(q).cuda()
     with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as ix:
         want_s, want_i = ix.search(q, 10)
@@ -412,7 +412,7 @@ def test_biased_search_is_the_citation_weighted_ranking_over_all_rows(ts, dtype,
     reference's max(50, 10 k) pool never sees)."""
     from theoremsearch_amd import pgvector
     n, nq, k, w = 20_000, 6, 10, 0.02
-    q, c = oracle.golden_inputs(n, nq, d, 300 + d, "ip")
+    q, c = oracle.inputs(n, nq, d, 300 + d, "ip")
     rng = np.random.default_rng(9)
     cites = [None if u < 0.1 else (0 if u < 0.2 else int(v)) for u, v in zip(rng.random(n), rng.integers(1, 400, n))]
     for r in rng.choice(n, 12, replace=False):
@@ -458,7 +458,7 @@ def test_pgvector_adapter_exact_form_equals_the_pool_form_when_the_pool_holds_th
     heavily cited theorem lies outside the pool."""
     from theoremsearch_amd import pgvector
     n, d, k = 8_000, 768, 5
-    q, c = oracle.golden_inputs(n, 1, d, 77, "ip")
+    q, c = oracle.inputs(n, 1, d, 77, "ip")
     rng = np.random.default_rng(3)
     cites = [int(v) for v in rng.integers(1, 4, n)]              # ln <= 1.1: with w = 0.001 a nudge among near neighbours
     with ts.TheoremIndex.from_embeddings(c, dtype="f32", metric="ip") as ix:
@@ -478,7 +478,7 @@ def test_biased_search_argument_checks(ts):
     import ctypes as C
     from theoremsearch_amd import _ffi
     lib = _ffi.load()
-    q, c = oracle.golden_inputs(3000, 2, 768, 5, "ip")
+    q, c = oracle.inputs(3000, 2, 768, 5, "ip")
     with ts.TheoremIndex.from_embeddings(c, metric="ip") as ix:
         bias = np.zeros(3000, np.float32)
         with pytest.raises(ValueError):

@@ -21,7 +21,7 @@ def encoder():
 
 def test_cos_sim_and_semantic_search_match_oracle():
     from theoremsearch_amd import util
-    q, c = oracle.golden_inputs(2000, 9, 768, 61, "cos")
+    q, c = oracle.inputs(2000, 9, 768, 61, "cos")
     got = util.cos_sim(q, c)
     assert np.max(np.abs(got - oracle.cos_sim(q, c))) <= 1e-5
     assert util.cos_sim(q[0], c[:5]).shape == (1, 5)                      # 1-D promoted like util.cos_sim
@@ -34,7 +34,7 @@ def test_encoder_similarity_is_the_cosine_matrix(encoder):
     """SentenceEncoder.similarity = SentenceTransformer.similarity as experiments/first_experiment.py:195,205 call it: the cosine
     matrix of two embedding sets (1-D promoted), a torch tensor; a checkpoint that names the dot product gets that."""
     import torch
-    a, b = oracle.golden_inputs(300, 5, 768, 17, "cos")
+    a, b = oracle.inputs(300, 5, 768, 17, "cos")
     got = encoder.similarity(a, b)
     assert isinstance(got, torch.Tensor) and tuple(got.shape) == (5, 300) and got.dtype == torch.float32
     assert np.max(np.abs(got.numpy() - oracle.cos_sim(a, b))) <= 1e-5
@@ -174,7 +174,7 @@ def test_concurrent_searches_on_one_handle():
     # Streamlit runs every session on its own thread against one shared library (streamlit_app.py:52)
     import threading
     import theoremsearch_amd as ts
-    q, c = oracle.golden_inputs(60_000, 64, 768, 91, "ip")
+    q, c = oracle.inputs(60_000, 64, 768, 91, "ip")
     want_s, want_i = oracle.search(q, c, 5, "ip", "bf16")
     errors = []
     with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as ix:
@@ -244,7 +244,7 @@ def _gpu_rank(rank, world, port, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))       # both ranks share the one GPU of the box
     try:
         from theoremsearch_amd.distributed import ShardedSearcher, shard_bounds
-        q, c = oracle.golden_inputs(30_000, 12, 768, 81, "ip")
+        q, c = oracle.inputs(30_000, 12, 768, 81, "ip")
         lo, hi = shard_bounds(len(c), world, rank)
         searcher = ShardedSearcher.from_local_rows(c[lo:hi], len(c), dtype="bf16", metric="ip")
         scores, idx = searcher.search(q, 10)
@@ -279,7 +279,7 @@ def test_index_from_a_pgvector_copy_stream_searches_like_the_matrix():
     import theoremsearch_amd as ts
     from theoremsearch_amd import pgvector
     n, d = 3000, 768
-    q, c = oracle.golden_inputs(n, 3, d, 17, "ip")
+    q, c = oracle.inputs(n, 3, d, 17, "ip")
     txt = "".join(f"{i}\t[{','.join(repr(float(v)) for v in row)}]\n" for i, row in enumerate(c)).encode()
     chunks = [txt[lo:lo + 1_000_003] for lo in range(0, len(txt), 1_000_003)]
     with pgvector.index_from_copy_stream(chunks, n, d) as ix, ts.TheoremIndex.from_embeddings(c, metric="ip") as ref:
@@ -294,7 +294,7 @@ def test_two_threads_share_one_index():
     import threading
     import theoremsearch_amd as ts
     n, d = 40000, 768
-    q, c = oracle.golden_inputs(n, 64, d, 23, "cos")
+    q, c = oracle.inputs(n, 64, d, 23, "cos")
     with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="cos") as ix:
         want = [ix.search(q[:1], 10), ix.search(q, 10)]
         errors = []
@@ -354,7 +354,7 @@ def test_pgvector_search_with_a_where_mask():
     from theoremsearch_amd import filters as flt
     from theoremsearch_amd import pgvector
     n, d = 5000, 768
-    q, e = oracle.golden_inputs(n, 1, d, 29, "ip")
+    q, e = oracle.inputs(n, 1, d, 29, "ip")
     rows = make_sql_rows(n)
     cit = [r["citations"] for r in rows]
     with ts.TheoremIndex.from_embeddings(e, metric="ip") as ix:
@@ -379,7 +379,7 @@ def test_view_handles_search_the_same_rows_concurrently():
     import threading
     import theoremsearch_amd as ts
     n, d = 50000, 768
-    q, c = oracle.golden_inputs(n, 48, d, 37, "cos")
+    q, c = oracle.inputs(n, 48, d, 37, "cos")
     with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="cos", row_offset=77) as ix:
         want = ix.search(q, 10)
         with ix.view() as v:

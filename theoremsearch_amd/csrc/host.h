@@ -101,8 +101,8 @@ struct ts_index {
     u64* cand = nullptr;        u32* count = nullptr;        float* thr = nullptr;
     u64* priv = nullptr;        u32* pcount = nullptr;       int priv_writers = 0;  // MFMA path: lane-private candidate lists
     float* sample = nullptr;                                 // MFMA path: dense [256 x 8192] score matrix of the threshold sample
-    bool rebalance_pending = false; int rebalance_grid = 0;  // the exact re-run's launch also moves the full pass's tile boundaries
-    int* fb_list = nullptr;     int* fb_count = nullptr;     unsigned long long* stat = nullptr;
+    bool rebalance_pending = false, rebalance_in_rerun = false; int rebalance_grid = 0;  // the exact re-run's launch also moves the full pass's tile boundaries
+    int* fb_list = nullptr;     int* fb_count = nullptr;     u32* stat = nullptr;   // [kQBlock] candidates per query of the last final select
     u64* partial = nullptr;     u64* partial2 = nullptr;     size_t partial_bytes = 0;
     float* res_scores = nullptr; int64_t* res_idx = nullptr; size_t res_cap = 0;  // device result buffers (entries)
     u32* mask_dev = nullptr;    size_t mask_bytes = 0;       // filtered search: device copy of a host bitmask

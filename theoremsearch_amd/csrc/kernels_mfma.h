@@ -100,7 +100,6 @@ struct MfmaArgs {
     int first_level;
     int nq_real;
     int* fb_count;
-    unsigned long long* stat;
     // full pass of the 16x16 kernel: tile ranges of the workgroups from a table instead of equal shares (part[w] .. part[w+1]),
     // and the time each workgroup took (100 MHz ticks) - the final select moves the boundaries for the next search
     const int64_t* part;
@@ -119,7 +118,6 @@ __device__ __forceinline__ float mfma_level_thr(const MfmaArgs& a, int qid) {
 __device__ __forceinline__ void mfma_level_begin(const MfmaArgs& a) {
     if (a.first_level && blockIdx.x == 0 && threadIdx.x == 0) {
         *a.fb_count = 0;
-        *a.stat = 0ull;
     }
 }
 

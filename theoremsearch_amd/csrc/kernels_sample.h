@@ -12,9 +12,9 @@
 //     six dependent HBM round trips, 22 us at 4,096 rows and 44 us at 8,192);
 //   * the queries come from L2 (every workgroup reads the same 393 KB) as MFMA B fragments, one 16-byte load per k-step
 //     and lane, all of a 64-query chunk in flight at once; wave w holds queries 16 w .. 16 w + 15 of the chunk;
-//   * a workgroup serves `chunks_per_wg` query chunks in turn (the host passes 1: 4,096 rows x 256 queries = 128 row
-//     groups x 4 chunks = 512 workgroups, two to a CU; a first cut with every chunk looped inside 64 workgroups of 64 rows
-//     took 36 us against 15 for this shape: the chunks are independent work).
+//   * one workgroup per (32 rows, 64-query chunk): 4,096 rows x 256 queries = 128 row groups x 4 chunks = 512 workgroups,
+//     two to a CU (a first cut with every chunk looped inside 64 workgroups of 64 rows took 36 us against 15 for this
+//     shape: the chunks are independent work); the chunk's query fragments are requested before the rows (round 4).
 //
 // Arithmetic: v_mfma_f32_16x16x32_bf16 (bf16 rows) or v_mfma_f32_16x16x4_f32 (fp32 rows: float i of a 16-byte chunk times
 // float i of the matching query chunk, as the full pass does).  The sums may differ from the full pass's in the order of
@@ -37,22 +37,31 @@ struct SampleArgs {
     const u32* row_mask;      // optional filter: disallowed rows score -inf (the sample sees the allowed rows only)
     float* scores;            // [64 * ceil(nq / 64)][row_stride]
     int row_stride;           // sample positions per query row of `scores` (multiple of 64, >= 32 * ntiles)
-    int chunks_per_wg;        // query chunks of 64 one workgroup serves (grid.y = ceil(chunks / chunks_per_wg))
     int* fb_count;            // per-search counters, reset here (this is the first launch of a search)
-    unsigned long long* stat;
+    // optional: tile boundaries of the previous search's full pass to rebalance (grid.y = chunks + 1 then)
+    int64_t* part;
+    const unsigned* wg_ticks;
+    int part_g;
+    float part_gain;
 };
 
 constexpr int kSampleRowPad = 16;                                   // bytes: rows land 4 banks apart, the 16-row reads spread out
 constexpr int sample_lds_bytes(int rows, int row_bytes) { return rows * (row_bytes + kSampleRowPad); }
 
-// RB = row blocks of 16 per workgroup (2: 32 rows).  grid = (row_stride / (16 RB), ceil(chunks / chunks_per_wg)),
-// 256 threads, dynamic LDS = sample_lds_bytes(16 RB, ld * elem).
+// RB = row blocks of 16 per workgroup (2: 32 rows).  grid = (row_stride / (16 RB), query chunks of 64 [+ 1]), 256 threads,
+// dynamic LDS = sample_lds_bytes(16 RB, ld * elem).  Row y = chunks of the grid exists when `part` is set: its first
+// workgroup moves the tile boundaries of the PREVIOUS search's full pass (rebalance_tiles, common.h) while the others score
+// - the job used to ride on the empty re-run launch behind the pass, where it was that launch's whole duration.
 template <bool F32, int RB>
 __global__ void __launch_bounds__(256) sample_scores_kernel(SampleArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char srows[];
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         *a.fb_count = 0;
-        *a.stat = 0ull;
+    }
+    const int nchunks = (a.nq + 63) / 64;
+    if ((int)blockIdx.y >= nchunks) {
+        if (blockIdx.x == 0 && a.part) rebalance_tiles(a.part, a.wg_ticks, a.part_g, a.part_gain, (double*)srows);
+        return;
     }
     constexpr int kRows = 16 * RB;
     constexpr int kElem = F32 ? 4 : 2;
@@ -71,6 +80,14 @@ __global__ void __launch_bounds__(256) sample_scores_kernel(SampleArgs a) {
         const int64_t gt = (a.run == 1) ? j * a.tile_stride : (j / a.run) * a.run * a.tile_stride + j % a.run;
         return gt * kTileRows + (p & 31);
     };
+    // the query fragments of the first segment (bf16: all of them up to d = 1024) are requested BEFORE the rows: they come
+    // from L2 and do not depend on anything, so their round trip runs beside the rows' trip to HBM instead of behind it
+    const int qrow = (int)blockIdx.y * 64 + wave * 16 + r16;      // this lane's query (B operand) and output column
+    const unsigned char* brow = (const unsigned char*)a.q + ((int64_t)qrow * a.ld + (F32 ? 4 : 8) * kq) * kElem;
+    uint4 bv[kSeg];
+#pragma unroll
+    for (int s = 0; s < kSeg; ++s)
+        if (s < steps) bv[s] = *(const uint4*)(brow + (int64_t)s * 64);
     // rows -> LDS by LDS-DMA (no registers, no compiler-made waits): wave w moves rows w, w + 4, ... in pieces of 64 lanes x
     // 16 bytes - whole 128-byte lines per request, every piece of every row in flight before the single wait below
     {
@@ -91,7 +108,7 @@ __global__ void __launch_bounds__(256) sample_scores_kernel(SampleArgs a) {
     const unsigned char* arow[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) arow[rb] = srows + (16 * rb + r16) * pitch + kq * 16;
-    // validity of this lane's output positions (the same for every query chunk)
+    // validity of this lane's output positions
     bool ok[RB][4];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
@@ -101,55 +118,50 @@ __global__ void __launch_bounds__(256) sample_scores_kernel(SampleArgs a) {
             const int64_t row = row_of(p);
             ok[rb][g] = p < npos && row < a.n && (!a.row_mask || ((a.row_mask[row >> 5] >> (row & 31)) & 1u));
         }
-    const int nchunks = (a.nq + 63) / 64;
-    const int c_begin = blockIdx.y * a.chunks_per_wg, c_end = min(nchunks, c_begin + a.chunks_per_wg);
-    for (int ch = c_begin; ch < c_end; ++ch) {
-        const int qrow = ch * 64 + wave * 16 + r16;               // this lane's query (B operand) and output column
-        const unsigned char* brow = (const unsigned char*)a.q + ((int64_t)qrow * a.ld + (F32 ? 4 : 8) * kq) * kElem;
-        f32x4 acc[RB];
+    f32x4 acc[RB];
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // k in segments of at most kSeg k-steps (bf16: one segment up to d = 1024; fp32: two): a segment's query fragments
-        // are all requested before its first MFMA
-        for (int s0 = 0; s0 < steps; s0 += kSeg) {
-            uint4 bv[kSeg];
+    for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // k in segments of at most kSeg k-steps (bf16: one segment up to d = 1024; fp32: two): a segment's query fragments
+    // are all requested before its first MFMA
+    for (int s0 = 0; s0 < steps; s0 += kSeg) {
+        if (s0 > 0) {
 #pragma unroll
             for (int s = 0; s < kSeg; ++s)
                 if (s0 + s < steps) bv[s] = *(const uint4*)(brow + (int64_t)(s0 + s) * 64);
-            // groups of 4 k-steps (every served width is a multiple): the 4 RB fragment reads of a group are issued before
-            // its MFMAs, so the LDS latency is paid once per group, not once per MFMA
+        }
+        // groups of 4 k-steps (every served width is a multiple): the 4 RB fragment reads of a group are issued before
+        // its MFMAs, so the LDS latency is paid once per group, not once per MFMA
 #pragma unroll
-            for (int g4 = 0; g4 < kSeg; g4 += 4) {
-                if (s0 + g4 < steps) {
-                    uint4 av[4][RB];
+        for (int g4 = 0; g4 < kSeg; g4 += 4) {
+            if (s0 + g4 < steps) {
+                uint4 av[4][RB];
 #pragma unroll
-                    for (int s = 0; s < 4; ++s)
+                for (int s = 0; s < 4; ++s)
 #pragma unroll
-                        for (int rb = 0; rb < RB; ++rb) av[s][rb] = *(const uint4*)(arow[rb] + (s0 + g4 + s) * 64);
+                    for (int rb = 0; rb < RB; ++rb) av[s][rb] = *(const uint4*)(arow[rb] + (s0 + g4 + s) * 64);
 #pragma unroll
-                    for (int s = 0; s < 4; ++s)
+                for (int s = 0; s < 4; ++s)
 #pragma unroll
-                        for (int rb = 0; rb < RB; ++rb) {
-                            if constexpr (F32) {
-                                const float* af = reinterpret_cast<const float*>(&av[s][rb]);
-                                const float* bf = reinterpret_cast<const float*>(&bv[g4 + s]);
+                    for (int rb = 0; rb < RB; ++rb) {
+                        if constexpr (F32) {
+                            const float* af = reinterpret_cast<const float*>(&av[s][rb]);
+                            const float* bf = reinterpret_cast<const float*>(&bv[g4 + s]);
 #pragma unroll
-                                for (int i = 0; i < 4; ++i) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[i], acc[rb], 0, 0, 0);
-                            } else {
-                                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(reinterpret_cast<const bf16x8&>(av[s][rb]),
-                                                                                  reinterpret_cast<const bf16x8&>(bv[g4 + s]), acc[rb], 0, 0, 0);
-                            }
+                            for (int i = 0; i < 4; ++i) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[i], acc[rb], 0, 0, 0);
+                        } else {
+                            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(reinterpret_cast<const bf16x8&>(av[s][rb]),
+                                                                              reinterpret_cast<const bf16x8&>(bv[g4 + s]), acc[rb], 0, 0, 0);
                         }
-                }
+                    }
             }
         }
-        // lane holds sample positions p0 + 16 rb + 4 kq + {0..3} for query qrow
-        float* out = a.scores + (int64_t)qrow * a.row_stride + p0 + 4 * kq;
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-            *(float4*)(out + 16 * rb) = make_float4(ok[rb][0] ? acc[rb][0] : -INFINITY, ok[rb][1] ? acc[rb][1] : -INFINITY,
-                                                    ok[rb][2] ? acc[rb][2] : -INFINITY, ok[rb][3] ? acc[rb][3] : -INFINITY);
     }
+    // lane holds sample positions p0 + 16 rb + 4 kq + {0..3} for query qrow
+    float* out = a.scores + (int64_t)qrow * a.row_stride + p0 + 4 * kq;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+        *(float4*)(out + 16 * rb) = make_float4(ok[rb][0] ? acc[rb][0] : -INFINITY, ok[rb][1] ? acc[rb][1] : -INFINITY,
+                                                ok[rb][2] ? acc[rb][2] : -INFINITY, ok[rb][3] ? acc[rb][3] : -INFINITY);
 }
 
 }  // namespace ts

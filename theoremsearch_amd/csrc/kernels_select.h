@@ -91,7 +91,8 @@ struct LevelArgs {
     const int64_t* id_map;
     int* fb_list;
     int* fb_count;
-    unsigned long long* stat_candidates;  // sum of candidates seen at the final level
+    u32* stat_q;         // [nq] candidates seen at the final level (the host adds them up when statistics are asked for:
+                         // one atomic per query on ONE counter was 256 serialised L2 operations at the end of every search)
     int nq;
 };
 
@@ -294,6 +295,78 @@ __device__ __forceinline__ float level_threshold(const LevelArgs& a, const u64* 
     return thr;
 }
 
+// Sum over the 64 lanes of a wave on the DPP path (row / quad permutes inside the vector pipe, a few cycles each) instead of
+// six dependent ds_bpermute round trips through the LDS crossbar: quad xor 1, xor 2, half-row mirror, row mirror leave every
+// lane with its row's sum; row_bcast15 / row_bcast31 fold the rows into lane 63; the result is read from there (uniform).
+#define TS_DPP(v, ctrl, rmask) ((u32)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rmask), 0xf, false))
+#define TS_DPP_QUAD_XOR1 0xB1      /* quad_perm [1,0,3,2] */
+#define TS_DPP_QUAD_XOR2 0x4E      /* quad_perm [2,3,0,1] */
+#define TS_DPP_HALF_MIRROR 0x141
+#define TS_DPP_ROW_MIRROR 0x140
+#define TS_DPP_BCAST15 0x142
+#define TS_DPP_BCAST31 0x143
+__device__ __forceinline__ double wave_total_f64(double v) {
+#define TS_DPP_F64_STEP(ctrl, rmask)                                                                          \
+    {                                                                                                          \
+        const u64 b = (u64)__double_as_longlong(v);                                                            \
+        const u32 lo = TS_DPP((u32)b, ctrl, rmask), hi = TS_DPP((u32)(b >> 32), ctrl, rmask);                  \
+        v += __longlong_as_double((long long)(((u64)hi << 32) | lo));                                          \
+    }
+    TS_DPP_F64_STEP(TS_DPP_QUAD_XOR1, 0xf)
+    TS_DPP_F64_STEP(TS_DPP_QUAD_XOR2, 0xf)
+    TS_DPP_F64_STEP(TS_DPP_HALF_MIRROR, 0xf)
+    TS_DPP_F64_STEP(TS_DPP_ROW_MIRROR, 0xf)
+    TS_DPP_F64_STEP(TS_DPP_BCAST15, 0xa)      // rows 1 and 3 += the row before them (disabled rows add 0.0: old = 0)
+    TS_DPP_F64_STEP(TS_DPP_BCAST31, 0xc)      // rows 2 and 3 += rows 0 + 1
+#undef TS_DPP_F64_STEP
+    const u64 b = (u64)__double_as_longlong(v);
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)b, 63), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(b >> 32), 63);
+    return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+}
+
+// Descending bitonic sort of 64 R values held by ONE wave, element e = 64 r + lane in v[r]: exchanges between lanes are
+// shuffles, exchanges at distances of 64 and more stay inside the lane - no LDS, no barrier.  What the two short selects
+// below run on: the kernels that bracket the full pass are latency, and a workgroup-wide sort of a hundred keys is 28
+// barriers of it.
+template <typename T> __device__ __forceinline__ T wave_xor(T v, int mask);
+template <> __device__ __forceinline__ u32 wave_xor<u32>(u32 v, int mask) { return (u32)__shfl_xor((int)v, mask, 64); }
+template <> __device__ __forceinline__ u64 wave_xor<u64>(u64 v, int mask) {
+    const u32 lo = (u32)__shfl_xor((int)(u32)v, mask, 64), hi = (u32)__shfl_xor((int)(u32)(v >> 32), mask, 64);
+    return ((u64)hi << 32) | lo;
+}
+template <typename T, int R>
+__device__ __forceinline__ void wave_sort_desc(T (&v)[R], int lane) {
+#pragma unroll
+    for (int size = 2; size <= 64 * R; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride >= 64) {
+                const int rs = stride >> 6;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (r & rs) continue;
+                    const bool desc = (((r << 6) & size) == 0);      // bit `size` of the element index lies in r here
+                    const T a = v[r], b = v[r | rs];
+                    const bool swap = (a < b) == desc;
+                    v[r] = swap ? b : a;
+                    v[r | rs] = swap ? a : b;
+                }
+            } else {
+                const bool low = (lane & stride) == 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const bool desc = ((((r << 6) | lane) & size) == 0);
+                    const T mine = v[r], other = wave_xor<T>(mine, stride);
+                    const T hi = mine > other ? mine : other, lo = mine > other ? other : mine;
+                    v[r] = (low == desc) ? hi : lo;
+                }
+            }
+        }
+    }
+}
+
+constexpr int kFinalFast = 128;     // candidates the one-wave form of the final select takes (2 keys per lane)
+
 template <int KR>
 __global__ void __launch_bounds__(kLevelThreads) level_select_kernel(LevelArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -307,6 +380,39 @@ __global__ void __launch_bounds__(kLevelThreads) level_select_kernel(LevelArgs a
     u32& base_shared = ctr[2];
     u32& nsmall = ctr[3];                                     // (ctr[4], ctr[8..11]: lds_select_top's cut bin, mean, sd)
     const int q = blockIdx.x;
+    // The usual final level behind the 16x16 full pass: a few dozen candidates in the query's shared list and nothing else
+    // (the threshold estimate aims at 6 k, at least 64).  One wave takes them straight into registers, sorts them there and
+    // writes the answer; the other waves leave.  Two dependent round trips (count, keys) and no barrier, instead of the
+    // gather / histogram / workgroup sort below.
+    if (a.final_level && a.nwriters == 0 && a.k_user <= kFinalFast) {
+        const u32 raw0 = a.count[q];                           // uniform over the workgroup
+        if (raw0 <= (u32)kFinalFast && raw0 <= (u32)a.cap) {
+            if (threadIdx.x >= 64) return;
+            const int lane = threadIdx.x;
+            u64 v[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) v[r] = ((u32)(64 * r + lane) < raw0) ? a.cand[(int64_t)q * a.cap + 64 * r + lane] : 0ull;
+            if (lane == 0) {
+                a.count[q] = 0;
+                a.stat_q[q] = raw0;
+            }
+            if ((int)raw0 < a.min_fill) {
+                if (lane == 0) a.fb_list[atomicAdd(a.fb_count, 1)] = q;
+                return;
+            }
+            wave_sort_desc<u64, 2>(v, lane);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int i = 64 * r + lane;
+                if (i < a.k_user) {
+                    const u64 key = v[r];
+                    a.out_scores[(int64_t)q * a.k_user + i] = key ? key_score(key) : -INFINITY;
+                    a.out_idx[(int64_t)q * a.k_user + i] = !key ? -1 : a.id_map ? a.id_map[key_row(key)] : (int64_t)key_row(key) + a.row_offset;
+                }
+            }
+            return;
+        }
+    }
     if (threadIdx.x == 0) {
         fill = 0;
         produced = 0;
@@ -362,7 +468,7 @@ __global__ void __launch_bounds__(kLevelThreads) level_select_kernel(LevelArgs a
         if (threadIdx.x == 0) a.thr[q] = thr;
         return;
     }
-    if (threadIdx.x == 0) atomicAdd(a.stat_candidates, (unsigned long long)produced);
+    if (threadIdx.x == 0) a.stat_q[q] = produced;
     if (lost || (int)total < a.min_fill) {
         if (threadIdx.x == 0) a.fb_list[atomicAdd(a.fb_count, 1)] = q;
         return;
@@ -375,48 +481,161 @@ __global__ void __launch_bounds__(kLevelThreads) level_select_kernel(LevelArgs a
 }
 
 // Sample level of the batched search, dense form (kernels_sample.h): one workgroup per query reads that query's row of the
-// sample score matrix (coalesced; -inf = no such row / filtered out, NaN never keyed), keys them by sample position and
-// sets thr[q] exactly as level_select_kernel does for a sample level - the same selection and the same estimates, without
-// the gather from a thousand lane-private lists.
-template <int KR>
-__global__ void __launch_bounds__(kLevelThreads) sample_select_kernel(LevelArgs a, const float* scores, int row_stride, int npos) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64* keys = (u64*)smem;
-    u64* small = (u64*)(smem + kLevelSortMax * 8);
-    u64* wlists = small + kLevelSmall;
-    u32* hist = (u32*)(wlists + (kLevelThreads / 64) * TS_MAX_K_INTERNAL);
-    u32* ctr = hist + kLevelBins;
+// sample score matrix (coalesced; -inf = no such row / filtered out, NaN never counted) and sets thr[q] with the estimates
+// level_select_kernel applies to a sample level (level_threshold) - without the gather from a thousand lane-private lists.
+// Shaped for latency (round 4; round 3's form keyed the scores by position and ran them through lds_select_top: 16 us): the threshold needs the SCORES of the kl best sample rows, their mean and their
+// standard deviation - not which rows they were.  One workgroup of 256 threads per query holds the whole row of the sample
+// matrix in registers (8 x 16-byte loads per thread, all in flight at once), reduces count / sum / sum of squares, cuts at
+// mean + z sd (`z_sel`: the host's guess for ~2 kl survivors on Gaussian-like scores), and one wave sorts the survivors in
+// registers (wave_sort_desc).  A cut that leaves fewer than kl or more than kSelCap survivors is moved (three tries), then
+// found exactly by bisection on the ordered 32-bit scores - piles of equal scores included.
+// test_dense_threshold_sample_and_the_list_form_give_the_same_answers holds the answers against the list form's.
+constexpr int kSelCap = 1024;        // survivors the sort takes (kl <= 256)
+
+// 256 threads per query (one wave per query measured 20 us against 15: the hundreds of compare / count instructions are
+// issue time, and four SIMDs share it).
+constexpr int kSelThreads = 256;
+template <int THREADS>   // = kSelThreads (a template so that every translation unit may include this header)
+__global__ void __launch_bounds__(THREADS) sample_select_fast_kernel(LevelArgs a, const float* scores, int row_stride, float z_sel) {
+    constexpr int NW = THREADS / 64;
+    constexpr int J4 = kLevelSortMax / (4 * THREADS);         // 8 float4 per thread cover 8192 positions
+    __shared__ double red[2 * NW];
+    __shared__ u32 wcount[2][NW];
+    __shared__ __attribute__((aligned(16))) u32 surv[kSelCap];
+    __shared__ __attribute__((aligned(16))) u64 best[kSelCap];
+    __shared__ u32 nsurv;
     const int q = blockIdx.x;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) {
-        ctr[0] = 0;
-        ctr[3] = 0;
-        a.count[q] = 0;                       // the shared list of the full pass starts empty
+        a.count[q] = 0;                                       // the shared list of the full pass starts empty
+        nsurv = 0;
     }
-    for (int i = threadIdx.x; i < kLevelBins; i += blockDim.x) hist[i] = 0;
-    __syncthreads();
-    const float* src = scores + (int64_t)q * row_stride;
-    const int m = min(npos, kLevelSortMax);
-    for (int i0 = (threadIdx.x & ~63); i0 < m; i0 += blockDim.x) {
-        const int i = i0 + lane;
-        const float sc = (i < m) ? src[i] : -INFINITY;
-        const bool live = sc == sc && sc > -INFINITY;
-        const u64 mask = __ballot(live);
-        u32 base = 0;
-        if (lane == 0 && mask) base = atomicAdd(&ctr[0], (u32)__popcll(mask));
-        base = (u32)__shfl((int)base, 0, 64);
-        if (live) keys[base + __popcll(mask & ((1ull << lane) - 1ull))] = make_key(sc, (u32)i);
+    const float4* src = (const float4*)(scores + (int64_t)q * row_stride);
+    const int n4 = row_stride >> 2;                           // row_stride is a multiple of 64; positions past the sample hold -inf
+    float v[4 * J4];
+#pragma unroll
+    for (int j = 0; j < J4; ++j) {
+        const int i = j * THREADS + threadIdx.x;
+        const float4 t = (i < n4) ? src[i] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
     }
+    // live scores: not NaN, not -inf (no such row / filtered out).  From here on a score is its ordered 32-bit image
+    // (0 = dead; every live score's image is above 0).
+    double s1 = 0.0, s2 = 0.0;
+    u32 nl = 0;
+    u32 o[4 * J4];
+#pragma unroll
+    for (int e = 0; e < 4 * J4; ++e) {
+        const bool live = v[e] == v[e] && v[e] > -INFINITY;
+        const double d = live ? (double)v[e] : 0.0;
+        s1 += d;
+        s2 += d * d;
+        nl += (u32)__popcll(__ballot(live));                  // wave-uniform: this wave's live count so far
+        o[e] = live ? ord_f32(v[e]) : 0u;
+    }
+    s1 = wave_total_f64(s1);
+    s2 = wave_total_f64(s2);
+    if (lane == 0) { red[2 * wave] = s1; red[2 * wave + 1] = s2; wcount[0][wave] = nl; }
     __syncthreads();
-    const int cnt = (int)ctr[0];
+    double t1 = 0.0, t2 = 0.0;
+    int cnt = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { t1 += red[2 * w]; t2 += red[2 * w + 1]; cnt += (int)wcount[0][w]; }
+    const double mean = cnt > 0 ? t1 / cnt : 0.0;
+    const double sd = cnt > 0 ? sqrt(fmax(t2 / cnt - mean * mean, 0.0)) : 0.0;
     const int kk = a.kk;
     constexpr int kTailM = 32;
     const bool tail_fit = a.tail_p > 0.0f;
-    const int kl = tail_fit ? max(kk, kTailM) : kk;
-    double mean = 0.0, sd = 0.0;
-    u64* best = lds_select_top<KR>(keys, cnt, kl, small, wlists, hist, ctr, a.z_tail > 0.0f && cnt >= 256, mean, sd);
+    const int kl = min(tail_fit ? max(kk, kTailM) : kk, TS_MAX_K_INTERNAL);
+
+    // survivors of a cut (>= cut, cut >= 1), counted over the workgroup (uniform result); the two count buffers alternate,
+    // so one barrier per call is enough
+    int flip = 1;
+    auto count_ge = [&](u32 cut) __attribute__((always_inline)) -> u32 {
+        u32 c = 0;
+#pragma unroll
+        for (int e = 0; e < 4 * J4; ++e) c += (u32)__popcll(__ballot(o[e] >= cut));
+        if (lane == 0) wcount[flip][wave] = c;
+        __syncthreads();
+        u32 tot = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tot += wcount[flip][w];
+        flip ^= 1;
+        return tot;
+    };
+    const u32 want = (u32)min(kl, cnt);                       // fewer live rows than kl: all of them
+    u32 cut = 1u, c = 0;
+    bool found = want == 0;
+    if (!found && sd > 0.0) {
+        float z = z_sel;
+        for (int t = 0; t < 3 && !found; ++t) {
+            cut = max(ord_f32((float)(mean + (double)z * sd)), 1u);
+            c = count_ge(cut);
+            if (c < want) z -= 0.75f;
+            else if (c > (u32)kSelCap) z += 0.75f;
+            else found = true;
+        }
+    }
+    if (!found) {
+        // exact: the largest cut that still leaves `want` survivors = the want-th best score itself; everything above it
+        // (fewer than want <= 256 values) plus copies of it are the want best scores
+        u32 lo = 1u, hi = 0xFFFFFFFFu;                        // count_ge(lo) >= want always; hi may fail
+        if (count_ge(hi) >= want) lo = hi;
+        while (lo < hi) {                                     // invariant: count_ge(lo) >= want, count_ge(hi + 1) < want
+            const u32 mid = lo + (hi - lo) / 2u + ((hi - lo) & 1u);
+            if (count_ge(mid) >= want) lo = mid;
+            else hi = mid - 1u;
+        }
+        cut = lo;
+        c = count_ge(cut);
+    }
+    // gather the survivors (order does not matter; equal scores beyond the capacity are the cut itself and are padded back)
+    const bool over = c > (u32)kSelCap;                       // only after the exact search: a pile of scores equal to the cut
+    const u32 take_cut = (over && cut != 0xFFFFFFFFu) ? cut + 1u : cut;   // then take what lies strictly above and pad with the cut
+    const bool take_any = want > 0 && !(over && cut == 0xFFFFFFFFu);
+#pragma unroll
+    for (int e = 0; e < 4 * J4; ++e) {
+        const bool in = take_any && o[e] >= take_cut;
+        const u64 m = __ballot(in);
+        if (m) {
+            u32 base = 0;
+            if (lane == 0) base = atomicAdd(&nsurv, (u32)__popcll(m));
+            base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+            const u32 at = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
+            if (in && at < (u32)kSelCap) surv[at] = o[e];
+        }
+    }
+    __syncthreads();
+    const int ns = (int)min(nsurv, (u32)kSelCap);
+    const int m = over ? max(ns, (int)want) : ns;             // `over`: surv[ns .. want) are copies of the cut (not stored)
+    // sorted scores as keys (score << 32), entries past the survivors 0 = empty, as level_threshold expects (it reads up
+    // to best[kl - 1])
+    if (m <= THREADS) {
+        // rank sort: thread t owns survivor t and counts the survivors that come before it - m broadcast reads of LDS and
+        // two instructions each, no exchange network
+        const u32 mine = (int)threadIdx.x < ns ? surv[threadIdx.x] : cut;
+        int rank = 0;
+        const uint4* s4 = (const uint4*)surv;                 // four survivors per read (entries past ns are not counted)
+#pragma unroll 2
+        for (int i = 0; i < ns; i += 4) {
+            const uint4 x = s4[i >> 2];
+            rank += (x.x > mine || (x.x == mine && i < (int)threadIdx.x)) ? 1 : 0;
+            rank += (i + 1 < ns && (x.y > mine || (x.y == mine && i + 1 < (int)threadIdx.x))) ? 1 : 0;
+            rank += (i + 2 < ns && (x.z > mine || (x.z == mine && i + 2 < (int)threadIdx.x))) ? 1 : 0;
+            rank += (i + 3 < ns && (x.w > mine || (x.w == mine && i + 3 < (int)threadIdx.x))) ? 1 : 0;
+        }
+        if ((int)threadIdx.x >= ns) rank = (int)threadIdx.x;  // the padding (copies of the cut, below every survivor) and the empty tail
+        best[rank] = (int)threadIdx.x < m ? ((u64)mine << 32) : 0ull;
+    } else {
+        for (int i = threadIdx.x; i < kSelCap; i += THREADS) best[i] = (i < ns) ? ((u64)surv[i] << 32) : (i < m ? ((u64)cut << 32) : 0ull);
+        int P = 2;
+        while (P < m) P <<= 1;
+        bitonic_sort_desc(best, P, threadIdx.x, THREADS);
+    }
+    __syncthreads();
+    if (wave != 0) return;
     const float thr = level_threshold(a, best, cnt, kk, tail_fit, mean, sd);
-    if (threadIdx.x == 0) a.thr[q] = thr;
+    if (lane == 0) a.thr[q] = thr;
 }
 
 // One-launch reduction of the scan's partial lists (up to kHistSelectMax keys per query: 1024 workgroups x k <= 12) to the

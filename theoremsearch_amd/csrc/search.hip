@@ -26,7 +26,7 @@ static int ensure_search_scratch(ts_index* ix, int k) {
     TS_TRY(need(&ix->thr, (size_t)kQBlock * 4, false));
     TS_TRY(need(&ix->fb_list, (size_t)kQBlock * 4, false));
     TS_TRY(need(&ix->fb_count, 16, true));
-    TS_TRY(need(&ix->stat, 16, true));
+    TS_TRY(need(&ix->stat, (size_t)kQBlock * 4, true));
     if (mfma_index(ix)) TS_TRY(need(&ix->cand, (size_t)kQBlock * kCandCap * 8, false));
     // scan partials: [256 slots][grid][k] keys, twice (ping-pong for the select rounds)
     const size_t grid = (size_t)ix->cu_count * kScanGridPerCU;
@@ -204,14 +204,14 @@ int scan_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* out_idx
         // an almost always empty launch: one workgroup per CU dispatches (and drains) faster than four; when it does
         // run, a pass at a lower share of the HBM rate is the price of the rare query the estimate failed for
         grid = std::min(grid, ix->cu_count);
-        if (ix->rebalance_pending && ix->rebalance_grid <= 256) {
+        if (ix->rebalance_pending && ix->rebalance_in_rerun && ix->rebalance_grid <= 256) {
             a.part = ix->part;
             a.wg_ticks = ix->wg_ticks;
             a.part_g = ix->rebalance_grid;
             const int b = ix->knobs.get(K_MFMA_BALANCE, 1);      // TS_MFMA_BALANCE = n > 1: gain n / 10 (default 0.7)
             a.part_gain = (b >= 2 && b <= 10) ? 0.1f * (float)b : 0.7f;
+            ix->rebalance_pending = false;
         }
-        ix->rebalance_pending = false;
     }
     // k > 64 keeps 4 keys per lane and query: on bf16 x 768 four queries at once need all 256 VGPRs, one wave per SIMD
     // (measured 0.18 of the HBM rate against 0.8 for one query per pass); the other shapes keep two waves
@@ -391,15 +391,19 @@ static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_
     }
     if (!out_on_device || stats) {
         int fb = 0;
-        unsigned long long cands = 0;
+        std::vector<u32> cands_q;
+        const int last_nb = nq - (nq - 1) / block * block;     // queries of the last block: what the counters describe
         if (stats && use == TS_ALGO_MFMA) {
+            cands_q.resize((size_t)last_nb);
             HIP_TRY(hipMemcpyAsync(&fb, ix->fb_count, 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(&cands, ix->stat, 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(cands_q.data(), ix->stat, (size_t)last_nb * 4, hipMemcpyDeviceToHost, st));
         }
         HIP_TRY(hipStreamSynchronize(st));
         if (stats && use == TS_ALGO_MFMA) {
             stats->fallback_queries = fb;
-            stats->candidates = (int64_t)cands;
+            int64_t cands = 0;
+            for (u32 c_ : cands_q) cands += c_;
+            stats->candidates = cands;
         }
     }
     return TS_OK;

@@ -131,8 +131,6 @@ int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* out_idx
     if (!ix->attr_done) {
         HIP_TRY(hipFuncSetAttribute((const void*)level_select_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelLds));
         HIP_TRY(hipFuncSetAttribute((const void*)level_select_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelLds));
-        HIP_TRY(hipFuncSetAttribute((const void*)sample_select_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelLds));
-        HIP_TRY(hipFuncSetAttribute((const void*)sample_select_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLevelLds));
         ix->attr_done = true;
     }
     // The sparsest level (every score a candidate, at most kLevelSortMax rows) runs as a dense score matrix + one select per
@@ -220,25 +218,34 @@ int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* out_idx
             sa.scores = ix->sample;
             sa.row_stride = (int)((lv[0].ntiles * kTileRows + 63) / 64 * 64);
             sa.fb_count = ix->fb_count;
-            sa.stat = ix->stat;
             // 32 rows per workgroup and one 64-query chunk: 512 workgroups of 50 KB LDS at 4,096 rows x 256 queries, two to
             // a CU (64-row workgroups serving two chunks each measured the same: 15.2 / 25.0 us against 14.9 / 24.3 us at
             // 4,096 / 8,192 rows - the launch is latency, not work)
             const bool f32 = ix->dtype == TS_F32;
             const int nchunks = (nq + 63) / 64;
             const int wg_rows = 32;
-            sa.chunks_per_wg = 1;
-            const dim3 sgrid((unsigned)(sa.row_stride / wg_rows), (unsigned)((nchunks + sa.chunks_per_wg - 1) / sa.chunks_per_wg));
+            // the previous search's full pass left its workgroups' times: one extra workgroup of this launch moves the
+            // tile boundaries before this search's pass reads them
+            if (ix->rebalance_pending && balance && ix->rebalance_grid == wgs && ix->rebalance_grid <= 256) {
+                sa.part = ix->part;
+                sa.wg_ticks = ix->wg_ticks;
+                sa.part_g = ix->rebalance_grid;
+                const int b = ix->knobs.get(K_MFMA_BALANCE, 1);      // TS_MFMA_BALANCE = n > 1: gain n / 10 (default 0.7)
+                sa.part_gain = (b >= 2 && b <= 10) ? 0.1f * (float)b : 0.7f;
+            }
+            ix->rebalance_pending = false;
+            const dim3 sgrid((unsigned)(sa.row_stride / wg_rows), (unsigned)(nchunks + (sa.part ? 1 : 0)));
             const int slds = sample_lds_bytes(wg_rows, (int)(ix->ld * ix->elem()));
-            if (slds > 160 * 1024) return fail(TS_ERR_INTERNAL, "threshold sample: rows of %lld bytes do not fit the LDS", (long long)(ix->ld * ix->elem()));
+            constexpr int kSampleLdsMax = 144 * 1024;   // dynamic part; the kernel also has a few hundred static bytes (rebalance_tiles)
+            if (slds > kSampleLdsMax) return fail(TS_ERR_INTERNAL, "threshold sample: rows of %lld bytes do not fit the LDS", (long long)(ix->ld * ix->elem()));
             {
                 static std::atomic<unsigned long long> sample_attr{0};
                 int dev = 0;
                 HIP_TRY(hipGetDevice(&dev));
                 const unsigned long long bit = 1ull << (dev & 63);
                 if (!(sample_attr.load(std::memory_order_acquire) & bit)) {
-                    HIP_TRY(hipFuncSetAttribute((const void*)sample_scores_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                    HIP_TRY(hipFuncSetAttribute((const void*)sample_scores_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    HIP_TRY(hipFuncSetAttribute((const void*)sample_scores_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kSampleLdsMax));
+                    HIP_TRY(hipFuncSetAttribute((const void*)sample_scores_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kSampleLdsMax));
                     sample_attr.fetch_or(bit, std::memory_order_release);
                 }
             }
@@ -254,8 +261,11 @@ int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* out_idx
             l.tail_p = tail_p;
             l.tail_z = (float)normal_tail_z(std::min(0.25, 32.0 / sample_rows));
             l.nq = nq;
-            if (kk <= 64) sample_select_kernel<1><<<nq, kLevelThreads, kLevelLds, st>>>(l, ix->sample, sa.row_stride, (int)(lv[0].ntiles * kTileRows));
-            else sample_select_kernel<4><<<nq, kLevelThreads, kLevelLds, st>>>(l, ix->sample, sa.row_stride, (int)(lv[0].ntiles * kTileRows));
+            // where the select cuts first: ~2 kl of the sample's live rows above it on Gaussian-like scores
+            const int kl = tail_p > 0.0f ? std::max(kk, 32) : kk;
+            const double live = sample_rows * (double)pop / (double)std::max<int64_t>(ix->n, 1);
+            const float z_sel = (float)normal_tail_z(std::min(0.25, 2.0 * kl / std::max(live, 1.0)));
+            sample_select_fast_kernel<kSelThreads><<<nq, kSelThreads, 0, st>>>(l, ix->sample, sa.row_stride, z_sel);
             HIP_TRY(hipGetLastError());
             continue;
         }
@@ -278,7 +288,6 @@ int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* out_idx
         a.first_level = (i == 0) ? 1 : 0;      // thresholds and per-search counters are initialised inside the first launch of a search
         a.nq_real = nq;
         a.fb_count = ix->fb_count;
-        a.stat = ix->stat;
         a.part = (balance && full_pass) ? ix->part : nullptr;
         a.wg_ticks = (balance && full_pass) ? ix->wg_ticks : nullptr;
         a.pair = (pair && full_pass) ? 1 : 0;
@@ -382,15 +391,17 @@ int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* out_idx
         l.id_map = ix->id_map;
         l.fb_list = ix->fb_list;
         l.fb_count = ix->fb_count;
-        l.stat_candidates = ix->stat;
+        l.stat_q = ix->stat;
         l.nq = nq;
         if (kk <= 64) level_select_kernel<1><<<nq, kLevelThreads, kLevelLds, st>>>(l);
         else level_select_kernel<4><<<nq, kLevelThreads, kLevelLds, st>>>(l);
         HIP_TRY(hipGetLastError());
     }
-    // block 0 of the launch below moves the tile boundaries of the pass just finished for the next search
+    // the pass just finished left its workgroups' times: the next search's sample launch moves the tile boundaries (without
+    // a dense sample: block 0 of the re-run launch below)
     ix->rebalance_pending = balance;
     ix->rebalance_grid = wgs;
+    ix->rebalance_in_rerun = !(dense_sample && lv.size() == 2);
     // exact fall-back for queries that lost candidates (device-side count; one empty launch when 0)
     if (!in_place) TS_TRY(scan_search(ix, nq, k, out_scores, out_idx, ix->fb_list, ix->fb_count, st));
     else if (ix->dtype == TS_F32) TS_TRY(scan_search(ix, nq, k, out_scores, out_idx, ix->fb_list, ix->fb_count, st, (const float*)qmat));

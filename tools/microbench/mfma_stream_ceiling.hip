@@ -120,7 +120,6 @@ int run_leg(int leg, const unsigned short* corpus, int64_t rows, const unsigned 
     a.first_level = 1;
     a.nq_real = 256;
     a.fb_count = s.fb;
-    a.stat = s.stat;
     if (!s.attr) {
         if (hipFuncSetAttribute((const void*)mfma16_topk_kernel<kD, kNB, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess) return -1;
         if (hipFuncSetAttribute((const void*)mfma16_topk_kernel<kD, kNB, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess) return -1;

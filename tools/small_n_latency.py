@@ -19,7 +19,7 @@ def main():
     from oracle import oracle
     out = {}
     for n in (1_000, 10_000, 100_000, 1_000_000):
-        q, c = oracle.golden_inputs(n, 1, 768, 7 + n, "cos")
+        q, c = oracle.inputs(n, 1, 768, 7 + n, "cos")
         with ts.TheoremIndex.from_embeddings(c, dtype="f32", metric="cos") as ix:
             qd = torch.from_numpy(q).cuda()
             st = torch.cuda.Stream()
