@@ -205,3 +205,14 @@ def test_showcase_loaders(tmp_path, monkeypatch):
     got, data = asm.load_embedding_library(str(tmp_path))
     assert torch.equal(got, emb) and len(data) == 3
     assert asm.EMBEDDING_LIBRARY_DIR == "./app_embeds"
+
+
+def test_ndcg_says_too_small_where_the_reference_does(capsys):
+    """compare_embeddings.py:201-203: an empty relevance list (a query without qrels: its ideal ranking is empty) prints
+    "TOO SMALL" and scores 0 - part of the printed report the mirror promises to reproduce."""
+    import numpy as np
+    from theoremsearch_amd import compare_embeddings as ce
+    sim = np.random.default_rng(0).standard_normal((2, 6)).astype(np.float32)
+    val = ce.ndcg_at_k(sim, {0: {1: 2.0}, 1: {}}, k=3)
+    out = capsys.readouterr().out
+    assert out.count("TOO SMALL") == 1 and 0.0 <= val <= 1.0

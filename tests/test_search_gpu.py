@@ -718,3 +718,41 @@ def test_dense_threshold_sample_and_the_list_form_give_the_same_answers(ts, dtyp
         # (round 4: the dense form's select is a one-wave kernel with its own reductions and cut - the same thresholds)
         assert 0.9 < st1["candidates"] / max(1, st0["candidates"]) < 1.11, (st1, st0)
         check(q, c, "ip", dtype, k, s1, i1)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_threshold_sample_of_degenerate_score_distributions(ts, dtype):
+    """Round 4: the sample's select cuts at mean + z sd and, where that leaves too few or too many survivors, finds the cut
+    by bisection on the ordered scores.  The shapes that send it there: every row the same (sd = 0: every sample score
+    equal), two values only (a pile of equal scores right at the cut, larger than the sort's capacity), a mask that leaves the
+    sample fewer live rows than k, and k = 200 over a plain corpus (hundreds of survivors).  The answers stay exact (ties:
+    lowest rows first) whatever the thresholds come out as."""
+    n, d, nq = 40_000, 768, 70
+    rng = np.random.default_rng(5)
+    q = rng.standard_normal((nq, d), dtype=np.float32) * np.float32(1.0 / np.sqrt(d))
+    one = rng.standard_normal(d).astype(np.float32) * np.float32(1.0 / np.sqrt(d))
+    # (a) every row the same
+    c = np.tile(one, (n, 1))
+    with ts.TheoremIndex.from_embeddings(c, dtype=dtype, metric="ip") as ix:
+        s, i = ix.search(q, 10, algo="mfma")
+        assert np.array_equal(i, np.tile(np.arange(10), (nq, 1)))
+        check(q, c, "ip", dtype, 10, s, i)
+    # (b) two values: a third of the rows score higher than the rest for every query that likes `one`
+    other = rng.standard_normal(d).astype(np.float32) * np.float32(1.0 / np.sqrt(d))
+    c = np.tile(other, (n, 1))
+    c[rng.random(n) < 0.33] = one
+    with ts.TheoremIndex.from_embeddings(c, dtype=dtype, metric="ip") as ix:
+        s, i = ix.search(q, 10, algo="mfma")
+        check(q, c, "ip", dtype, 10, s, i)
+    # (c) plain rows: a mask that keeps a tenth of them with k = 200 (a 4,096-row sample sees ~400 live rows), and k = 200 unmasked
+    q2, c2 = oracle.inputs(n, nq, d, 97, "ip")
+    mask = rng.random(n) < 0.1
+    with ts.TheoremIndex.from_embeddings(c2, dtype=dtype, metric="ip") as ix:
+        s, i, st = ix.search(q2, 200, algo="mfma", return_stats=True)
+        assert st["fallback_queries"] == 0, st
+        check(q2, c2, "ip", dtype, 200, s, i)
+        s, i = ix.search(q2, 200, mask=mask)
+        rows = np.flatnonzero(mask)
+        local = np.searchsorted(rows, i)
+        assert (rows[local] == i).all()
+        check(q2, c2[rows], "ip", dtype, 200, s, local)

@@ -195,6 +195,7 @@ def _get_rels_sparse(order, rels_dict, k=None, default=0.0):
 
 def _dcg_from_rels(rels, gain="exp"):
     if rels.size == 0:
+        print("TOO SMALL")          # the reference says so on stdout (compare_embeddings.py:201-203): same printed report
         return 0.0
     if gain == "exp":
         gains = np.exp2(rels) - 1.0

@@ -38,8 +38,12 @@ def main(src, tag):
     if os.path.exists(tpath):
         traffic = json.load(open(tpath))
     notes = []
-    for w, kern in (("c3", "mfma16_topk_kernel<768, 4, 0, false"), ("c2", "scan_kernel"), ("c2b", "mfma16_topk_kernel<768, 2, 0, false, true")):
-        stats = newest(glob.glob(os.path.join(src, f"trace_{w}", "**", "*kernel_stats.csv"), recursive=True))
+    kernels = (("c3", "mfma16_topk_kernel<768, 4, 0, false"), ("c2", "scan_kernel"), ("c2b", "mfma16_topk_kernel<768, 2, 0, false, true"),
+               ("c3q", "mfma16_topk_kernel<1024, 2, 0, false, false, true"))
+    for w, kern in kernels:
+        # tools/run_profiles_r04.sh leaves <w>_kernel_stats.csv beside the trace directories; round 3's script only the directories
+        stats = newest(glob.glob(os.path.join(src, f"{w}_kernel_stats.csv")) or
+                       glob.glob(os.path.join(src, f"trace_{w}", "**", "*kernel_stats.csv"), recursive=True))
         if stats:
             shutil.copy(stats[0], os.path.join(out, f"{tag}_{w}_kernel_stats.csv"))
         fetch = pmc_per_launch(os.path.join(src, f"pmc_{w}_FETCH_SIZE"), "FETCH_SIZE", kern)
@@ -51,19 +55,33 @@ def main(src, tag):
             traffic[f"{w}_n1"] = int(hbm)
             notes.append(f"{w}: kernel {kern}: FETCH_SIZE {f_kib:.0f} KiB (x2 gfx950 correction) + WRITE_SIZE {w_kib:.0f} KiB "
                          f"= {hbm / 1e9:.3f} GB per launch")
-    for extra in ("clock_probe.json",):
+    for extra in ("clock_probe.json", "shard_steps.json"):
         if os.path.exists(os.path.join(src, extra)):
             shutil.copy(os.path.join(src, extra), os.path.join(out, f"{tag}_{extra}"))
-    stats = newest(glob.glob(os.path.join(src, "trace_c5", "**", "*kernel_stats.csv"), recursive=True))
-    if stats:
-        shutil.copy(stats[0], os.path.join(out, f"{tag}_c5_kernel_stats.csv"))
-    for w in ("c3", "c2", "c2b", "c5", "c1"):
+    for w in ("c5", "c5_128", "c5_qwen"):
+        stats = newest(glob.glob(os.path.join(src, f"{w}_kernel_stats.csv")) or
+                       glob.glob(os.path.join(src, f"trace_{w}", "**", "*kernel_stats.csv"), recursive=True))
+        if stats:
+            shutil.copy(stats[0], os.path.join(out, f"{tag}_{w}_kernel_stats.csv"))
+    for w in ("c3", "c2", "c2b", "c3q", "c5", "c5_128", "c5_qwen", "c1"):
         b = os.path.join(src, f"bench_{w}.json")
         if os.path.exists(b) and os.path.getsize(b) > 0:
             shutil.copy(b, os.path.join(out, f"{tag}_bench_{w}.json"))
-    stats = newest(glob.glob(os.path.join(src, "trace_shard", "**", "*kernel_stats.csv"), recursive=True))
+    stats = newest(glob.glob(os.path.join(src, "shard_1p25M_kernel_stats.csv")) or
+                   glob.glob(os.path.join(src, "trace_shard", "**", "*kernel_stats.csv"), recursive=True))
     if stats:
         shutil.copy(stats[0], os.path.join(out, f"{tag}_shard_1p25M_kernel_stats.csv"))
+    sq = newest(glob.glob(os.path.join(src, "pmc_c3_SQ_WAVE_CYCLES", "**", "*counter_collection.csv"), recursive=True))
+    if sq:
+        # sums over the dispatches of the full pass, one line per counter
+        tot = {}
+        for r in csv.DictReader(open(sq[0])):
+            if kernels[0][1] in r["Kernel_Name"]:
+                tot.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        with open(os.path.join(out, f"{tag}_c3_sq_counters_raw.txt"), "w") as f:
+            f.write("rocprofv3 --kernel-trace --pmc SQ_* (its own pass), bench.py --workload c3 --steps 3 --warmup 1: per launch of the full pass\n")
+            for k_, v in sorted(tot.items()):
+                f.write(f"{k_}: launches {len(v)}, mean {sum(v) / len(v):.6g}, min {min(v):.6g}, max {max(v):.6g}\n")
     json.dump(traffic, open(tpath, "w"), indent=1)
     with open(os.path.join(out, f"{tag}_traffic_notes.txt"), "w") as f:
         f.write("HBM traffic per launch of the dominant kernel, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes),\n"
