@@ -126,14 +126,26 @@ __device__ __forceinline__ void mfma_level_begin(const MfmaArgs& a) {
 // bookkeeping for it, so it never drains the DMA queue behind our back (a compiler-visible LDS-DMA
 // makes every following ds_read wait vmcnt(0)); the waits are the counted ones in the kernel.
 // M0 is not saved: the generated code of this kernel never reads M0 (checked in the .s).
+// NT = false: default cache policy - the paired pass of kernels_mfma16.h, whose two workgroups read every tile one behind the
+// other on one XCD: the first read must leave the lines in L2 for the second.
+template <bool NT = true>
 __device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst) {
-    asm volatile(
-        "s_mov_b32 m0, %1\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %0, off" TS_DMA_POLICY
-        :
-        : "v"(gsrc), "s"(lds_dst)
-        : "memory");
+    if constexpr (NT)
+        asm volatile(
+            "s_mov_b32 m0, %1\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %0, off" TS_DMA_POLICY
+            :
+            : "v"(gsrc), "s"(lds_dst)
+            : "memory");
+    else
+        asm volatile(
+            "s_mov_b32 m0, %1\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %0, off"
+            :
+            : "v"(gsrc), "s"(lds_dst)
+            : "memory");
 }
 
 template <int N>

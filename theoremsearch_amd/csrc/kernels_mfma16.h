@@ -91,16 +91,25 @@ __device__ __forceinline__ void lds_read16(frag16& dst, unsigned addr) {
 #ifndef TS16_DMA_IMM_LDS
 #define TS16_DMA_IMM_LDS 1
 #endif
-template <int IMM>
+template <int IMM, bool NT = true>
 __device__ __forceinline__ void lds_dma16s(unsigned voff, const void* sbase, unsigned lds_dst) {
     static_assert(IMM >= 0 && IMM < 4096, "13-bit signed immediate");
-    asm volatile(
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %0, %1 offset:%3" TS_DMA_POLICY
-        :
-        : "v"(voff), "s"(sbase), "s"(lds_dst), "n"(IMM)
-        : "memory");
+    if constexpr (NT)
+        asm volatile(
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %0, %1 offset:%3" TS_DMA_POLICY
+            :
+            : "v"(voff), "s"(sbase), "s"(lds_dst), "n"(IMM)
+            : "memory");
+    else
+        asm volatile(
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %0, %1 offset:%3"
+            :
+            : "v"(voff), "s"(sbase), "s"(lds_dst), "n"(IMM)
+            : "memory");
 }
 // Every outstanding fragment read has landed; names the whole ring, so that no copy of a ring register the compiler may
 // need where control flow merges (end of a tile, steady / general branch) is placed above it.
@@ -227,6 +236,10 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     constexpr int kA = (kUnitSteps % 3 == 0) ? 3 : 4;
     constexpr int kQVmax = 36 - 2 * (kA - 2);            // the ring's registers come out of the VGPR share of the queries
     constexpr int kQV = kFrags < kQVmax ? kFrags : kQVmax;   // ... the first kQV of them in VGPRs, the rest in AGPRs
+    // cache policy of the corpus stream: non-temporal (read once per search) - except in the paired pass, where the first
+    // of a pair's two reads of a tile must leave its lines in the XCD's L2 for the second (with nt on both the fabric
+    // carried 35.6 GB per launch of 10M x 1024 x 256 queries, 1.74 x the corpus: profiles/r04_traffic_notes.txt)
+    constexpr bool kStreamNT = !PAIR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -300,7 +313,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     for (int i = 0; i < ahead && issue_u < nu && !kNoDma; ++i) {
         const unsigned char* src = tile_src + issue_ui * (kUnitK * 2);
 #pragma unroll
-        for (int j = 0; j < kPieces; ++j) lds_dma16(src + j * 128, lds0 + issue_slot * kUnitBytes + j * 4096);
+        for (int j = 0; j < kPieces; ++j) lds_dma16<kStreamNT>(src + j * 128, lds0 + issue_slot * kUnitBytes + j * 4096);
         TS16_ISSUED();
     }
     // query fragments: fragment f = b * kSteps + ks holds q[qid[b]][32 ks + 8 kq .. + 8]
@@ -403,8 +416,8 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
                 constexpr int j_ = (S_) / kPieceEvery;                                                     \
                 unsigned long long d0_ = 0;                                                                \
                 if (VARIANT == 5) d0_ = cycle_stamp();                                                     \
-                if constexpr (steady_) lds_dma16s<j_ * 128>(dma_voff, ssrc, idst + j_ * (4096 - 128 * TS16_DMA_IMM_LDS)); \
-                else lds_dma16(isrc + j_ * 128, idst + j_ * 4096);                                         \
+                if constexpr (steady_) lds_dma16s<j_ * 128, kStreamNT>(dma_voff, ssrc, idst + j_ * (4096 - 128 * TS16_DMA_IMM_LDS)); \
+                else lds_dma16<kStreamNT>(isrc + j_ * 128, idst + j_ * 4096);                                         \
                 if (VARIANT == 5) t_dma += cycle_stamp() - d0_;                                            \
             }                                                                                              \
     } while (0)
