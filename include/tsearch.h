@@ -334,6 +334,16 @@ int ts_embed_layernorm(int device, const int64_t *ids, const int64_t *type_ids, 
 int ts_attention_short(int device, const void *qkv, const int64_t *attention_mask, int32_t batch, int32_t seq, int32_t heads,
                       int32_t head_dim, void *out, void *stream);
 
+/* The same for the decoder-style encoder the production app embeds with (Qwen/Qwen3-Embedding-0.6B, streamlit_app.py:55;
+ * Qwen3Attention: grouped-query, causal, head size 128): out = softmax(Q K^T / sqrt(128) + causal + key mask) V per (sequence,
+ * query head); query head h reads key / value head h / (q_heads / kv_heads).  qkv: device bf16 [batch * seq][(q_heads + 2 kv_heads)
+ * * 128] - query heads, key heads, value heads of each token, the output of one GEMM over the stacked projection weights after
+ * ts_qk_norm_rope; attention_mask: device int64 [batch][seq], 0 = padding key, or NULL; out: device bf16 [batch * seq][q_heads * 128].
+ * head_dim must be 128 and seq at most 64 (TS_ERR_UNSUPPORTED otherwise: the caller keeps its library attention).  A query row
+ * without a single allowed key (a padding token on the left of a causal sequence) comes back as zeros. */
+int ts_attention_gqa(int device, const void *qkv, const int64_t *attention_mask, int32_t batch, int32_t seq, int32_t q_heads,
+                    int32_t kv_heads, int32_t head_dim, int causal, void *out, void *stream);
+
 /* The decoder-style encoder the production app embeds with (Qwen/Qwen3-Embedding-0.6B, streamlit_app.py:55;
  * ec2/generate_embeddings/embedders.py:1-4): RMSNorm, rotary positions, grouped-query attention, gated MLP.  Three kernels for
  * what its layers do around the GEMMs; each follows the roundings of the torch modules it replaces.

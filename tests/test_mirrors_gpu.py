@@ -578,6 +578,52 @@ def test_short_sequence_attention_kernel_matches_fp64():
             _ffi.check(lib.ts_attention_short(0, C.c_void_p(qkv.data_ptr()), None, 1, S, 1, hd, C.c_void_p(out.data_ptr()), st))
 
 
+def test_gqa_causal_attention_kernel_matches_fp64():
+    """ts_attention_gqa = softmax(Q K^T / sqrt(128) + causal + key mask) V per (sequence, query head), query head h over key /
+    value head h / (hq / hkv), from the stacked projection's layout [tokens][(hq + 2 hkv) * 128] (Qwen3Attention, the production
+    embedder: streamlit_app.py:55), against the same expression in fp64 on the same bf16 inputs: every tile count up to 64
+    tokens, ragged lengths, padding on the LEFT (the Qwen tokenizer's side: the padding rows of a causal sequence have no allowed
+    key and come back as zeros) and on the right, causal and not, 16 / 8 and 4 / 4 heads; longer sequences and other head sizes
+    are refused."""
+    import ctypes as C
+    import torch
+    from theoremsearch_amd import _ffi
+    lib = _ffi.load()
+    g = torch.Generator(device="cpu").manual_seed(12)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for B, S, HQ, HKV in ((3, 1, 2, 1), (5, 7, 4, 2), (4, 16, 16, 8), (9, 19, 6, 2), (6, 32, 16, 8), (3, 33, 4, 4), (2, 48, 6, 3),
+                          (5, 61, 2, 2), (2, 64, 16, 8)):
+        qkv = (torch.randn((B, S, (HQ + 2 * HKV), 128), generator=g) * 1.2).to(torch.bfloat16).cuda()
+        lens = torch.randint(1, S + 1, (B,), generator=g)
+        right = (torch.arange(S)[None, :] < lens[:, None]).to(torch.int64).cuda()
+        left = (torch.arange(S)[None, :] >= (S - lens)[:, None]).to(torch.int64).cuda()
+        rep = HQ // HKV
+        q = qkv[:, :, :HQ].permute(0, 2, 1, 3).double()                                           # [B][HQ][S][128]
+        k = qkv[:, :, HQ:HQ + HKV].permute(0, 2, 1, 3).double().repeat_interleave(rep, dim=1)
+        v = qkv[:, :, HQ + HKV:].permute(0, 2, 1, 3).double().repeat_interleave(rep, dim=1)
+        for causal in (True, False):
+            for mask in (None, right, left):
+                sc = q @ k.transpose(-1, -2) / (128.0 ** 0.5)
+                allow = torch.ones((B, 1, S, S), dtype=torch.bool, device="cuda")
+                if causal:
+                    allow = allow & torch.ones((S, S), dtype=torch.bool, device="cuda").tril_()[None, None]
+                if mask is not None:
+                    allow = allow & (mask[:, None, None, :] != 0)
+                sc = sc.masked_fill(~allow, float("-inf"))
+                p = torch.softmax(sc, dim=-1)
+                p = torch.where(allow.any(dim=-1, keepdim=True), p, torch.zeros_like(p))          # a row without a key: zeros
+                want = (p @ v).permute(0, 2, 1, 3).reshape(B, S, HQ * 128)
+                out = torch.empty((B, S, HQ * 128), dtype=torch.bfloat16, device="cuda")
+                _ffi.check(lib.ts_attention_gqa(0, C.c_void_p(qkv.data_ptr()), C.c_void_p(mask.data_ptr()) if mask is not None else None,
+                                               B, S, HQ, HKV, 128, 1 if causal else 0, C.c_void_p(out.data_ptr()), st))
+                torch.cuda.synchronize()
+                err = (out.double() - want).abs().max().item()
+                assert err <= 3e-2, (B, S, HQ, HKV, causal, mask is not None, err)                # bf16 probabilities and output
+    for S, hd in ((65, 128), (16, 64)):
+        with pytest.raises(_ffi.TSearchError):
+            _ffi.check(lib.ts_attention_gqa(0, C.c_void_p(qkv.data_ptr()), None, 1, S, 2, 1, hd, 1, C.c_void_p(out.data_ptr()), st))
+
+
 def test_fused_bert_forward_matches_the_models_own(encoder):
     """FusedBertForward (QKV as one GEMM, add + LayerNorm as one kernel) against the model's own forward on the same bf16
     weights: hidden states of the real tokens within bf16 noise, sentence embeddings within 2e-2 and cosine > 0.9995;

@@ -111,7 +111,7 @@ extern "C" int ts_attention_short(int device, const void* qkv, const int64_t* at
     const unsigned grid = (unsigned)(((int64_t)batch * heads + 3) / 4);
     const unsigned short* in = (const unsigned short*)qkv;
     unsigned short* o = (unsigned short*)out;
-    // 65 .. 128 tokens: one query tile at a time (attention_rows_kernel, dynamic LDS: 4 waves x up to 22.5 KB)
+    // 65 .. 128 tokens: one query tile at a time (attention_rows_kernel, dynamic LDS: 4 waves x up to 17 KB, two workgroups per CU)
 #define TS_ATTN_ROWS(T_)                                                                                                     \
     do {                                                                                                                     \
         constexpr int lds_ = 4 * attn_rows_wave_lds(T_);                                                                     \
@@ -167,6 +167,44 @@ extern "C" int ts_add_rmsnorm(int device, const void* a, const void* b, const vo
     return TS_OK;
 }
 
+extern "C" int ts_attention_gqa(int device, const void* qkv, const int64_t* attention_mask, int32_t batch, int32_t seq, int32_t q_heads,
+                               int32_t kv_heads, int32_t head_dim, int causal, void* out, void* stream) {
+    if (!qkv || !out) return fail(TS_ERR_INVALID, "NULL argument");
+    if (batch < 0 || seq < 1 || q_heads < 1 || kv_heads < 1 || q_heads % kv_heads != 0)
+        return fail(TS_ERR_INVALID, "batch = %d, seq = %d, heads = %d over %d", batch, seq, q_heads, kv_heads);
+    if (head_dim != 128 || seq > kAttnGqaMaxSeq)
+        return fail(TS_ERR_UNSUPPORTED, "head size %d / %d tokens: this kernel serves head size 128 and at most %d tokens", head_dim, seq,
+                    kAttnGqaMaxSeq);
+    if ((((uintptr_t)qkv | (uintptr_t)out) & 15) != 0) return fail(TS_ERR_INVALID, "qkv and out must be 16-byte aligned");
+    if (batch == 0) return TS_OK;
+    TS_TRY(check_device(device));
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)(((int64_t)batch * q_heads + 3) / 4);
+    const unsigned short* in = (const unsigned short*)qkv;
+    unsigned short* o = (unsigned short*)out;
+#define TS_ATTN_GQA(T_, C_)                                                                                                  \
+    do {                                                                                                                     \
+        constexpr int lds_ = 4 * attn_gqa_wave_lds(T_);                                                                      \
+        static std::atomic<unsigned long long> attr_{0};                                                                     \
+        const unsigned long long bit_ = 1ull << (device & 63);                                                               \
+        if (!(attr_.load(std::memory_order_acquire) & bit_)) {                                                               \
+            HIP_TRY(hipFuncSetAttribute((const void*)attention_gqa_kernel<T_, C_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_)); \
+            attr_.fetch_or(bit_, std::memory_order_release);                                                                 \
+        }                                                                                                                    \
+        attention_gqa_kernel<T_, C_><<<grid, 256, lds_, st>>>(in, attention_mask, batch, seq, q_heads, kv_heads, o);         \
+    } while (0)
+    const int tiles = (seq + 15) / 16;
+    if (causal) {
+        if (tiles == 1) TS_ATTN_GQA(1, true); else if (tiles == 2) TS_ATTN_GQA(2, true); else if (tiles == 3) TS_ATTN_GQA(3, true); else TS_ATTN_GQA(4, true);
+    } else {
+        if (tiles == 1) TS_ATTN_GQA(1, false); else if (tiles == 2) TS_ATTN_GQA(2, false); else if (tiles == 3) TS_ATTN_GQA(3, false); else TS_ATTN_GQA(4, false);
+    }
+#undef TS_ATTN_GQA
+    HIP_TRY(hipGetLastError());
+    return TS_OK;
+}
+
 extern "C" int ts_qk_norm_rope(int device, void* qkv, const void* q_weight, const void* k_weight, const void* cos_table,
                                const void* sin_table, float eps, int64_t tokens, int32_t seq, int32_t q_heads, int32_t kv_heads,
                                int32_t head_dim, int dtype, void* stream) {
@@ -178,7 +216,8 @@ extern "C" int ts_qk_norm_rope(int device, void* qkv, const void* q_weight, cons
     TS_TRY(check_device(device));
     HIP_TRY(hipSetDevice(device));
     const int64_t items = tokens * (q_heads + kv_heads);
-    const unsigned grid = (unsigned)((items + 3) / 4);
+    const int per_wg = 4 * (dtype == TS_BF16 ? 4 : 2);                  // 4 waves x (64 lanes / (128 / VEC) lanes per head)
+    const unsigned grid = (unsigned)((items + per_wg - 1) / per_wg);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == TS_F32) qk_norm_rope_kernel<0><<<grid, 256, 0, st>>>(qkv, q_weight, k_weight, cos_table, sin_table, eps, tokens, seq, q_heads, kv_heads);
     else qk_norm_rope_kernel<1><<<grid, 256, 0, st>>>(qkv, q_weight, k_weight, cos_table, sin_table, eps, tokens, seq, q_heads, kv_heads);

@@ -190,11 +190,13 @@ __global__ void __launch_bounds__(256) attention_short_kernel(const unsigned sho
 // V^T fragments (4 x KS) stay in registers for the whole problem and the wave walks the query tiles: scores of ONE tile against
 // all keys (T x 4 registers) -> softmax over registers and quarter-wave shuffles, exactly as above (every key of a row is in
 // hand: no running maximum, no rescaling) -> P tile through wave-private LDS -> O^T tile -> whole 128-byte rows out.
-// LDS per wave: P tile [16][PP] + V^T [64][PP] + O tile [16][72], bf16: 22.5 KB at T = 8; one workgroup (4 waves) per CU.
+// LDS per wave: V^T [64][PP] bf16 (17 KB at T = 8) - and nothing else: once the V^T fragments are in registers the image is
+// dead, and the P tile [16][PP] and the O tile [16][72] of the query loop live in its place.  Two workgroups per CU instead of
+// one (the first cut kept all three: 22.5 KB per wave, one wave per SIMD, every latency of the serial chain exposed).
 constexpr int kAttnRowsMaxSeq = 128;
 constexpr int attn_rows_wave_lds(int T) {
     const int sp = 16 * T, ks = (sp + 31) / 32, pp = 32 * ks + 8;
-    return 16 * pp * 2 + 64 * pp * 2 + 16 * (64 + 8) * 2;
+    return 64 * pp * 2;
 }
 
 template <int T>
@@ -212,9 +214,10 @@ __global__ void __launch_bounds__(256) attention_rows_kernel(const unsigned shor
     const int r16 = lane & 15, g = lane >> 4;
     const int64_t tok = (int64_t)3 * H * 64;
     const unsigned short* base = qkv + (int64_t)b * S * tok + h * 64;
-    unsigned short* sP = (unsigned short*)(attn_smem + (size_t)wave * attn_rows_wave_lds(T));
-    unsigned short* sVT = sP + 16 * PP;
-    unsigned short* sO = sVT + 64 * PP;
+    unsigned short* sVT = (unsigned short*)(attn_smem + (size_t)wave * attn_rows_wave_lds(T));
+    unsigned short* sP = sVT;                      // after the V^T fragments have been read (below)
+    unsigned short* sO = sVT + 16 * PP;
+    static_assert(16 * PP + 16 * OP <= 64 * PP, "P and O tiles fit the V^T image");
 
     // K fragments of every key tile, the first query tile's fragments and the V rows: all requested before the first use
     bf16x8 kf[T][2], qf[2];
@@ -242,8 +245,7 @@ __global__ void __launch_bounds__(256) attention_rows_kernel(const unsigned shor
         const int key = 16 * kj + r16;
         keyok[kj] = key < S && (!mask || mask[(int64_t)b * S + key] != 0);
     }
-    // keys past the padded sequence inside the last 32-key step: zeros in P (never rewritten: the tile's stores stop at SP) and in V^T
-    for (int i = lane; i < 16 * PP / 8; i += 64) ((uint4*)sP)[i] = make_uint4(0u, 0u, 0u, 0u);
+    // keys past the padded sequence inside the last 32-key step: zeros in V^T (and in P, below)
     if (KS * 32 > SP)
         for (int i = lane; i < 64 * PP / 8; i += 64) ((uint4*)sVT)[i] = make_uint4(0u, 0u, 0u, 0u);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -270,6 +272,15 @@ __global__ void __launch_bounds__(256) attention_rows_kernel(const unsigned shor
     for (int dj = 0; dj < 4; ++dj)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) vf[dj][ks] = *(const bf16x8*)(sVT + (16 * dj + r16) * PP + 32 * ks + 8 * g);
+    // the image is dead from here on (the wave's LDS operations execute in order: the reads above come first); the P tile
+    // takes its place, zeroed once: the tile's stores stop at SP, the columns past it stay zero
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int i = lane; i < 16 * PP / 8; i += 64) ((uint4*)sP)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     constexpr float kScaleLog2e = 0.125f * 1.4426950408889634f;
     unsigned short* obase = out + (int64_t)b * S * H * 64 + h * 64;
@@ -337,6 +348,178 @@ __global__ void __launch_bounds__(256) attention_rows_kernel(const unsigned shor
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         qf[0] = qn[0];
         qf[1] = qn[1];
+    }
+}
+
+// ---- head size 128, grouped-query, causal: the attention of the Qwen3-family encoder ---------------------------------------
+// Qwen/Qwen3-Embedding-0.6B is what the production app embeds with (streamlit_app.py:55, ec2/generate_embeddings/embedders.py:1-4):
+// 16 query heads over 8 key / value heads of 128, causal, queries of one sentence each.  At 256 sequences x 32 tokens the
+// library's flash-attention launch takes 202 us per layer (profiles/r04_c5_qwen_kernel_stats.csv: 5.7 of the step's 20.7 ms);
+// the whole problem of a (sequence, query head) is 24 KB and 32 MFMAs.  The same wave-per-problem form as attention_short_kernel:
+//   qkv [tokens][(hq + 2 hkv) * 128]: query heads, key heads, value heads of each token (the output of ONE GEMM over the
+//   stacked projection weights, after ts_qk_norm_rope);  query head h reads key / value head h / (hq / hkv);
+//   scores D[q][key] = Q K^T over four 32-deep k-steps, allowed = key <= q (causal) and not a padding key, softmax in fp32
+//   (scale 1 / sqrt(128)), P -> LDS (bf16) -> O^T = V^T P^T with V^T [128][keys] transposed through LDS;
+//   out [tokens][hq * 128].
+// LDS per wave: V^T image + P image; the O tile reuses the V^T image once its fragments are in registers.
+constexpr int kAttnGqaMaxSeq = 64;
+constexpr int attn_gqa_wave_lds(int T) {
+    const int sp = 16 * T, ks = (sp + 31) / 32, pp = 32 * ks + 8;
+    return 128 * pp * 2 + sp * pp * 2;
+}
+
+template <int T, bool CAUSAL>
+__global__ void __launch_bounds__(256) attention_gqa_kernel(const unsigned short* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                             int B, int S, int HQ, int HKV, unsigned short* __restrict__ out) {
+    constexpr int HD = 128;
+    constexpr int SP = 16 * T;
+    constexpr int KS = (SP + 31) / 32;
+    constexpr int PP = 32 * KS + 8;
+    constexpr int OP = HD + 8;
+    static_assert(SP * OP <= HD * PP, "the O tile fits the V^T image");
+    extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bh = blockIdx.x * 4 + wave;
+    if (bh >= B * HQ) return;
+    const int b = bh / HQ, h = bh - b * HQ;
+    const int kvh = h / (HQ / HKV);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int64_t tok = (int64_t)(HQ + 2 * HKV) * HD;
+    const unsigned short* qb = qkv + (int64_t)b * S * tok + (int64_t)h * HD;
+    const unsigned short* kb = qkv + (int64_t)b * S * tok + (int64_t)(HQ + kvh) * HD;
+    const unsigned short* vb = qkv + (int64_t)b * S * tok + (int64_t)(HQ + HKV + kvh) * HD;
+    unsigned short* sVT = (unsigned short*)(attn_smem + (size_t)wave * attn_gqa_wave_lds(T));
+    unsigned short* sP = sVT + HD * PP;
+    unsigned short* sO = sVT;                        // after the V^T fragments have been read
+
+    bf16x8 qf[T][4], kf[T][4];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int row = min(16 * t + r16, S - 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[t][ks] = *(const bf16x8*)(qb + row * tok + 32 * ks + 8 * g);
+            kf[t][ks] = *(const bf16x8*)(kb + row * tok + 32 * ks + 8 * g);
+        }
+    }
+    // V rows as they lie: 16 lanes x 16 bytes per row, four key pairs per pass (lane >> 4)
+    constexpr int KP = SP / 2;
+    constexpr int VI = (KP + 3) / 4;
+    uint4 v0[VI], v1[VI];
+#pragma unroll
+    for (int i = 0; i < VI; ++i) {
+        const int kp = g + 4 * i;
+        const int k0 = min(2 * kp, S - 1), k1 = min(2 * kp + 1, S - 1);
+        v0[i] = *(const uint4*)(vb + k0 * tok + 8 * r16);
+        v1[i] = *(const uint4*)(vb + k1 * tok + 8 * r16);
+    }
+    bool keyok[T];
+#pragma unroll
+    for (int kj = 0; kj < T; ++kj) {
+        const int key = 16 * kj + r16;
+        keyok[kj] = key < S && (!mask || mask[(int64_t)b * S + key] != 0);
+    }
+    for (int i = lane; i < SP * PP / 8; i += 64) ((uint4*)sP)[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (KS * 32 > SP)
+        for (int i = lane; i < HD * PP / 8; i += 64) ((uint4*)sVT)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < VI; ++i) {
+        const int kp = g + 4 * i;
+        if (kp < KP) {
+            const u32 a[4] = {v0[i].x, v0[i].y, v0[i].z, v0[i].w}, c[4] = {v1[i].x, v1[i].y, v1[i].z, v1[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                u32* dst = (u32*)(sVT + (8 * r16 + 2 * e) * PP + 2 * kp);
+                dst[0] = (a[e] & 0xFFFFu) | (c[e] << 16);
+                *(u32*)((unsigned short*)dst + PP) = (a[e] >> 16) | (c[e] & 0xFFFF0000u);
+            }
+        }
+    }
+
+    f32x4 sc[T][T];
+#pragma unroll
+    for (int qi = 0; qi < T; ++qi)
+#pragma unroll
+        for (int kj = 0; kj < T; ++kj) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            if (!CAUSAL || kj <= qi) {               // a key tile past the query tile holds no allowed key
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[qi][ks], kf[kj][ks], a, 0, 0, 0);
+            }
+            sc[qi][kj] = a;
+        }
+    constexpr float kScaleLog2e = 0.08838834764831845f * 1.4426950408889634f;     // 1 / sqrt(128), exp through exp2
+#pragma unroll
+    for (int qi = 0; qi < T; ++qi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qrow = 16 * qi + 4 * g + r;
+            bool ok[T];
+#pragma unroll
+            for (int kj = 0; kj < T; ++kj) ok[kj] = keyok[kj] && (!CAUSAL || 16 * kj + r16 <= qrow);
+            float m = -INFINITY;
+#pragma unroll
+            for (int kj = 0; kj < T; ++kj) m = fmaxf(m, ok[kj] ? sc[qi][kj][r] : -INFINITY);
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            float e[T], sum = 0.0f;
+#pragma unroll
+            for (int kj = 0; kj < T; ++kj) {
+                e[kj] = ok[kj] ? exp2f((sc[qi][kj][r] - m) * kScaleLog2e) : 0.0f;
+                sum += e[kj];
+            }
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) sum += __shfl_xor(sum, off, 64);
+            const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;        // a row without a single allowed key: zeros
+#pragma unroll
+            for (int kj = 0; kj < T; ++kj) sP[qrow * PP + 16 * kj + r16] = f32_to_bf16(e[kj] * inv);
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    bf16x8 pf[T][KS];
+#pragma unroll
+    for (int qi = 0; qi < T; ++qi)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) pf[qi][ks] = *(const bf16x8*)(sP + (16 * qi + r16) * PP + 32 * ks + 8 * g);
+    // O^T tile by tile of 16 head dimensions: the V^T fragments of a tile are read, used and dropped (8 x KS x 4 registers
+    // would not fit beside the rest at T = 4)
+    f32x4 oc[HD / 16][T];
+#pragma unroll
+    for (int dj = 0; dj < HD / 16; ++dj) {
+        bf16x8 vf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) vf[ks] = *(const bf16x8*)(sVT + (16 * dj + r16) * PP + 32 * ks + 8 * g);
+#pragma unroll
+        for (int qi = 0; qi < T; ++qi) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[ks], pf[qi][ks], a, 0, 0, 0);
+            oc[dj][qi] = a;
+        }
+    }
+    // the V^T image has been read: the same LDS takes O as [q][d]
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int dj = 0; dj < HD / 16; ++dj)
+#pragma unroll
+        for (int qi = 0; qi < T; ++qi) {
+            const u32 lo = (u32)f32_to_bf16(oc[dj][qi][0]) | ((u32)f32_to_bf16(oc[dj][qi][1]) << 16);
+            const u32 hi = (u32)f32_to_bf16(oc[dj][qi][2]) | ((u32)f32_to_bf16(oc[dj][qi][3]) << 16);
+            *(uint2*)(sO + (16 * qi + r16) * OP + 16 * dj + 4 * g) = make_uint2(lo, hi);
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    unsigned short* obase = out + (int64_t)b * S * HQ * HD + (int64_t)h * HD;
+    for (int i = lane; i < SP * 16; i += 64) {
+        const int q = i >> 4, c = i & 15;
+        if (q < S) *(uint4*)(obase + (int64_t)q * HQ * HD + 8 * c) = *(const uint4*)(sO + q * OP + 8 * c);
     }
 }
 

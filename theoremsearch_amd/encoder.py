@@ -630,8 +630,11 @@ class FusedQwen3Forward:
       twenty-two launches per layer in PyTorch);
     * ``silu(gate) * up`` as ONE kernel (``ts_swiglu``).
 
-    Same weights, same order of operations, the roundings of the modules replaced; the attention itself is
-    ``scaled_dot_product_attention`` (causal, grouped-query), as the model's own ``sdpa`` path."""
+    * causal grouped-query attention of short sequences (bf16, up to 64 tokens) as ONE kernel straight from the stacked
+      projection (``ts_attention_gqa``: one wave per (sequence, query head); torch's flash-attention launch took 202 us per
+      layer at 256 sequences x 32 tokens); longer sequences and fp32 keep ``scaled_dot_product_attention``.
+
+    Same weights, same order of operations, the roundings of the modules replaced."""
 
     def __init__(self, model):
         cfg = model.config
@@ -693,6 +696,24 @@ class FusedQwen3Forward:
             C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)))
         return (new_res if new_res is not None else a), out
 
+    def _sdpa(self, qkv: torch.Tensor, mask: Optional[torch.Tensor], B: int, S: int, nq: int, nkv: int, hd: int) -> torch.Tensor:
+        """torch's attention on the stacked projection (longer sequences, fp32): causal, grouped-query, as the model's own sdpa path."""
+        F = torch.nn.functional
+        q = qkv[..., :nq].view(B, S, self.hq, hd).transpose(1, 2)
+        k = qkv[..., nq:nq + nkv].view(B, S, self.hkv, hd).transpose(1, 2)
+        v = qkv[..., nq + nkv:].view(B, S, self.hkv, hd).transpose(1, 2)
+        ctx = None
+        if self._gqa_native:
+            try:
+                ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, is_causal=mask is None, enable_gqa=True)
+            except (RuntimeError, TypeError):
+                self._gqa_native = False
+        if ctx is None:
+            rep = self.hq // self.hkv
+            ctx = F.scaled_dot_product_attention(q, k.repeat_interleave(rep, dim=1), v.repeat_interleave(rep, dim=1),
+                                                 attn_mask=mask, is_causal=mask is None)
+        return ctx.transpose(1, 2).reshape(B, S, nq)
+
     def __call__(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, token_type_ids: Optional[torch.Tensor] = None,
                  no_padding: bool = False):
         import ctypes as C
@@ -710,7 +731,11 @@ class FusedQwen3Forward:
         cos, sin = m.rotary_emb(x, pos)                                  # [1 x S x 128] of the model's type
         cos, sin = cos[0].contiguous(), sin[0].contiguous()
         mask = None
-        if not no_padding:
+        # short sequences in bf16: the library's own causal grouped-query attention (TS_ENCODER_ATTENTION=0 keeps torch's)
+        short = (x.dtype == torch.bfloat16 and self.hd == 128 and S <= 64 and x.is_contiguous() and
+                 os.environ.get("TS_ENCODER_ATTENTION", "1") != "0")
+        key_mask = None if (no_padding or not short) else attention_mask.to(torch.int64).contiguous()
+        if not no_padding and not short:
             # causal, and padding keys are never attended to (the most negative finite value: rows of padding stay finite)
             neg = torch.finfo(x.dtype).min
             causal = torch.ones((S, S), dtype=torch.bool, device=x.device).tril_()
@@ -723,20 +748,13 @@ class FusedQwen3Forward:
             _ffi.check(lib.ts_qk_norm_rope(dev, C.c_void_p(qkv.data_ptr()), C.c_void_p(L["qn"].data_ptr()), C.c_void_p(L["kn"].data_ptr()),
                                            C.c_void_p(cos.data_ptr()), C.c_void_p(sin.data_ptr()), self.eps, B * S, S, self.hq, self.hkv,
                                            hd, dt, stream))
-            q = qkv[..., :nq].view(B, S, self.hq, hd).transpose(1, 2)
-            k = qkv[..., nq:nq + nkv].view(B, S, self.hkv, hd).transpose(1, 2)
-            v = qkv[..., nq + nkv:].view(B, S, self.hkv, hd).transpose(1, 2)
-            ctx = None
-            if self._gqa_native:
-                try:
-                    ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, is_causal=mask is None, enable_gqa=True)
-                except (RuntimeError, TypeError):
-                    self._gqa_native = False
-            if ctx is None:
-                rep = self.hq // self.hkv
-                ctx = F.scaled_dot_product_attention(q, k.repeat_interleave(rep, dim=1), v.repeat_interleave(rep, dim=1),
-                                                     attn_mask=mask, is_causal=mask is None)
-            ctx = ctx.transpose(1, 2).reshape(B, S, nq)
+            if short:
+                # one wave per (sequence, query head), straight from the stacked projection's output (ts_attention_gqa)
+                ctx = torch.empty((B, S, nq), dtype=x.dtype, device=x.device)
+                _ffi.check(lib.ts_attention_gqa(dev, C.c_void_p(qkv.data_ptr()), C.c_void_p(key_mask.data_ptr()) if key_mask is not None else None,
+                                               B, S, self.hq, self.hkv, hd, 1, C.c_void_p(ctx.data_ptr()), stream))
+            else:
+                ctx = self._sdpa(qkv, mask, B, S, nq, nkv, hd)
             x, h = self._add_rmsnorm(x, F.linear(ctx, L["wo"]), L["ln2"], True)
             gu = F.linear(h, L["wgu"])
             inter = gu.shape[-1] // 2

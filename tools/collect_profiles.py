@@ -49,8 +49,11 @@ def main(src, tag):
         fetch = pmc_per_launch(os.path.join(src, f"pmc_{w}_FETCH_SIZE"), "FETCH_SIZE", kern)
         write = pmc_per_launch(os.path.join(src, f"pmc_{w}_WRITE_SIZE"), "WRITE_SIZE", kern)
         if fetch:
-            # the full-corpus pass is the launch with the largest fetch
-            f_kib, w_kib = max(fetch), (max(write) if write else 0.0)
+            # the full-corpus passes are the launches with the largest fetch: the median of those within a factor 2 of it
+            def typical(v):
+                big = sorted(x for x in v if x >= 0.5 * max(v))
+                return big[len(big) // 2]
+            f_kib, w_kib = typical(fetch), (typical(write) if write else 0.0)
             hbm = 2.0 * f_kib * 1024.0 + w_kib * 1024.0
             traffic[f"{w}_n1"] = int(hbm)
             notes.append(f"{w}: kernel {kern}: FETCH_SIZE {f_kib:.0f} KiB (x2 gfx950 correction) + WRITE_SIZE {w_kib:.0f} KiB "
