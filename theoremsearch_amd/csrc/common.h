@@ -43,6 +43,22 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
     return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
 
+// The same rounding by the hardware (gfx950: v_cvt_pk_bf16_f32, two values per instruction; RNE, NaN stays NaN - the payload
+// may differ from the software form's).  For the kernels around the encoder's GEMMs, whose roundings are emulated many
+// times per element; the index's own storage (prep_rows_kernel) keeps the software form the oracle restates bit for bit.
+typedef __bf16 ts_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float ts_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32 pack_bf16_hw(float lo, float hi) {
+    const ts_f32x2 v = {lo, hi};
+    const ts_bf16x2 r = __builtin_convertvector(v, ts_bf16x2);
+    return *reinterpret_cast<const u32*>(&r);
+}
+__device__ __forceinline__ void round2_bf16_hw(float& a, float& b) {
+    const u32 p = pack_bf16_hw(a, b);
+    a = bf16_lo(p);
+    b = bf16_hi(p);
+}
+
 // ---- wave helpers ---------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

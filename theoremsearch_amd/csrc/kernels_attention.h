@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(256) attention_short_kernel(const unsigned sho
             for (int off = 1; off < 16; off <<= 1) sum += __shfl_xor(sum, off, 64);
             const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;        // a row without a single allowed key: zeros
 #pragma unroll
-            for (int kj = 0; kj < T; ++kj) sP[(16 * qi + 4 * g + r) * PP + 16 * kj + r16] = f32_to_bf16(e[kj] * inv);
+            for (int kj = 0; kj < T; ++kj) sP[(16 * qi + 4 * g + r) * PP + 16 * kj + r16] = (unsigned short)pack_bf16_hw(e[kj] * inv, 0.0f);
         }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -169,8 +169,8 @@ __global__ void __launch_bounds__(256) attention_short_kernel(const unsigned sho
     for (int dj = 0; dj < 4; ++dj)
 #pragma unroll
         for (int qi = 0; qi < T; ++qi) {
-            const u32 lo = (u32)f32_to_bf16(oc[dj][qi][0]) | ((u32)f32_to_bf16(oc[dj][qi][1]) << 16);
-            const u32 hi = (u32)f32_to_bf16(oc[dj][qi][2]) | ((u32)f32_to_bf16(oc[dj][qi][3]) << 16);
+            const u32 lo = pack_bf16_hw(oc[dj][qi][0], oc[dj][qi][1]);
+            const u32 hi = pack_bf16_hw(oc[dj][qi][2], oc[dj][qi][3]);
             *(uint2*)(sO + (16 * qi + r16) * OP + 16 * dj + 4 * g) = make_uint2(lo, hi);
         }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(256) attention_rows_kernel(const unsigned shor
             for (int off = 1; off < 16; off <<= 1) sum += __shfl_xor(sum, off, 64);
             const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;
 #pragma unroll
-            for (int kj = 0; kj < T; ++kj) sP[(4 * g + r) * PP + 16 * kj + r16] = f32_to_bf16(e[kj] * inv);
+            for (int kj = 0; kj < T; ++kj) sP[(4 * g + r) * PP + 16 * kj + r16] = (unsigned short)pack_bf16_hw(e[kj] * inv, 0.0f);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -330,8 +330,8 @@ __global__ void __launch_bounds__(256) attention_rows_kernel(const unsigned shor
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dj][ks], pf[ks], a, 0, 0, 0);
-            const u32 lo = (u32)f32_to_bf16(a[0]) | ((u32)f32_to_bf16(a[1]) << 16);
-            const u32 hi = (u32)f32_to_bf16(a[2]) | ((u32)f32_to_bf16(a[3]) << 16);
+            const u32 lo = pack_bf16_hw(a[0], a[1]);
+            const u32 hi = pack_bf16_hw(a[2], a[3]);
             *(uint2*)(sO + r16 * OP + 16 * dj + 4 * g) = make_uint2(lo, hi);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -361,6 +361,9 @@ __global__ void __launch_bounds__(256) attention_rows_kernel(const unsigned shor
 //   scores D[q][key] = Q K^T over four 32-deep k-steps, allowed = key <= q (causal) and not a padding key, softmax in fp32
 //   (scale 1 / sqrt(128)), P -> LDS (bf16) -> O^T = V^T P^T with V^T [128][keys] transposed through LDS;
 //   out [tokens][hq * 128].
+// (The per-head RMSNorm of q / k and the rotary embedding were also applied to the fragments on the way in, in place of
+// ts_qk_norm_rope's launch: the transform took the kernel from two or three waves per SIMD to one, and the step of the
+// Qwen3-shaped encoder did not move - 14.60 against 14.65 ms.  Removed; profiles/HISTORY.md, round 4.)
 // LDS per wave: V^T image + P image; the O tile reuses the V^T image once its fragments are in registers.
 constexpr int kAttnGqaMaxSeq = 64;
 constexpr int attn_gqa_wave_lds(int T) {
@@ -369,8 +372,9 @@ constexpr int attn_gqa_wave_lds(int T) {
 }
 
 template <int T, bool CAUSAL>
-__global__ void __launch_bounds__(256) attention_gqa_kernel(const unsigned short* __restrict__ qkv, const int64_t* __restrict__ mask,
-                                                             int B, int S, int HQ, int HKV, unsigned short* __restrict__ out) {
+__global__ void __launch_bounds__(256, (T <= 2 ? 2 : 1)) attention_gqa_kernel(const unsigned short* __restrict__ qkv,
+                                                                               const int64_t* __restrict__ mask, int B, int S, int HQ, int HKV,
+                                                                               unsigned short* __restrict__ out) {
     constexpr int HD = 128;
     constexpr int SP = 16 * T;
     constexpr int KS = (SP + 31) / 32;
@@ -475,7 +479,7 @@ __global__ void __launch_bounds__(256) attention_gqa_kernel(const unsigned short
             for (int off = 1; off < 16; off <<= 1) sum += __shfl_xor(sum, off, 64);
             const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;        // a row without a single allowed key: zeros
 #pragma unroll
-            for (int kj = 0; kj < T; ++kj) sP[qrow * PP + 16 * kj + r16] = f32_to_bf16(e[kj] * inv);
+            for (int kj = 0; kj < T; ++kj) sP[qrow * PP + 16 * kj + r16] = (unsigned short)pack_bf16_hw(e[kj] * inv, 0.0f);
         }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -509,8 +513,8 @@ __global__ void __launch_bounds__(256) attention_gqa_kernel(const unsigned short
     for (int dj = 0; dj < HD / 16; ++dj)
 #pragma unroll
         for (int qi = 0; qi < T; ++qi) {
-            const u32 lo = (u32)f32_to_bf16(oc[dj][qi][0]) | ((u32)f32_to_bf16(oc[dj][qi][1]) << 16);
-            const u32 hi = (u32)f32_to_bf16(oc[dj][qi][2]) | ((u32)f32_to_bf16(oc[dj][qi][3]) << 16);
+            const u32 lo = pack_bf16_hw(oc[dj][qi][0], oc[dj][qi][1]);
+            const u32 hi = pack_bf16_hw(oc[dj][qi][2], oc[dj][qi][3]);
             *(uint2*)(sO + (16 * qi + r16) * OP + 16 * dj + 4 * g) = make_uint2(lo, hi);
         }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

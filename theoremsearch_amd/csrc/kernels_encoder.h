@@ -383,16 +383,13 @@ __device__ __forceinline__ void enc_unpack(const uint4& v, float* f) {
 template <int DT>
 __device__ __forceinline__ uint4 enc_pack(const float* y) {
     if (DT == 0) return make_uint4(__float_as_uint(y[0]), __float_as_uint(y[1]), __float_as_uint(y[2]), __float_as_uint(y[3]));
-    uint4 o;
-    o.x = (u32)f32_to_bf16(y[0]) | ((u32)f32_to_bf16(y[1]) << 16);
-    o.y = (u32)f32_to_bf16(y[2]) | ((u32)f32_to_bf16(y[3]) << 16);
-    o.z = (u32)f32_to_bf16(y[4 % (DT == 0 ? 4 : 8)]) | ((u32)f32_to_bf16(y[5 % (DT == 0 ? 4 : 8)]) << 16);
-    o.w = (u32)f32_to_bf16(y[6 % (DT == 0 ? 4 : 8)]) | ((u32)f32_to_bf16(y[7 % (DT == 0 ? 4 : 8)]) << 16);
-    return o;
+    // hardware conversion (common.h): two values per instruction
+    return make_uint4(pack_bf16_hw(y[0], y[1]), pack_bf16_hw(y[2], y[3]), pack_bf16_hw(y[4 % (DT == 0 ? 4 : 8)], y[5 % (DT == 0 ? 4 : 8)]),
+                      pack_bf16_hw(y[6 % (DT == 0 ? 4 : 8)], y[7 % (DT == 0 ? 4 : 8)]));
 }
 // round to the storage type and back: where the replaced module chain materialises a tensor of that type
 template <int DT>
-__device__ __forceinline__ float enc_round(float v) { return DT == 0 ? v : bf16_to_f32(f32_to_bf16(v)); }
+__device__ __forceinline__ float enc_round(float v) { return DT == 0 ? v : bf16_lo(pack_bf16_hw(v, 0.0f)); }
 
 // Residual add + RMSNorm (Qwen3DecoderLayer: `hidden = residual + sublayer(hidden)` followed by the next RMSNorm):
 //   s    = a + b          rounded to the storage type (torch materialises the sum)       -> out_sum (optional: the new residual)

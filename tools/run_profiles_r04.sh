@@ -2,7 +2,7 @@
 # Round 4, on the GPU box (gpurun): the bench lines and rocprofv3 passes whose summaries tools/collect_profiles.py copies into
 # profiles/.  Usage: bash tools/run_profiles_r04.sh <out-dir under gpurun_out> <part>
 #   part a: c3 (bench, kernel trace, FETCH / WRITE passes, SQ counters), c2, c2b
-#   part b: c3q (10M x 1024 bf16), c5 at 32 and 128 tokens, c5 with the Qwen3-shaped encoder, c1;  part c: c3q alone
+#   part b: c3q (10M x 1024 bf16), c5 at 32 and 128 tokens, c5 with the Qwen3-shaped encoder, c1;  part c: c3q alone;  part d: c5 at 128 tokens and with the Qwen3-shaped encoder
 # Trace and counter passes are separate runs (never --pmc together with a trace domain other than kernel-trace).
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$R/gpurun_out/${1:-r04}"
@@ -29,6 +29,9 @@ if [ "$PART" = "a" ]; then
   pmc c2 FETCH_SIZE --workload c2
   pmc c2 WRITE_SIZE --workload c2
   bench_and_trace c2b --workload c2b || exit 1
+elif [ "$PART" = "d" ]; then
+  bench_and_trace c5_128 --workload c5 --seq-len 128 || exit 1
+  bench_and_trace c5_qwen --workload c5 --encoder qwen || exit 1
 elif [ "$PART" = "c" ]; then
   bench_and_trace c3q --workload c3q || exit 1
   pmc c3q FETCH_SIZE --workload c3q
