@@ -401,6 +401,12 @@ def test_the_product_library_refuses_timing_only_kernel_variants(ts):
             assert e.value.code == -5
         ix.set_option("TS_MFMA_VARIANT", 0)
         ix.set_option("TS_MFMA_VARIANT", None)
+        # round 4: the knobs that only the A/B tools ever turned moved to the diagnostic build with them
+        for name in ("TS_MFMA_NO_IDLE", "TS_MFMA_MIN_RANK", "TS_MFMA_GROUPS", "TS_MFMA_STAT_CANDS", "TS_MFMA_TARGET_CANDS",
+                     "TS_MFMA_TARGET_SPARSE", "TS_MFMA_MIN_ROWS", "TS_SCAN_GENERIC", "TS_SCAN_MAX_QUERIES", "TS_PROBE_SPREAD"):
+            with pytest.raises(_ffi.TSearchError) as e:
+                ix.set_option(name, 1)
+            assert e.value.code == -5, name
 
 
 # ---- citation-weighted ranking on the device ------------------------------------------------

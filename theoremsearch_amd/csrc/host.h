@@ -72,9 +72,16 @@ struct Knobs {
             v[i] = set[i] ? atoi(e) : 0;
         }
 #ifndef TS_DIAG
-        set[K_MFMA_VARIANT] = false;      // the timing-only kernel variants exist in the diagnostic build only (make diag)
-        v[K_MFMA_VARIANT] = 0;
+        // the timing-only kernel variants and the knobs only the A/B tools ever turned exist in the diagnostic build only
+        // (make diag): the product library runs their defaults
+        for (int i = 0; i < K_COUNT; ++i)
+            if (diag_only((Knob)i)) { set[i] = false; v[i] = 0; }
 #endif
+    }
+    static bool diag_only(Knob k) {
+        return k == K_MFMA_VARIANT || k == K_MFMA_MIN_RANK || k == K_MFMA_GROUPS || k == K_MFMA_STAT_CANDS || k == K_MFMA_NO_IDLE ||
+               k == K_MFMA_TARGET_CANDS || k == K_MFMA_TARGET_SPARSE || k == K_MFMA_MIN_ROWS || k == K_SCAN_GENERIC ||
+               k == K_SCAN_MAX_QUERIES || k == K_PROBE_SPREAD;
     }
     int get(Knob k, int dflt) const { return set[k] ? v[k] : dflt; }
 };

@@ -146,6 +146,8 @@ extern "C" int ts_index_set_option(ts_index* ix, const char* name, int32_t value
             if (i == K_MFMA_VARIANT && value != 0)
                 return fail(TS_ERR_UNSUPPORTED, "TS_MFMA_VARIANT = %d: the timing-only kernel variants are compiled into the "
                             "diagnostic build only (make -C theoremsearch_amd/csrc diag; TS_LIB selects it)", value);
+            if (i != K_MFMA_VARIANT && Knobs::diag_only((Knob)i))
+                return fail(TS_ERR_UNSUPPORTED, "%s is an option of the diagnostic build only (make -C theoremsearch_amd/csrc diag)", name);
 #endif
             std::lock_guard<std::mutex> lock(ix->mu);
             ix->knobs.v[i] = value;
