@@ -337,6 +337,10 @@ def main():
     ap.add_argument("--exchange", default="auto", choices=["auto", "native", "torch"],
                     help="N > 1: collective of the per-shard top-k: native = ncclAllGather inside libtsearch (ts_comm_*), "
                          "torch = torch.distributed.all_gather_into_tensor; auto = native on the nccl backend")
+    ap.add_argument("--exchange-placement", default="auto", choices=["auto", "overlap", "inline"],
+                    help="N > 1: where the all-gather + merge of a step run - 'overlap': on a side stream beside the next step's "
+                         "search; 'inline': on the search's own stream; 'auto': both are tried for a few steps before the warm-up "
+                         "and the faster one is used (every rank sees the same timings: max over ranks)")
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="time the CPU baseline for EVERY query of the batch over the whole corpus, 16 queries at a time (minutes; "
                          "default: the whole corpus, as many 16-query chunks as fit in --cpu-baseline-seconds)")
@@ -548,7 +552,7 @@ def main():
             else:
                 qp, qd = q_dev.data_ptr(), dtype
             if searcher is not None:
-                last_out[0] = searcher.search_device(qp, qd, nq, K, stream=lane, algo=args.algo, mask_ptr=mask_ptr)
+                last_out[0] = searcher.search_device(qp, qd, nq, K, stream=lane, algo=args.algo, mask_ptr=mask_ptr, overlap=overlap[0])
             else:
                 base = res[b].data_ptr()
                 handles[i % len(handles)].search_device(qp, qd, nq, K, base, base + idx_off, lane.cuda_stream, algo=args.algo,
@@ -559,6 +563,37 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # Where the exchange of a step runs.  On a side stream it overlaps the next step's search - but the full pass of that
+    # search wants every CU (one workgroup per CU, all registers), and a collective's kernel that sits on a CU waiting for a
+    # slower rank holds the pass's last workgroup back; on the search's own stream it costs its latency every step and
+    # nothing else.  Which is faster depends on the fabric and on how evenly the ranks run: with more than one rank both are
+    # tried (two rounds of `trial` steps each, interleaved, behind a warm-up; the time of a round is the slowest rank's) and
+    # the faster one is used.  One rank has no collective: overlap.
+    overlap = [args.exchange_placement != "inline"]
+    placement_trial = None
+    if searcher is not None and world > 1 and args.exchange_placement == "auto":
+        trial = 40
+        times = {True: [], False: []}
+        for _ in range(trial):
+            step()
+        barrier()
+        for rnd in range(2):
+            for mode in (True, False):
+                overlap[0] = mode
+                barrier()
+                tt = time.perf_counter()
+                for _ in range(trial):
+                    step()
+                torch.cuda.synchronize()
+                barrier()
+                t_ = torch.tensor([time.perf_counter() - tt], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+                times[mode].append(float(t_.item()) / trial * 1e3)
+        overlap[0] = min(times[True]) <= min(times[False])
+        placement_trial = {"overlap_ms_per_step": [round(x, 4) for x in times[True]], "inline_ms_per_step": [round(x, 4) for x in times[False]],
+                           "steps_per_round": trial}
+        log(rank, f"exchange placement: {'overlap' if overlap[0] else 'inline'} ({placement_trial})")
 
     if encoder is not None and args.encoder_graph:
         for lane_ in lanes:
@@ -648,6 +683,8 @@ def main():
     exchange = None
     if searcher is not None:
         exchange = searcher.measure_exchange(nq, K)
+        exchange["placement"] = "overlap (side stream, beside the next step's search)" if overlap[0] else "inline (the search's own stream)"
+        exchange["placement_trial"] = placement_trial
         exchange["launched_by"] = os.environ.get("TS_BENCH_LAUNCHED_BY", "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "env")
         log(rank, f"exchange: {exchange}")
 
