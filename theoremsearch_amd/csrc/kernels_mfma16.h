@@ -273,7 +273,6 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         return;
     }
     const int nu = kUnits * nt;
-
     // The stream starts first: the DMA prologue goes out before the query fragments are fetched, so that the first units
     // cross the chip while 393 KB of fragments per workgroup come out of L2 (both are vector-memory operations: they
     // return in order, the one vmcnt(0) below certifies this wave's pieces of every prologue unit and its fragments).
