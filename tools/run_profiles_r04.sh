@@ -29,6 +29,12 @@ if [ "$PART" = "a" ]; then
   pmc c2 FETCH_SIZE --workload c2
   pmc c2 WRITE_SIZE --workload c2
   bench_and_trace c2b --workload c2b || exit 1
+elif [ "$PART" = "e" ]; then
+  # configs[2] again, the trace over the bench line's own command (300 sustained steps: the average is the steady state's)
+  timeout -k 10 420 python3 "$R/bench.py" --workload c3 > "$OUT/bench_c3.json" 2> "$OUT/bench_c3.log" || exit 1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c3" -- python3 "$R/bench.py" --workload c3 --no-cpu-baseline --no-recall > "$OUT/trace_c3.json" 2> "$OUT/trace_c3.log" || exit 1
+  cp "$(ls -t "$OUT"/trace_c3/*/*kernel_stats.csv | head -1)" "$OUT/c3_kernel_stats.csv"
+  head -3 "$OUT/c3_kernel_stats.csv" | cut -c1-160 >&2
 elif [ "$PART" = "d" ]; then
   bench_and_trace c5_128 --workload c5 --seq-len 128 || exit 1
   bench_and_trace c5_qwen --workload c5 --encoder qwen || exit 1
