@@ -329,10 +329,12 @@ def main():
     ap.add_argument("--gen-threads", type=int, default=0)
     ap.add_argument("--dim", type=int, default=0, help="embedding dimension (default 768, the BASELINE configs'; c3q: 1024)")
     ap.add_argument("--seq-len", type=int, default=32, help="c5: tokens per synthetic query")
-    ap.add_argument("--encoder", default="bert", choices=["bert", "qwen"],
+    ap.add_argument("--encoder", default="bert", choices=["bert", "qwen", "gemma"],
                     help="c5: random-init stand-in of math-similarity/Bert-MLM_arXiv-MP-class_zbMath (BERT-base shape, 768-d: the "
                          "BASELINE config) or of Qwen/Qwen3-Embedding-0.6B (the production embedder, streamlit_app.py:55: 28 layers, "
-                         "1024-d, grouped-query attention, last-token pooling; the index is then 10M x 1024)")
+                         "1024-d, grouped-query attention, last-token pooling; the index is then 10M x 1024) or of google/embeddinggemma-300m "
+                         "(the reference's second embedder, ec2/generate_embeddings/embedders.py:1-4: Gemma3 text model, 24 layers, "
+                         "768-d, mean pooling + two Dense modules)")
     ap.add_argument("--force-dist", action="store_true", help="debug: run the exchange + merge path even with one rank")
     ap.add_argument("--exchange", default="auto", choices=["auto", "native", "torch"],
                     help="N > 1: collective of the per-shard top-k: native = ncclAllGather inside libtsearch (ts_comm_*), "
@@ -486,7 +488,8 @@ def main():
             tunable.set_max_tuning_duration(30)
             tunable.set_max_tuning_iterations(20)
             tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"ts_tunableop_rank{rank}.csv"))
-        enc_name = "Qwen/Qwen3-Embedding-0.6B" if args.encoder == "qwen" else "math-similarity/Bert-MLM_arXiv-MP-class_zbMath"
+        enc_name = {"qwen": "Qwen/Qwen3-Embedding-0.6B", "gemma": "google/embeddinggemma-300m"}.get(
+            args.encoder, "math-similarity/Bert-MLM_arXiv-MP-class_zbMath")
         encoder = SentenceEncoder(enc_name, allow_random_init=True)
         if encoder.embedding_dim != D:
             raise SystemExit(f"the {args.encoder} encoder embeds into {encoder.embedding_dim} dimensions, the index has {D}")
@@ -863,7 +866,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"{rows_total}x{D} {dtype} corpus, batch-{nq} queries, top-{K} "
                                    + (f"(BASELINE.json configs[{ {'c1': 0, 'c2': 1, 'c2b': 1, 'c3': 2, 'c4': 3, 'c5': 4}[args.workload] }])" if args.workload != "c3q" else
-                                      "(the reference's production table shape, theorem_embedding_qwen vector(1024): streamlit_app.py:49, rds_schema.sql:50-56; not a BASELINE.json config)") + (f", encoder forward in the loop ({args.seq_len} tokens/query, random-init " + ("Qwen3-Embedding-0.6B shape: the production embedder, streamlit_app.py:55)" if args.encoder == "qwen" else "BERT-base shape)") if encoder is not None else ""),
+                                      "(the reference's production table shape, theorem_embedding_qwen vector(1024): streamlit_app.py:49, rds_schema.sql:50-56; not a BASELINE.json config)") + (f", encoder forward in the loop ({args.seq_len} tokens/query, random-init " + ("Qwen3-Embedding-0.6B shape: the production embedder, streamlit_app.py:55)" if args.encoder == "qwen" else "embeddinggemma-300m shape: the reference's second embedder, embedders.py:1-4)" if args.encoder == "gemma" else "BERT-base shape)") if encoder is not None else ""),
                        "rows": rows_total, "dim": D, "batch": nq, "k": K, "searches_in_flight": P,
                        **({"mask_frac": args.mask_frac} if args.mask_frac > 0 else {}),
                        "parallelism": f"corpus row-sharded x{world}" + ((", gloo rehearsal on one GPU" if args.share_gpu else (", ncclAllGather of per-shard top-k inside libtsearch (ts_comm)" if searcher.exchange == "native" else ", torch.distributed all-gather of per-shard top-k (RCCL)")) if use_dist else "")},

@@ -365,6 +365,25 @@ int ts_qk_norm_rope(int device, void *qkv, const void *q_weight, const void *k_w
  * weights: gate_up device [rows][2 * inter] (gate columns, then up columns) -> out device [rows][inter]. */
 int ts_swiglu(int device, const void *gate_up, int64_t rows, int32_t inter, int dtype, void *out, void *stream);
 
+/* The reference's second embedder, google/embeddinggemma-300m (ec2/generate_embeddings/embedders.py:1-4; Gemma3TextModel:
+ * "sandwich" RMSNorms around every sublayer, q / k norms over heads of 256, rotary positions, GeGLU).  Three kernels for what its
+ * layers do around the GEMMs, with the roundings of the torch modules they replace (Gemma3RMSNorm: v * rsqrt(mean(v^2) + eps) *
+ * (1 + w) in fp32, rounded once).
+ *
+ * ts_gemma_norm: s = x + norm(y; w_post) (the residual add in `dtype`; y may be NULL: s = x), out_norm = norm(s; w_next) over rows
+ * of d elements - the post-sublayer norm, the residual add and the pre-norm of what follows in one kernel; out_sum (may be NULL)
+ * receives s.  d as for ts_add_layernorm; buffers 16-byte aligned. */
+int ts_gemma_norm(int device, const void *y, const void *x, const void *w_post, const void *w_next, float eps, int64_t rows,
+                  int32_t d, int dtype, void *out_sum, void *out_norm, void *stream);
+/* ts_qk_norm_rope for Gemma3Attention: heads of 256, Gemma3RMSNorm (weights q_weight / k_weight [256]), rotate_half at 128;
+ * cos / sin: [seq][256] of `dtype` (the layer type's table: sliding and full attention layers use different bases). */
+int ts_gemma_qk_norm_rope(int device, void *qkv, const void *q_weight, const void *k_weight, const void *cos_table,
+                          const void *sin_table, float eps, int64_t tokens, int32_t seq, int32_t q_heads, int32_t kv_heads,
+                          int32_t head_dim, int dtype, void *stream);
+/* Gemma3MLP's activation on the fused projection's output: out = gelu_tanh(gate) * up (gate_up [rows][2 * inter]: gate columns,
+ * then up columns), the activation rounded to `dtype` before the product as torch does. */
+int ts_geglu(int device, const void *gate_up, int64_t rows, int32_t inter, int dtype, void *out, void *stream);
+
 /* ---- kernel timing inside the library ----------------------------------------------------------
  * With profiling enabled, every launch of the dominant kernel of a search (the full-corpus pass of
  * the MFMA path, or the scan kernel) is bracketed by a hipEvent pair on the stream it runs on.

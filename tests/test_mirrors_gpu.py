@@ -849,3 +849,125 @@ def test_fused_qwen3_forward_matches_the_models_own():
         w32 = f32.model(input_ids=e32["input_ids"], attention_mask=e32["attention_mask"]).last_hidden_state
         g32 = f32.forward_hidden(e32["input_ids"], e32["attention_mask"])
     assert (w32 - g32)[e32["attention_mask"].bool()].abs().max().item() < 5e-4
+
+
+# ---- round 4: the reference's second embedder, google/embeddinggemma-300m (Gemma3TextModel, bidirectional) -------------------------
+def test_gemma3_kernels_match_the_modules():
+    """ts_gemma_norm against Gemma3DecoderLayer's post-sublayer norm + residual add + the norm that follows (Gemma3RMSNorm:
+    v * rsqrt(mean(v^2) + eps) * (1 + w) in fp32, rounded once), ts_gemma_qk_norm_rope against Gemma3Attention's q_norm / k_norm +
+    apply_rotary_pos_emb over heads of 256 (values untouched), ts_geglu against Gemma3MLP's gelu_tanh(gate) * up - each on the
+    same tensors as the torch modules, bf16 and fp32."""
+    import ctypes as C
+    import torch
+    from transformers.models.gemma3.modeling_gemma3 import Gemma3RMSNorm, apply_rotary_pos_emb
+    from theoremsearch_amd import _ffi
+    lib = _ffi.load()
+    g = torch.Generator(device="cpu").manual_seed(16)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for dtype, code in ((torch.bfloat16, 1), (torch.float32, 0)):
+        tol = 2 ** -6 if dtype == torch.bfloat16 else 2e-5
+        for d in (768, 1152 if dtype == torch.bfloat16 else 1024, 640):
+            rows = 333
+            x = (torch.randn((rows, d), generator=g) * 3.0).to(dtype).cuda()
+            y = (torch.randn((rows, d), generator=g) * 0.7).to(dtype).cuda()
+            post, nxt = Gemma3RMSNorm(d, eps=1e-6).to("cuda", dtype=dtype), Gemma3RMSNorm(d, eps=1e-6).to("cuda", dtype=dtype)
+            with torch.no_grad():
+                post.weight.copy_((0.3 * torch.randn(d, generator=g)).to(dtype))
+                nxt.weight.copy_((0.3 * torch.randn(d, generator=g)).to(dtype))
+                want_sum = x + post(y)
+                want = nxt(want_sum)
+                plain = nxt(x)
+            out_sum, out, out_plain = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+            _ffi.check(lib.ts_gemma_norm(0, C.c_void_p(y.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(post.weight.data_ptr()),
+                                         C.c_void_p(nxt.weight.data_ptr()), 1e-6, rows, d, code, C.c_void_p(out_sum.data_ptr()),
+                                         C.c_void_p(out.data_ptr()), st))
+            _ffi.check(lib.ts_gemma_norm(0, None, C.c_void_p(x.data_ptr()), None, C.c_void_p(nxt.weight.data_ptr()), 1e-6, rows, d, code,
+                                         None, C.c_void_p(out_plain.data_ptr()), st))
+            torch.cuda.synchronize()
+            for have, ref in ((out_sum, want_sum), (out, want), (out_plain, plain)):
+                assert (have.float() - ref.float()).abs().max().item() <= tol * max(1.0, ref.float().abs().max().item()), (dtype, d)
+                if dtype == torch.bfloat16:
+                    assert (have != ref).float().mean().item() < 2e-3, (dtype, d)          # the same roundings, step by step
+        B, S, hq, hkv, hd = 5, 37, 3, 1, 256
+        qkv = (torch.randn((B, S, (hq + 2 * hkv) * hd), generator=g) * 1.3).to(dtype).cuda()
+        qn, kn = Gemma3RMSNorm(hd, eps=1e-6).to("cuda", dtype=dtype), Gemma3RMSNorm(hd, eps=1e-6).to("cuda", dtype=dtype)
+        with torch.no_grad():
+            qn.weight.copy_((0.3 * torch.randn(hd, generator=g)).to(dtype))
+            kn.weight.copy_((0.3 * torch.randn(hd, generator=g)).to(dtype))
+        inv = 1.0 / (1e4 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+        ang = torch.arange(S, dtype=torch.float32)[:, None] * inv[None, :]
+        emb = torch.cat((ang, ang), dim=-1)
+        cos, sin = emb.cos().to(dtype).cuda(), emb.sin().to(dtype).cuda()
+        with torch.no_grad():
+            q = qn(qkv[..., :hq * hd].view(B, S, hq, hd).transpose(1, 2))
+            k = kn(qkv[..., hq * hd:(hq + hkv) * hd].view(B, S, hkv, hd).transpose(1, 2))
+            wq, wk = apply_rotary_pos_emb(q, k, cos[None], sin[None])
+        got = qkv.clone()
+        _ffi.check(lib.ts_gemma_qk_norm_rope(0, C.c_void_p(got.data_ptr()), C.c_void_p(qn.weight.data_ptr()), C.c_void_p(kn.weight.data_ptr()),
+                                             C.c_void_p(cos.data_ptr()), C.c_void_p(sin.data_ptr()), 1e-6, B * S, S, hq, hkv, hd, code, st))
+        torch.cuda.synchronize()
+        gq = got[..., :hq * hd].view(B, S, hq, hd).transpose(1, 2)
+        gk = got[..., hq * hd:(hq + hkv) * hd].view(B, S, hkv, hd).transpose(1, 2)
+        assert torch.equal(got[..., (hq + hkv) * hd:], qkv[..., (hq + hkv) * hd:])                 # the values
+        for have, want in ((gq, wq), (gk, wk)):
+            assert (have.float() - want.float()).abs().max().item() <= tol * max(1.0, want.float().abs().max().item())
+            if dtype == torch.bfloat16:
+                assert (have != want).float().mean().item() < 2e-3
+        with pytest.raises(_ffi.TSearchError) as e:
+            _ffi.check(lib.ts_gemma_qk_norm_rope(0, C.c_void_p(got.data_ptr()), C.c_void_p(qn.weight.data_ptr()), C.c_void_p(kn.weight.data_ptr()),
+                                                 C.c_void_p(cos.data_ptr()), C.c_void_p(sin.data_ptr()), 1e-6, B * S, S, hq, hkv, 128, code, st))
+        assert e.value.code == -5
+        rows, inter = 1001, 1152
+        gu = (torch.randn((rows, 2 * inter), generator=g) * 2.0).to(dtype).cuda()
+        want = torch.nn.functional.gelu(gu[:, :inter], approximate="tanh") * gu[:, inter:]
+        out = torch.empty((rows, inter), dtype=dtype, device="cuda")
+        _ffi.check(lib.ts_geglu(0, C.c_void_p(gu.data_ptr()), rows, inter, code, C.c_void_p(out.data_ptr()), st))
+        torch.cuda.synchronize()
+        assert (out.float() - want.float()).abs().max().item() <= tol * max(1.0, want.float().abs().max().item())
+        if dtype == torch.bfloat16:
+            assert (out != want).float().mean().item() < 5e-3
+
+
+def test_fused_gemma3_forward_matches_the_models_own():
+    """FusedGemma3Forward (stacked projections + ts_gemma_norm + ts_gemma_qk_norm_rope + ts_geglu) against Gemma3TextModel's own
+    forward (bidirectional attention) on the same random-init weights: hidden states of the real tokens to bf16 noise, sentence
+    embeddings (mean pooling, the two Dense modules, Normalize) to cosine > 0.9995; padded and unpadded batches; fp32 to 5e-4;
+    TS_ENCODER_FUSED=0 keeps the model's own."""
+    import torch
+    from theoremsearch_amd.encoder import FusedGemma3Forward, SentenceEncoder
+    name = "google/embeddinggemma-300m"
+    enc = SentenceEncoder(name, num_layers=7, allow_random_init=True)              # seven layers: sliding and full attention ones
+    assert isinstance(enc._fused, FusedGemma3Forward) and enc.pooling == "mean" and enc.embedding_dim == 768
+    assert len(set(enc.model.config.layer_types)) == 2
+    texts = [f"lemma {i}: every finite group of order {i} " + "is solvable " * (i % 5) for i in range(40)]
+    tok = {k: v.cuda() for k, v in enc._tokenize(texts).items()}
+    assert not bool(tok["attention_mask"].all())
+    with torch.inference_mode():
+        want = enc.model(input_ids=tok["input_ids"], attention_mask=tok["attention_mask"]).last_hidden_state.float()
+        got = enc.forward_hidden(tok["input_ids"], tok["attention_mask"]).float()
+    real = tok["attention_mask"].bool()
+    scale = want[real].abs().max().item()
+    assert (want - got)[real].abs().max().item() < 0.06 * scale and (want - got)[real].abs().mean().item() < 0.01 * scale
+    same = tok["input_ids"][:, :6].contiguous()
+    ones = torch.ones_like(same)
+    with torch.inference_mode():
+        w2 = enc.model(input_ids=same, attention_mask=ones).last_hidden_state.float()
+        g2 = enc.forward_hidden(same, ones, no_padding=True).float()
+    assert (w2 - g2).abs().max().item() < 0.06 * w2.abs().max().item()
+    fused = enc.encode(texts, convert_to_numpy=True)
+    assert np.allclose(np.sum(fused * fused, axis=1), 1.0, atol=1e-3)               # the pipeline's Normalize module
+    os.environ["TS_ENCODER_FUSED"] = "0"
+    try:
+        plain_enc = SentenceEncoder(name, num_layers=7, allow_random_init=True)
+    finally:
+        del os.environ["TS_ENCODER_FUSED"]
+    assert plain_enc._fused is None
+    plain = plain_enc.encode(texts, convert_to_numpy=True)
+    assert np.min(np.sum(fused * plain, axis=1)) > 0.9995
+    f32 = SentenceEncoder(name, num_layers=2, allow_random_init=True, dtype=torch.float32)
+    assert isinstance(f32._fused, FusedGemma3Forward)
+    e32 = {k: v.cuda() for k, v in f32._tokenize(texts[:9]).items()}
+    with torch.inference_mode():
+        w32 = f32.model(input_ids=e32["input_ids"], attention_mask=e32["attention_mask"]).last_hidden_state
+        g32 = f32.forward_hidden(e32["input_ids"], e32["attention_mask"])
+    assert (w32 - g32)[e32["attention_mask"].bool()].abs().max().item() < 5e-4 * max(1.0, w32.abs().max().item())

@@ -111,6 +111,11 @@ _SIGNATURES = {
     "ts_qk_norm_rope": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_int, C.c_void_p]),
     "ts_swiglu": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_void_p, C.c_void_p]),
+    "ts_geglu": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_void_p, C.c_void_p]),
+    "ts_gemma_norm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_int32, C.c_int,
+                                C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ts_gemma_qk_norm_rope": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64,
+                                        C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int, C.c_void_p]),
     "ts_index_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "ts_index_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "ts_index_probe_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

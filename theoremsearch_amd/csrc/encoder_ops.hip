@@ -205,27 +205,78 @@ extern "C" int ts_attention_gqa(int device, const void* qkv, const int64_t* atte
     return TS_OK;
 }
 
-extern "C" int ts_qk_norm_rope(int device, void* qkv, const void* q_weight, const void* k_weight, const void* cos_table,
+static int qk_norm_rope_launch(int device, void* qkv, const void* q_weight, const void* k_weight, const void* cos_table,
                                const void* sin_table, float eps, int64_t tokens, int32_t seq, int32_t q_heads, int32_t kv_heads,
-                               int32_t head_dim, int dtype, void* stream) {
+                               int32_t head_dim, int dtype, bool gemma, void* stream) {
     if (!qkv || !q_weight || !k_weight || !cos_table || !sin_table) return fail(TS_ERR_INVALID, "NULL argument");
     if (dtype != TS_F32 && dtype != TS_BF16) return fail(TS_ERR_INVALID, "dtype %d", dtype);
     if (tokens < 0 || seq < 1 || q_heads < 1 || kv_heads < 1) return fail(TS_ERR_INVALID, "bad shape");
-    if (head_dim != 128) return fail(TS_ERR_UNSUPPORTED, "head size %d: this kernel serves head size 128 (Qwen3)", head_dim);
+    if (head_dim != (gemma ? 256 : 128))
+        return fail(TS_ERR_UNSUPPORTED, "head size %d: this kernel serves head size %d", head_dim, gemma ? 256 : 128);
+    if ((((uintptr_t)qkv | (uintptr_t)q_weight | (uintptr_t)k_weight | (uintptr_t)cos_table | (uintptr_t)sin_table) & 15) != 0)
+        return fail(TS_ERR_INVALID, "buffers must be 16-byte aligned");
     if (tokens == 0) return TS_OK;
     TS_TRY(check_device(device));
     HIP_TRY(hipSetDevice(device));
     const int64_t items = tokens * (q_heads + kv_heads);
-    const int per_wg = 4 * (dtype == TS_BF16 ? 4 : 2);                  // 4 waves x (64 lanes / (128 / VEC) lanes per head)
+    const int vec = dtype == TS_BF16 ? 8 : 4;
+    const int per_wg = 4 * (64 / (head_dim / vec));                    // 4 waves x heads per wave
     const unsigned grid = (unsigned)((items + per_wg - 1) / per_wg);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == TS_F32) qk_norm_rope_kernel<0><<<grid, 256, 0, st>>>(qkv, q_weight, k_weight, cos_table, sin_table, eps, tokens, seq, q_heads, kv_heads);
-    else qk_norm_rope_kernel<1><<<grid, 256, 0, st>>>(qkv, q_weight, k_weight, cos_table, sin_table, eps, tokens, seq, q_heads, kv_heads);
+    if (gemma) {
+        if (dtype == TS_F32) qk_norm_rope_kernel<0, 256, true><<<grid, 256, 0, st>>>(qkv, q_weight, k_weight, cos_table, sin_table, eps, tokens, seq, q_heads, kv_heads);
+        else qk_norm_rope_kernel<1, 256, true><<<grid, 256, 0, st>>>(qkv, q_weight, k_weight, cos_table, sin_table, eps, tokens, seq, q_heads, kv_heads);
+    } else {
+        if (dtype == TS_F32) qk_norm_rope_kernel<0, 128, false><<<grid, 256, 0, st>>>(qkv, q_weight, k_weight, cos_table, sin_table, eps, tokens, seq, q_heads, kv_heads);
+        else qk_norm_rope_kernel<1, 128, false><<<grid, 256, 0, st>>>(qkv, q_weight, k_weight, cos_table, sin_table, eps, tokens, seq, q_heads, kv_heads);
+    }
     HIP_TRY(hipGetLastError());
     return TS_OK;
 }
 
-extern "C" int ts_swiglu(int device, const void* gate_up, int64_t rows, int32_t inter, int dtype, void* out, void* stream) {
+extern "C" int ts_qk_norm_rope(int device, void* qkv, const void* q_weight, const void* k_weight, const void* cos_table,
+                               const void* sin_table, float eps, int64_t tokens, int32_t seq, int32_t q_heads, int32_t kv_heads,
+                               int32_t head_dim, int dtype, void* stream) {
+    return qk_norm_rope_launch(device, qkv, q_weight, k_weight, cos_table, sin_table, eps, tokens, seq, q_heads, kv_heads, head_dim, dtype,
+                               false, stream);
+}
+
+extern "C" int ts_gemma_qk_norm_rope(int device, void* qkv, const void* q_weight, const void* k_weight, const void* cos_table,
+                                     const void* sin_table, float eps, int64_t tokens, int32_t seq, int32_t q_heads, int32_t kv_heads,
+                                     int32_t head_dim, int dtype, void* stream) {
+    return qk_norm_rope_launch(device, qkv, q_weight, k_weight, cos_table, sin_table, eps, tokens, seq, q_heads, kv_heads, head_dim, dtype,
+                               true, stream);
+}
+
+extern "C" int ts_gemma_norm(int device, const void* y, const void* x, const void* w_post, const void* w_next, float eps, int64_t rows,
+                             int32_t d, int dtype, void* out_sum, void* out_norm, void* stream) {
+    if (!x || !w_next || !out_norm || (y && !w_post)) return fail(TS_ERR_INVALID, "NULL argument");
+    if (dtype != TS_F32 && dtype != TS_BF16) return fail(TS_ERR_INVALID, "dtype %d", dtype);
+    const int vec = dtype == TS_BF16 ? 8 : 4;
+    if (rows < 0 || d < vec || d % vec || d > 64 * kLnMax * vec)
+        return fail(TS_ERR_INVALID, "d = %d must be a multiple of %d and at most %d", d, vec, 64 * kLnMax * vec);
+    if ((((uintptr_t)y | (uintptr_t)x | (uintptr_t)w_post | (uintptr_t)w_next | (uintptr_t)out_sum | (uintptr_t)out_norm) & 15) != 0)
+        return fail(TS_ERR_INVALID, "buffers must be 16-byte aligned");
+    if (rows == 0) return TS_OK;
+    TS_TRY(check_device(device));
+    HIP_TRY(hipSetDevice(device));
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    const int per_lane = (d / vec + 63) / 64;
+    hipStream_t st = (hipStream_t)stream;
+#define TS_GN_LAUNCH(DT_)                                                                                                      \
+    do {                                                                                                                       \
+        if (per_lane <= 1) gemma_norm_kernel<DT_, 1><<<grid, 256, 0, st>>>(y, x, w_post, w_next, eps, rows, d, out_sum, out_norm); \
+        else if (per_lane <= 2) gemma_norm_kernel<DT_, 2><<<grid, 256, 0, st>>>(y, x, w_post, w_next, eps, rows, d, out_sum, out_norm); \
+        else gemma_norm_kernel<DT_, 4><<<grid, 256, 0, st>>>(y, x, w_post, w_next, eps, rows, d, out_sum, out_norm);           \
+    } while (0)
+    if (dtype == TS_F32) TS_GN_LAUNCH(0);
+    else TS_GN_LAUNCH(1);
+#undef TS_GN_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return TS_OK;
+}
+
+static int gated_act_launch(int device, const void* gate_up, int64_t rows, int32_t inter, int dtype, bool gelu_tanh, void* out, void* stream) {
     if (!gate_up || !out) return fail(TS_ERR_INVALID, "NULL argument");
     if (dtype != TS_F32 && dtype != TS_BF16) return fail(TS_ERR_INVALID, "dtype %d", dtype);
     const int vec = dtype == TS_BF16 ? 8 : 4;
@@ -237,8 +288,21 @@ extern "C" int ts_swiglu(int device, const void* gate_up, int64_t rows, int32_t 
     const int64_t total = rows * (inter / vec);
     const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 16384);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == TS_F32) swiglu_kernel<0><<<grid, 256, 0, st>>>(gate_up, rows, inter, out);
-    else swiglu_kernel<1><<<grid, 256, 0, st>>>(gate_up, rows, inter, out);
+    if (gelu_tanh) {
+        if (dtype == TS_F32) geglu_kernel<0><<<grid, 256, 0, st>>>(gate_up, rows, inter, out);
+        else geglu_kernel<1><<<grid, 256, 0, st>>>(gate_up, rows, inter, out);
+    } else {
+        if (dtype == TS_F32) swiglu_kernel<0><<<grid, 256, 0, st>>>(gate_up, rows, inter, out);
+        else swiglu_kernel<1><<<grid, 256, 0, st>>>(gate_up, rows, inter, out);
+    }
     HIP_TRY(hipGetLastError());
     return TS_OK;
+}
+
+extern "C" int ts_swiglu(int device, const void* gate_up, int64_t rows, int32_t inter, int dtype, void* out, void* stream) {
+    return gated_act_launch(device, gate_up, rows, inter, dtype, false, out, stream);
+}
+
+extern "C" int ts_geglu(int device, const void* gate_up, int64_t rows, int32_t inter, int dtype, void* out, void* stream) {
+    return gated_act_launch(device, gate_up, rows, inter, dtype, true, out, stream);
 }

@@ -462,13 +462,16 @@ __global__ void __launch_bounds__(256) add_rmsnorm_kernel(const void* a, const v
 // elements): four (bf16) or two (fp32) heads per wave.  Element i rotates with element i +- 64 = the same slot of the lane half
 // a group away: one exchange of the lane's packed, already rounded y.  (The first cut gave a whole wave to a head, two bytes
 // per lane: 68 us for 8,192 tokens x 24 heads in the Qwen3-shaped step - the launch moves 100 MB.)
-template <int DT>
+// HD = head size (128: Qwen3; 256: Gemma3).  GEMMA: Gemma3RMSNorm - x * rsqrt(mean(x^2) + eps) * (1 + w), all in fp32, rounded
+// ONCE to the storage type - instead of Qwen3RMSNorm's w * round(x * rsqrt(..)).
+template <int DT, int HD = 128, bool GEMMA = false>
 __global__ void __launch_bounds__(256) qk_norm_rope_kernel(void* qkv, const void* __restrict__ wq, const void* __restrict__ wk,
                                                             const void* __restrict__ cos_t, const void* __restrict__ sin_t, float eps,
                                                             int64_t tokens, int seq, int hq, int hkv) {
     constexpr int VEC = DT == 0 ? 4 : 8;
-    constexpr int LPH = 128 / VEC;                       // lanes per head: 16 (bf16) or 32 (fp32)
+    constexpr int LPH = HD / VEC;                        // lanes per head: 16 / 32 (bf16 128 / 256) or 32 / 64 (fp32)
     constexpr int HPW = 64 / LPH;                        // heads per wave
+    static_assert(LPH <= 64 && HPW >= 1, "a head fits a wave");
     const int lane = threadIdx.x & 63;
     const int j = lane & (LPH - 1);
     const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -479,8 +482,8 @@ __global__ void __launch_bounds__(256) qk_norm_rope_kernel(void* qkv, const void
     const int64_t tok = item / heads;
     const int h = (int)(item - tok * heads);
     const int pos = (int)(tok % seq);
-    const int64_t width = (int64_t)(hq + 2 * hkv) * 128;
-    uint4* px = (uint4*)((char*)qkv + (tok * width + (int64_t)h * 128) * (DT == 0 ? 4 : 2)) + j;
+    const int64_t width = (int64_t)(hq + 2 * hkv) * HD;
+    uint4* px = (uint4*)((char*)qkv + (tok * width + (int64_t)h * HD) * (DT == 0 ? 4 : 2)) + j;
     const uint4 rx = *px;
     const uint4 rw = ((const uint4*)(h < hq ? wq : wk))[j];
     const uint4 rc = ((const uint4*)cos_t)[(int64_t)pos * LPH + j];
@@ -495,9 +498,10 @@ __global__ void __launch_bounds__(256) qk_norm_rope_kernel(void* qkv, const void
     for (int e = 0; e < VEC; ++e) sq += x[e] * x[e];
 #pragma unroll
     for (int off = LPH / 2; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
-    const float rstd = rsqrtf(sq / 128.0f + eps);
+    const float rstd = rsqrtf(sq / (float)HD + eps);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) y[e] = enc_round<DT>(w[e] * enc_round<DT>(x[e] * rstd));
+    for (int e = 0; e < VEC; ++e)
+        y[e] = GEMMA ? enc_round<DT>((x[e] * rstd) * (1.0f + w[e])) : enc_round<DT>(w[e] * enc_round<DT>(x[e] * rstd));
     // the partner's y (exact in the storage type: it was just rounded to it), packed: four shuffles
     const uint4 py = enc_pack<DT>(y);
     uint4 pp;
@@ -506,7 +510,7 @@ __global__ void __launch_bounds__(256) qk_norm_rope_kernel(void* qkv, const void
     pp.z = (u32)__shfl_xor((int)py.z, LPH / 2, 64);
     pp.w = (u32)__shfl_xor((int)py.w, LPH / 2, 64);
     enc_unpack<DT>(pp, yp);
-    const float sgn = j < LPH / 2 ? -1.0f : 1.0f;       // rot = (-y[64..127], y[0..63])
+    const float sgn = j < LPH / 2 ? -1.0f : 1.0f;       // rot = (-y[HD/2 ..], y[.. HD/2])
 #pragma unroll
     for (int e = 0; e < VEC; ++e) o[e] = enc_round<DT>(y[e] * c[e]) + enc_round<DT>(sgn * yp[e] * sn[e]);
     if (live) *px = enc_pack<DT>(o);
@@ -530,6 +534,113 @@ __global__ void __launch_bounds__(256) swiglu_kernel(const void* __restrict__ ga
         enc_unpack<DT>(u4, u);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) y[e] = enc_round<DT>(g[e] / (1.0f + __expf(-g[e]))) * u[e];
+        ((uint4*)out)[i] = enc_pack<DT>(y);
+    }
+}
+
+// Gemma3's "sandwich" norms around a sublayer (Gemma3DecoderLayer.forward; google/embeddinggemma-300m is the reference's second
+// embedder, ec2/generate_embeddings/embedders.py:1-4):   s = x + post_norm(y),   h = pre_norm_of_what_follows(s)
+// with Gemma3RMSNorm(v) = v * rsqrt(mean(v^2) + eps) * (1 + w) in fp32, rounded once; the residual add in the storage type.
+// y may be NULL (the first norm of the first layer: s = x).  out_sum (may be NULL) receives s.  One wave per row.
+template <int DT, int LN>
+__global__ void __launch_bounds__(256) gemma_norm_kernel(const void* y, const void* x, const void* __restrict__ w_post,
+                                                          const void* __restrict__ w_next, float eps, int64_t rows, int d, void* out_sum,
+                                                          void* out_norm) {
+    constexpr int VEC = DT == 0 ? 4 : 8;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = d / VEC;
+    const uint4* px = (const uint4*)x + row * nchunk;
+    const uint4* py = y ? (const uint4*)y + row * nchunk : nullptr;
+    uint4 rx[LN], ry[LN], rp[LN], rn[LN];
+#pragma unroll
+    for (int j = 0; j < LN; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nchunk) {
+            rx[j] = px[c];
+            rn[j] = ((const uint4*)w_next)[c];
+            if (py) {
+                ry[j] = py[c];
+                rp[j] = ((const uint4*)w_post)[c];
+            }
+        }
+    }
+    float s[LN][VEC];
+    if (py) {
+        float t[LN][VEC];
+        float sq = 0.0f;
+#pragma unroll
+        for (int j = 0; j < LN; ++j)
+            if (lane + 64 * j < nchunk) {
+                enc_unpack<DT>(ry[j], t[j]);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) sq += t[j][e] * t[j][e];
+            }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+        const float rstd = rsqrtf(sq / (float)d + eps);
+#pragma unroll
+        for (int j = 0; j < LN; ++j)
+            if (lane + 64 * j < nchunk) {
+                float fx[VEC], wp[VEC];
+                enc_unpack<DT>(rx[j], fx);
+                enc_unpack<DT>(rp[j], wp);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) s[j][e] = enc_round<DT>(fx[e] + enc_round<DT>((t[j][e] * rstd) * (1.0f + wp[e])));
+            }
+    } else {
+#pragma unroll
+        for (int j = 0; j < LN; ++j)
+            if (lane + 64 * j < nchunk) enc_unpack<DT>(rx[j], s[j]);
+    }
+    float sq = 0.0f;
+#pragma unroll
+    for (int j = 0; j < LN; ++j)
+        if (lane + 64 * j < nchunk) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) sq += s[j][e] * s[j][e];
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    const float rstd = rsqrtf(sq / (float)d + eps);
+    uint4* ps = out_sum ? (uint4*)out_sum + row * nchunk : nullptr;
+    uint4* po = (uint4*)out_norm + row * nchunk;
+#pragma unroll
+    for (int j = 0; j < LN; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nchunk) {
+            float wn[VEC], h[VEC];
+            enc_unpack<DT>(rn[j], wn);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) h[e] = (s[j][e] * rstd) * (1.0f + wn[e]);
+            if (ps) ps[c] = enc_pack<DT>(s[j]);
+            po[c] = enc_pack<DT>(h);
+        }
+    }
+}
+
+// Gemma3MLP's activation: act_fn(gate_proj(x)) * up_proj(x), act_fn = gelu_pytorch_tanh, on the fused projection's output
+//   gate_up [rows][2 * inter]: gate columns, then up columns;   out [rows][inter] = round(round(gelu_tanh(gate)) * up)
+template <int DT>
+__global__ void __launch_bounds__(256) geglu_kernel(const void* __restrict__ gate_up, int64_t rows, int inter, void* __restrict__ out) {
+    constexpr int VEC = DT == 0 ? 4 : 8;
+    const int per_row = inter / VEC;
+    const int64_t total = rows * per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / per_row;
+        const int c = (int)(i - r * per_row);
+        const uint4 g4 = ((const uint4*)gate_up)[r * 2 * per_row + c];
+        const uint4 u4 = ((const uint4*)gate_up)[r * 2 * per_row + per_row + c];
+        float g[VEC], u[VEC], y[VEC];
+        enc_unpack<DT>(g4, g);
+        enc_unpack<DT>(u4, u);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float v = g[e];
+            const float inner = 0.7978845608028654f * (v + 0.044715f * v * v * v);       // sqrt(2 / pi) (v + 0.044715 v^3)
+            y[e] = enc_round<DT>(0.5f * v * (1.0f + tanhf(inner))) * u[e];
+        }
         ((uint4*)out)[i] = enc_pack<DT>(y);
     }
 }

@@ -46,10 +46,14 @@ import torch
 
 # Stand-in architectures for allow_random_init only (no weights offline): the published shapes of the reference's embedders
 # (ec2/generate_embeddings/embedders.py:1-4, app_create_embeddings.py:8).  family "bert": BertModel; family "qwen3": Qwen3Model
-# (decoder-style: RMSNorm, rotary positions, 16 query / 8 key-value heads of 128, gated MLP, last-token pooling).
+# (decoder-style: RMSNorm, rotary positions, 16 query / 8 key-value heads of 128, gated MLP, last-token pooling); family "gemma3":
+# Gemma3TextModel with bidirectional attention (sandwich RMSNorms, 3 query heads over 1 key-value head of 256, GeGLU, sliding /
+# full attention layers 5 : 1, mean pooling, two Dense modules 768 -> 3072 -> 768 behind the pooling).
 ARCHITECTURES = {
     "math-similarity/Bert-MLM_arXiv-MP-class_zbMath": dict(family="bert", hidden=768, layers=12, heads=12, ffn=3072, pooling="mean", max_len=512),
-    "google/embeddinggemma-300m": dict(family="bert", hidden=768, layers=24, heads=12, ffn=3072, pooling="mean", max_len=2048),
+    "google/embeddinggemma-300m": dict(family="gemma3", hidden=768, layers=24, heads=3, kv_heads=1, head_dim=256, ffn=1152,
+                                       pooling="mean", max_len=2048, vocab=262144, sliding_window=512, rms_eps=1e-6,
+                                       dense=(3072, 768)),
     "Qwen/Qwen3-Embedding-0.6B": dict(family="qwen3", hidden=1024, layers=28, heads=16, kv_heads=8, head_dim=128, ffn=3072,
                                       pooling="lasttoken", max_len=8192, vocab=151669, rope_theta=1000000.0, rms_eps=1e-6),
 }
@@ -232,6 +236,14 @@ class SentenceEncoder:
                                   intermediate_size=arch["ffn"], max_position_embeddings=max_len, rms_norm_eps=arch["rms_eps"],
                                   rope_theta=arch["rope_theta"], attention_bias=False, use_sliding_window=False)
                 self.model = Qwen3Model(cfg)
+            elif arch["family"] == "gemma3":
+                from transformers import Gemma3TextConfig, Gemma3TextModel
+                cfg = Gemma3TextConfig(vocab_size=arch["vocab"], hidden_size=arch["hidden"], num_hidden_layers=num_layers or arch["layers"],
+                                       num_attention_heads=arch["heads"], num_key_value_heads=arch["kv_heads"], head_dim=arch["head_dim"],
+                                       intermediate_size=arch["ffn"], max_position_embeddings=max_len, rms_norm_eps=arch["rms_eps"],
+                                       sliding_window=arch["sliding_window"], query_pre_attn_scalar=arch["head_dim"],
+                                       use_bidirectional_attention=True, attention_bias=False)
+                self.model = Gemma3TextModel(cfg)
             else:
                 from transformers import BertConfig, BertModel
                 cfg = BertConfig(vocab_size=30522, hidden_size=arch["hidden"], num_hidden_layers=num_layers or arch["layers"],
@@ -244,6 +256,15 @@ class SentenceEncoder:
             self.pretrained = False
             self.pipeline = _Pipeline()
             self.pipeline.pooling = pooling
+            if arch.get("dense"):                         # the checkpoint's Dense modules (no bias, identity activation) + Normalize
+                gen_state = torch.random.get_rng_state()
+                torch.manual_seed(seed + 1)
+                width = arch["hidden"]
+                for out_f in arch["dense"]:
+                    self.pipeline.dense.append(torch.nn.Sequential(torch.nn.Linear(width, out_f, bias=False), torch.nn.Identity()))
+                    width = out_f
+                torch.random.set_rng_state(gen_state)
+                self.pipeline.normalize = True
             self.max_seq_length = min(max_len, 512)
             if dtype is None:
                 dtype = torch.bfloat16 if self.device.type == "cuda" else torch.float32
@@ -257,6 +278,8 @@ class SentenceEncoder:
                 self._fused = FusedBertForward(self.model)
             elif FusedQwen3Forward.covers(self.model):
                 self._fused = FusedQwen3Forward(self.model)
+            elif FusedGemma3Forward.covers(self.model):
+                self._fused = FusedGemma3Forward(self.model)
         for m in self.pipeline.dense:
             m.to(self.device, dtype=torch.float32).eval()
         self.embedding_dim = (self.pipeline.dense[-1][0].out_features if self.pipeline.dense
@@ -763,6 +786,142 @@ class FusedQwen3Forward:
             last = li + 1 == len(self.layers)
             gamma = m.norm.weight if last else self.layers[li + 1]["ln1"]
             x, h = self._add_rmsnorm(x, F.linear(act, L["wd"]), gamma, not last)
+        return h
+
+
+class FusedGemma3Forward:
+    """The forward of a Gemma3 text encoder with bidirectional attention (``Gemma3TextModel``: what
+    ``google/embeddinggemma-300m`` is, the reference's second embedder, ec2/generate_embeddings/embedders.py:1-4) with everything
+    around its GEMMs and its attention as kernels of libtsearch:
+
+    * query / key / value projections as ONE GEMM over the stacked weight, gate / up projections as ONE;
+    * the post-sublayer RMSNorm, the residual add and the pre-norm of the next sublayer as ONE kernel (``ts_gemma_norm``:
+      PyTorch runs two norms of seven launches each and an add, twice per layer);
+    * the per-head RMSNorm of queries and keys + the rotary embedding as ONE kernel, in place (``ts_gemma_qk_norm_rope``;
+      sliding and full attention layers have their own cos / sin tables);
+    * ``gelu_tanh(gate) * up`` as ONE kernel (``ts_geglu``).
+
+    The attention is ``scaled_dot_product_attention`` (heads of 256, grouped-query, every key visible: sequences shorter than
+    the sliding window).  Same weights, same order of operations, the roundings of the modules replaced.  Longer sequences
+    than the sliding window take the model's own forward."""
+
+    def __init__(self, model):
+        cfg = model.config
+        self.model, self.cfg = model, cfg
+        self.hq, self.hkv, self.hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        self.eps = float(cfg.rms_norm_eps)
+        self.scaling = float(cfg.query_pre_attn_scalar) ** -0.5
+        self._stamp = None
+        self._gqa_native = True
+        self._refresh()
+
+    def _sources(self):
+        for layer in self.model.layers:
+            att, mlp = layer.self_attn, layer.mlp
+            yield from (att.q_proj.weight, att.k_proj.weight, att.v_proj.weight, mlp.gate_proj.weight, mlp.up_proj.weight)
+
+    def _refresh(self):
+        stamp = tuple((p.data_ptr(), p._version, p.dtype) for p in self._sources())
+        if stamp == self._stamp:
+            return
+        self._stamp = stamp
+        self.layers = []
+        for layer in self.model.layers:
+            att, mlp = layer.self_attn, layer.mlp
+            self.layers.append({
+                "wqkv": torch.cat([att.q_proj.weight, att.k_proj.weight, att.v_proj.weight], dim=0).contiguous(),
+                "wo": att.o_proj.weight, "qn": att.q_norm.weight, "kn": att.k_norm.weight,
+                "wgu": torch.cat([mlp.gate_proj.weight, mlp.up_proj.weight], dim=0).contiguous(), "wd": mlp.down_proj.weight,
+                "ln_in": layer.input_layernorm.weight, "ln_post_attn": layer.post_attention_layernorm.weight,
+                "ln_pre_ffn": layer.pre_feedforward_layernorm.weight, "ln_post_ffn": layer.post_feedforward_layernorm.weight,
+                "type": att.layer_type,
+            })
+
+    @staticmethod
+    def covers(model) -> bool:
+        cfg = getattr(model, "config", None)
+        if cfg is None or getattr(cfg, "model_type", "") != "gemma3_text" or not hasattr(model, "layers"):
+            return False
+        if not getattr(cfg, "use_bidirectional_attention", False) or getattr(cfg, "attention_bias", False):
+            return False
+        if getattr(cfg, "attn_logit_softcapping", None) or getattr(cfg, "head_dim", 0) != 256:
+            return False
+        if getattr(cfg, "hidden_activation", "") != "gelu_pytorch_tanh":
+            return False
+        p = next(model.parameters())
+        vec = 8 if p.dtype == torch.bfloat16 else 4
+        return (p.is_cuda and p.dtype in (torch.float32, torch.bfloat16) and cfg.hidden_size % vec == 0 and
+                cfg.hidden_size <= 256 * vec and cfg.intermediate_size % vec == 0 and
+                cfg.num_attention_heads % cfg.num_key_value_heads == 0)
+
+    def _norm(self, y: Optional[torch.Tensor], x: torch.Tensor, w_post: Optional[torch.Tensor], w_next: torch.Tensor, want_sum: bool):
+        import ctypes as C
+        from . import _ffi
+        d = x.shape[-1]
+        rows = x.numel() // d
+        out = torch.empty_like(x)
+        new_res = torch.empty_like(x) if (want_sum and y is not None) else None
+        _ffi.check(_ffi.load().ts_gemma_norm(
+            x.device.index or 0, C.c_void_p(y.data_ptr()) if y is not None else None, C.c_void_p(x.data_ptr()),
+            C.c_void_p(w_post.data_ptr()) if w_post is not None else None, C.c_void_p(w_next.data_ptr()), self.eps, rows, d,
+            1 if x.dtype == torch.bfloat16 else 0, C.c_void_p(new_res.data_ptr()) if new_res is not None else None,
+            C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        return (new_res if new_res is not None else x), out
+
+    def __call__(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, token_type_ids: Optional[torch.Tensor] = None,
+                 no_padding: bool = False):
+        import ctypes as C
+        from . import _ffi
+        F = torch.nn.functional
+        B, S = input_ids.shape
+        if S >= int(self.cfg.sliding_window):                        # the sliding layers would hide keys: the model's own masks
+            return self.model(input_ids=input_ids, attention_mask=attention_mask).last_hidden_state
+        lib = _ffi.load()
+        self._refresh()
+        m = self.model
+        x = m.embed_tokens(input_ids).contiguous()                    # scaled by sqrt(hidden) in the storage type, as the module does
+        dt = 1 if x.dtype == torch.bfloat16 else 0
+        dev = x.device.index or 0
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        pos = torch.arange(S, device=x.device).unsqueeze(0)
+        tables = {}
+        for lt in set(self.cfg.layer_types):
+            cos, sin = m.rotary_emb(x, pos, lt)                       # [1 x S x 256] of the model's type
+            tables[lt] = (cos[0].contiguous(), sin[0].contiguous())
+        mask = None
+        if not no_padding:
+            neg = torch.finfo(x.dtype).min
+            mask = torch.zeros((B, 1, 1, S), dtype=x.dtype, device=x.device).masked_fill_(~attention_mask[:, None, None, :].to(torch.bool), neg)
+        nq, nkv, hd = self.hq * self.hd, self.hkv * self.hd, self.hd
+        h = self._norm(None, x, None, self.layers[0]["ln_in"], False)[1]
+        for li, L in enumerate(self.layers):
+            qkv = F.linear(h, L["wqkv"])
+            cos, sin = tables[L["type"]]
+            _ffi.check(lib.ts_gemma_qk_norm_rope(dev, C.c_void_p(qkv.data_ptr()), C.c_void_p(L["qn"].data_ptr()), C.c_void_p(L["kn"].data_ptr()),
+                                                 C.c_void_p(cos.data_ptr()), C.c_void_p(sin.data_ptr()), self.eps, B * S, S, self.hq, self.hkv,
+                                                 hd, dt, stream))
+            q = qkv[..., :nq].view(B, S, self.hq, hd).transpose(1, 2)
+            k = qkv[..., nq:nq + nkv].view(B, S, self.hkv, hd).transpose(1, 2)
+            v = qkv[..., nq + nkv:].view(B, S, self.hkv, hd).transpose(1, 2)
+            ctx = None
+            if self._gqa_native:
+                try:
+                    ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, scale=self.scaling, enable_gqa=True)
+                except (RuntimeError, TypeError):
+                    self._gqa_native = False
+            if ctx is None:
+                rep = self.hq // self.hkv
+                ctx = F.scaled_dot_product_attention(q, k.repeat_interleave(rep, dim=1), v.repeat_interleave(rep, dim=1),
+                                                     attn_mask=mask, scale=self.scaling)
+            ctx = ctx.transpose(1, 2).reshape(B, S, nq)
+            x, h = self._norm(F.linear(ctx, L["wo"]), x, L["ln_post_attn"], L["ln_pre_ffn"], True)
+            gu = F.linear(h, L["wgu"])
+            inter = gu.shape[-1] // 2
+            act = torch.empty((B, S, inter), dtype=x.dtype, device=x.device)
+            _ffi.check(lib.ts_geglu(dev, C.c_void_p(gu.data_ptr()), B * S, inter, dt, C.c_void_p(act.data_ptr()), stream))
+            last = li + 1 == len(self.layers)
+            w_next = m.norm.weight if last else self.layers[li + 1]["ln_in"]
+            x, h = self._norm(F.linear(act, L["wd"]), x, L["ln_post_ffn"], w_next, not last)
         return h
 
 
