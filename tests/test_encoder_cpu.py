@@ -206,3 +206,20 @@ def test_the_qwen3_stand_in_is_a_qwen3_shaped_model():
     # causal + right padding: a sentence's embedding does not depend on what it is batched with
     b = enc.encode(texts[1:2], normalize_embeddings=True)
     assert np.allclose(a[1], b[0], atol=1e-5)
+
+
+def test_random_stand_ins_have_the_published_shapes_of_the_three_embedders():
+    """allow_random_init builds the architecture of the model that was asked for (no weights offline): BERT-base for the legacy
+    embedder, Qwen3 (last-token pooling, 1024-d) for the production one, a Gemma3 text model with bidirectional attention, mean
+    pooling, two Dense modules and Normalize for google/embeddinggemma-300m (ec2/generate_embeddings/embedders.py:1-4)."""
+    import numpy as np
+    from theoremsearch_amd.encoder import SentenceEncoder
+    enc = SentenceEncoder("google/embeddinggemma-300m", allow_random_init=True, num_layers=1, device="cpu")
+    cfg = enc.model.config
+    assert type(enc.model).__name__ == "Gemma3TextModel" and cfg.use_bidirectional_attention
+    assert (cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.intermediate_size) == (768, 3, 1, 256, 1152)
+    assert enc.pooling == "mean" and len(enc.pipeline.dense) == 2 and enc.pipeline.normalize and enc.embedding_dim == 768
+    out = enc.encode(["Let $G$ be a finite group.", "Every compact metric space is separable, and more words follow here."])
+    assert out.shape == (2, 768) and np.allclose(np.sum(out * out, axis=1), 1.0, atol=1e-4)
+    q = SentenceEncoder("Qwen/Qwen3-Embedding-0.6B", allow_random_init=True, num_layers=1, device="cpu")
+    assert type(q.model).__name__ == "Qwen3Model" and q.pooling == "lasttoken" and q.embedding_dim == 1024
