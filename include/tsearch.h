@@ -339,7 +339,9 @@ int ts_attention_short(int device, const void *qkv, const int64_t *attention_mas
  * query head); query head h reads key / value head h / (q_heads / kv_heads).  qkv: device bf16 [batch * seq][(q_heads + 2 kv_heads)
  * * 128] - query heads, key heads, value heads of each token, the output of one GEMM over the stacked projection weights after
  * ts_qk_norm_rope; attention_mask: device int64 [batch][seq], 0 = padding key, or NULL; out: device bf16 [batch * seq][q_heads * 128].
- * head_dim must be 128 and seq at most 64 (TS_ERR_UNSUPPORTED otherwise: the caller keeps its library attention).  A query row
+ * head_dim must be 128 and seq at most 128 (TS_ERR_UNSUPPORTED otherwise: the caller keeps its library attention); up to 64
+ * tokens every score tile of a (sequence, head) is held at once, 65 .. 128 tokens walk the query tiles against K fragments held in
+ * registers and a V^T image in LDS.  A query row
  * without a single allowed key (a padding token on the left of a causal sequence) comes back as zeros. */
 int ts_attention_gqa(int device, const void *qkv, const int64_t *attention_mask, int32_t batch, int32_t seq, int32_t q_heads,
                     int32_t kv_heads, int32_t head_dim, int causal, void *out, void *stream);

@@ -581,8 +581,8 @@ def test_short_sequence_attention_kernel_matches_fp64():
 def test_gqa_causal_attention_kernel_matches_fp64():
     """ts_attention_gqa = softmax(Q K^T / sqrt(128) + causal + key mask) V per (sequence, query head), query head h over key /
     value head h / (hq / hkv), from the stacked projection's layout [tokens][(hq + 2 hkv) * 128] (Qwen3Attention, the production
-    embedder: streamlit_app.py:55), against the same expression in fp64 on the same bf16 inputs: every tile count up to 64
-    tokens, ragged lengths, padding on the LEFT (the Qwen tokenizer's side: the padding rows of a causal sequence have no allowed
+    embedder: streamlit_app.py:55), against the same expression in fp64 on the same bf16 inputs: every tile count up to 128
+    tokens (up to 64: all score tiles at once; 65 .. 128: one query tile at a time), ragged lengths, padding on the LEFT (the Qwen tokenizer's side: the padding rows of a causal sequence have no allowed
     key and come back as zeros) and on the right, causal and not, 16 / 8 and 4 / 4 heads; longer sequences and other head sizes
     are refused."""
     import ctypes as C
@@ -592,7 +592,8 @@ def test_gqa_causal_attention_kernel_matches_fp64():
     g = torch.Generator(device="cpu").manual_seed(12)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for B, S, HQ, HKV in ((3, 1, 2, 1), (5, 7, 4, 2), (4, 16, 16, 8), (9, 19, 6, 2), (6, 32, 16, 8), (3, 33, 4, 4), (2, 48, 6, 3),
-                          (5, 61, 2, 2), (2, 64, 16, 8)):
+                          (5, 61, 2, 2), (2, 64, 16, 8), (3, 65, 4, 2), (2, 80, 16, 8), (5, 81, 2, 1), (2, 96, 6, 3), (3, 100, 16, 8),
+                          (2, 112, 4, 4), (4, 127, 2, 1), (3, 128, 16, 8)):
         qkv = (torch.randn((B, S, (HQ + 2 * HKV), 128), generator=g) * 1.2).to(torch.bfloat16).cuda()
         lens = torch.randint(1, S + 1, (B,), generator=g)
         right = (torch.arange(S)[None, :] < lens[:, None]).to(torch.int64).cuda()
@@ -619,7 +620,7 @@ def test_gqa_causal_attention_kernel_matches_fp64():
                 torch.cuda.synchronize()
                 err = (out.double() - want).abs().max().item()
                 assert err <= 3e-2, (B, S, HQ, HKV, causal, mask is not None, err)                # bf16 probabilities and output
-    for S, hd in ((65, 128), (16, 64)):
+    for S, hd in ((129, 128), (16, 64)):
         with pytest.raises(_ffi.TSearchError):
             _ffi.check(lib.ts_attention_gqa(0, C.c_void_p(qkv.data_ptr()), None, 1, S, 2, 1, hd, 1, C.c_void_p(out.data_ptr()), st))
 

@@ -172,9 +172,9 @@ extern "C" int ts_attention_gqa(int device, const void* qkv, const int64_t* atte
     if (!qkv || !out) return fail(TS_ERR_INVALID, "NULL argument");
     if (batch < 0 || seq < 1 || q_heads < 1 || kv_heads < 1 || q_heads % kv_heads != 0)
         return fail(TS_ERR_INVALID, "batch = %d, seq = %d, heads = %d over %d", batch, seq, q_heads, kv_heads);
-    if (head_dim != 128 || seq > kAttnGqaMaxSeq)
+    if (head_dim != 128 || seq > kAttnGqaRowsMaxSeq)
         return fail(TS_ERR_UNSUPPORTED, "head size %d / %d tokens: this kernel serves head size 128 and at most %d tokens", head_dim, seq,
-                    kAttnGqaMaxSeq);
+                    kAttnGqaRowsMaxSeq);
     if ((((uintptr_t)qkv | (uintptr_t)out) & 15) != 0) return fail(TS_ERR_INVALID, "qkv and out must be 16-byte aligned");
     if (batch == 0) return TS_OK;
     TS_TRY(check_device(device));
@@ -194,12 +194,44 @@ extern "C" int ts_attention_gqa(int device, const void* qkv, const int64_t* atte
         }                                                                                                                    \
         attention_gqa_kernel<T_, C_><<<grid, 256, lds_, st>>>(in, attention_mask, batch, seq, q_heads, kv_heads, o);         \
     } while (0)
+    // 65 .. 128 tokens: one query tile at a time against K fragments in registers and the V^T image in LDS
+#define TS_ATTN_GQA_ROWS(T_, C_)                                                                                             \
+    do {                                                                                                                     \
+        constexpr int lds_ = 4 * attn_gqa_rows_wave_lds(T_);                                                                 \
+        static_assert(lds_ <= 160 * 1024, "four waves' images fit the CU's LDS");                                            \
+        static std::atomic<unsigned long long> attr_{0};                                                                     \
+        const unsigned long long bit_ = 1ull << (device & 63);                                                               \
+        if (!(attr_.load(std::memory_order_acquire) & bit_)) {                                                               \
+            HIP_TRY(hipFuncSetAttribute((const void*)attention_gqa_rows_kernel<T_, C_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_)); \
+            attr_.fetch_or(bit_, std::memory_order_release);                                                                 \
+        }                                                                                                                    \
+        attention_gqa_rows_kernel<T_, C_><<<grid, 256, lds_, st>>>(in, attention_mask, batch, seq, q_heads, kv_heads, o);    \
+    } while (0)
     const int tiles = (seq + 15) / 16;
     if (causal) {
-        if (tiles == 1) TS_ATTN_GQA(1, true); else if (tiles == 2) TS_ATTN_GQA(2, true); else if (tiles == 3) TS_ATTN_GQA(3, true); else TS_ATTN_GQA(4, true);
+        switch (tiles) {
+            case 1: TS_ATTN_GQA(1, true); break;
+            case 2: TS_ATTN_GQA(2, true); break;
+            case 3: TS_ATTN_GQA(3, true); break;
+            case 4: TS_ATTN_GQA(4, true); break;
+            case 5: TS_ATTN_GQA_ROWS(5, true); break;
+            case 6: TS_ATTN_GQA_ROWS(6, true); break;
+            case 7: TS_ATTN_GQA_ROWS(7, true); break;
+            default: TS_ATTN_GQA_ROWS(8, true); break;
+        }
     } else {
-        if (tiles == 1) TS_ATTN_GQA(1, false); else if (tiles == 2) TS_ATTN_GQA(2, false); else if (tiles == 3) TS_ATTN_GQA(3, false); else TS_ATTN_GQA(4, false);
+        switch (tiles) {
+            case 1: TS_ATTN_GQA(1, false); break;
+            case 2: TS_ATTN_GQA(2, false); break;
+            case 3: TS_ATTN_GQA(3, false); break;
+            case 4: TS_ATTN_GQA(4, false); break;
+            case 5: TS_ATTN_GQA_ROWS(5, false); break;
+            case 6: TS_ATTN_GQA_ROWS(6, false); break;
+            case 7: TS_ATTN_GQA_ROWS(7, false); break;
+            default: TS_ATTN_GQA_ROWS(8, false); break;
+        }
     }
+#undef TS_ATTN_GQA_ROWS
 #undef TS_ATTN_GQA
     HIP_TRY(hipGetLastError());
     return TS_OK;

@@ -527,4 +527,178 @@ __global__ void __launch_bounds__(256, (T <= 2 ? 2 : 1)) attention_gqa_kernel(co
     }
 }
 
+// ---- head size 128, grouped-query, causal, 65 .. 128 tokens: one 16-query tile at a time ------------------------------------------
+// The production embedder's real inputs are `global_context + statement` (app_create_embeddings.py:48-70): longer than 64 tokens
+// more often than not, and torch's flash-attention launch takes 504 us per layer at 256 sequences x 128 tokens (14 of the 48 ms of
+// the Qwen3-shaped encoder-in-loop step).  The form of attention_rows_kernel with attention_gqa_kernel's layout: the K fragments of
+// the whole sequence (T x 4 x 4 registers) stay in registers, V^T [128][keys] stays in LDS (its fragments are read per query
+// tile: 128 more registers do not exist), the wave walks the query tiles; causal: tile qi multiplies key tiles 0 .. qi only.
+// LDS per wave: V^T image + ONE tile that is the P tile first and the O tile after P's fragments have been read.
+constexpr int kAttnGqaRowsMaxSeq = 128;
+constexpr int attn_gqa_rows_wave_lds(int T) {
+    const int sp = 16 * T, ks = (sp + 31) / 32, pp = 32 * ks + 8;
+    const int tile = 16 * (pp > 136 ? pp : 136) * 2;
+    return 128 * pp * 2 + tile;
+}
+
+template <int T, bool CAUSAL>
+__global__ void __launch_bounds__(256) attention_gqa_rows_kernel(const unsigned short* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                                  int B, int S, int HQ, int HKV, unsigned short* __restrict__ out) {
+    constexpr int HD = 128;
+    constexpr int SP = 16 * T;
+    constexpr int KS = (SP + 31) / 32;
+    constexpr int PP = 32 * KS + 8;
+    constexpr int OP = HD + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bh = blockIdx.x * 4 + wave;
+    if (bh >= B * HQ) return;
+    const int b = bh / HQ, h = bh - b * HQ;
+    const int kvh = h / (HQ / HKV);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int64_t tok = (int64_t)(HQ + 2 * HKV) * HD;
+    const unsigned short* qb = qkv + (int64_t)b * S * tok + (int64_t)h * HD;
+    const unsigned short* kb = qkv + (int64_t)b * S * tok + (int64_t)(HQ + kvh) * HD;
+    const unsigned short* vb = qkv + (int64_t)b * S * tok + (int64_t)(HQ + HKV + kvh) * HD;
+    unsigned short* sVT = (unsigned short*)(attn_smem + (size_t)wave * attn_gqa_rows_wave_lds(T));
+    unsigned short* sP = sVT + HD * PP;               // P tile [16][PP], then the O tile [16][OP]
+    unsigned short* sO = sP;
+
+    bf16x8 kf[T][4], qf[4];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int row = min(16 * t + r16, S - 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kf[t][ks] = *(const bf16x8*)(kb + row * tok + 32 * ks + 8 * g);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qb + min(r16, S - 1) * tok + 32 * ks + 8 * g);
+    // V rows -> V^T image: 16 lanes x 16 bytes per row, four key pairs per pass
+    constexpr int KP = SP / 2;
+    constexpr int VI = (KP + 3) / 4;
+    if (KS * 32 > SP)
+        for (int i = lane; i < HD * PP / 8; i += 64) ((uint4*)sVT)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i0 = 0; i0 < VI; i0 += 4) {              // four passes of loads in flight at a time (VI = 16 at T = 8)
+        uint4 v0[4], v1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kp = g + 4 * (i0 + i);
+            const int k0 = min(2 * kp, S - 1), k1 = min(2 * kp + 1, S - 1);
+            v0[i] = *(const uint4*)(vb + k0 * tok + 8 * r16);
+            v1[i] = *(const uint4*)(vb + k1 * tok + 8 * r16);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kp = g + 4 * (i0 + i);
+            if (i0 + i < VI && kp < KP) {
+                const u32 a[4] = {v0[i].x, v0[i].y, v0[i].z, v0[i].w}, c[4] = {v1[i].x, v1[i].y, v1[i].z, v1[i].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    u32* dst = (u32*)(sVT + (8 * r16 + 2 * e) * PP + 2 * kp);
+                    dst[0] = (a[e] & 0xFFFFu) | (c[e] << 16);
+                    *(u32*)((unsigned short*)dst + PP) = (a[e] >> 16) | (c[e] & 0xFFFF0000u);
+                }
+            }
+        }
+    }
+    bool keyok[T];
+#pragma unroll
+    for (int kj = 0; kj < T; ++kj) {
+        const int key = 16 * kj + r16;
+        keyok[kj] = key < S && (!mask || mask[(int64_t)b * S + key] != 0);
+    }
+    constexpr float kScaleLog2e = 0.08838834764831845f * 1.4426950408889634f;
+    unsigned short* obase = out + (int64_t)b * S * HQ * HD + (int64_t)h * HD;
+    const int ntile = (S + 15) / 16;
+#pragma unroll 1
+    for (int qi = 0; qi < ntile; ++qi) {
+        bf16x8 qn[4];
+        const int nrow = min(16 * (qi + 1) + r16, S - 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qn[ks] = *(const bf16x8*)(qb + nrow * tok + 32 * ks + 8 * g);
+        // the tile (P now) starts as zeros: the columns this query tile does not write (keys past it, keys past the padded sequence) stay zero
+        for (int i = lane; i < 16 * PP / 8; i += 64) ((uint4*)sP)[i] = make_uint4(0u, 0u, 0u, 0u);
+        f32x4 sc[T];
+#pragma unroll
+        for (int kj = 0; kj < T; ++kj) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            if (!CAUSAL || kj <= qi) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf[kj][ks], a, 0, 0, 0);
+            }
+            sc[kj] = a;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qrow = 16 * qi + 4 * g + r;
+            bool ok[T];
+#pragma unroll
+            for (int kj = 0; kj < T; ++kj) ok[kj] = keyok[kj] && (!CAUSAL || 16 * kj + r16 <= qrow);
+            float m = -INFINITY;
+#pragma unroll
+            for (int kj = 0; kj < T; ++kj) m = fmaxf(m, ok[kj] ? sc[kj][r] : -INFINITY);
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            float e[T], sum = 0.0f;
+#pragma unroll
+            for (int kj = 0; kj < T; ++kj) {
+                e[kj] = ok[kj] ? exp2f((sc[kj][r] - m) * kScaleLog2e) : 0.0f;
+                sum += e[kj];
+            }
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) sum += __shfl_xor(sum, off, 64);
+            const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;
+#pragma unroll
+            for (int kj = 0; kj < T; ++kj)
+                if (!CAUSAL || kj <= qi) sP[(4 * g + r) * PP + 16 * kj + r16] = (unsigned short)pack_bf16_hw(e[kj] * inv, 0.0f);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        bf16x8 pf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) pf[ks] = *(const bf16x8*)(sP + r16 * PP + 32 * ks + 8 * g);
+        const int ks_end = CAUSAL ? min(KS, (16 * (qi + 1) + 31) / 32) : KS;       // 32-key steps that hold an allowed key
+        f32x4 oc[HD / 16];
+#pragma unroll
+        for (int dj = 0; dj < HD / 16; ++dj) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                if (ks < ks_end) {
+                    const bf16x8 vf = *(const bf16x8*)(sVT + (16 * dj + r16) * PP + 32 * ks + 8 * g);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[ks], a, 0, 0, 0);
+                }
+            oc[dj] = a;
+        }
+        // P's fragments are in registers: the tile takes O as [q][d]
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int dj = 0; dj < HD / 16; ++dj)
+            *(uint2*)(sO + r16 * OP + 16 * dj + 4 * g) = make_uint2(pack_bf16_hw(oc[dj][0], oc[dj][1]), pack_bf16_hw(oc[dj][2], oc[dj][3]));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int i = lane; i < 16 * 16; i += 64) {
+            const int q = 16 * qi + (i >> 4), c = i & 15;
+            if (q < S) *(uint4*)(obase + (int64_t)q * HQ * HD + 8 * c) = *(const uint4*)(sO + (i >> 4) * OP + 8 * c);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
+    }
+}
+
 }  // namespace ts

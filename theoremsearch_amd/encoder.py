@@ -653,9 +653,9 @@ class FusedQwen3Forward:
       twenty-two launches per layer in PyTorch);
     * ``silu(gate) * up`` as ONE kernel (``ts_swiglu``).
 
-    * causal grouped-query attention of short sequences (bf16, up to 64 tokens) as ONE kernel straight from the stacked
+    * causal grouped-query attention of short sequences (bf16, up to 128 tokens) as ONE kernel straight from the stacked
       projection (``ts_attention_gqa``: one wave per (sequence, query head); torch's flash-attention launch took 202 us per
-      layer at 256 sequences x 32 tokens); longer sequences and fp32 keep ``scaled_dot_product_attention``.
+      layer at 256 sequences x 32 tokens, 504 us at 128); longer sequences and fp32 keep ``scaled_dot_product_attention``.
 
     Same weights, same order of operations, the roundings of the modules replaced."""
 
@@ -755,7 +755,7 @@ class FusedQwen3Forward:
         cos, sin = cos[0].contiguous(), sin[0].contiguous()
         mask = None
         # short sequences in bf16: the library's own causal grouped-query attention (TS_ENCODER_ATTENTION=0 keeps torch's)
-        short = (x.dtype == torch.bfloat16 and self.hd == 128 and S <= 64 and x.is_contiguous() and
+        short = (x.dtype == torch.bfloat16 and self.hd == 128 and S <= 128 and x.is_contiguous() and
                  os.environ.get("TS_ENCODER_ATTENTION", "1") != "0")
         key_mask = None if (no_padding or not short) else attention_mask.to(torch.int64).contiguous()
         if not no_padding and not short:
