@@ -61,12 +61,12 @@ def main(src, tag):
     for extra in ("clock_probe.json", "shard_steps.json"):
         if os.path.exists(os.path.join(src, extra)):
             shutil.copy(os.path.join(src, extra), os.path.join(out, f"{tag}_{extra}"))
-    for w in ("c5", "c5_128", "c5_qwen", "c5_gemma"):
+    for w in ("c5", "c5_128", "c5_qwen", "c5_qwen_128", "c5_gemma"):
         stats = newest(glob.glob(os.path.join(src, f"{w}_kernel_stats.csv")) or
                        glob.glob(os.path.join(src, f"trace_{w}", "**", "*kernel_stats.csv"), recursive=True))
         if stats:
             shutil.copy(stats[0], os.path.join(out, f"{tag}_{w}_kernel_stats.csv"))
-    for w in ("c3", "c2", "c2b", "c3q", "c5", "c5_128", "c5_qwen", "c5_gemma", "c1"):
+    for w in ("c3", "c2", "c2b", "c3q", "c5", "c5_128", "c5_qwen", "c5_qwen_128", "c5_gemma", "c1"):
         b = os.path.join(src, f"bench_{w}.json")
         if os.path.exists(b) and os.path.getsize(b) > 0:
             shutil.copy(b, os.path.join(out, f"{tag}_bench_{w}.json"))

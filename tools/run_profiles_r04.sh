@@ -35,6 +35,8 @@ elif [ "$PART" = "e" ]; then
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c3" -- python3 "$R/bench.py" --workload c3 --no-cpu-baseline --no-recall > "$OUT/trace_c3.json" 2> "$OUT/trace_c3.log" || exit 1
   cp "$(ls -t "$OUT"/trace_c3/*/*kernel_stats.csv | head -1)" "$OUT/c3_kernel_stats.csv"
   head -3 "$OUT/c3_kernel_stats.csv" | cut -c1-160 >&2
+elif [ "$PART" = "g" ]; then
+  bench_and_trace c5_qwen_128 --workload c5 --encoder qwen --seq-len 128 || exit 1
 elif [ "$PART" = "f" ]; then
   bench_and_trace c5_gemma --workload c5 --encoder gemma || exit 1
 elif [ "$PART" = "d" ]; then
