@@ -593,7 +593,7 @@ def test_gqa_causal_attention_kernel_matches_fp64():
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for B, S, HQ, HKV in ((3, 1, 2, 1), (5, 7, 4, 2), (4, 16, 16, 8), (9, 19, 6, 2), (6, 32, 16, 8), (3, 33, 4, 4), (2, 48, 6, 3),
                           (5, 61, 2, 2), (2, 64, 16, 8), (3, 65, 4, 2), (2, 80, 16, 8), (5, 81, 2, 1), (2, 96, 6, 3), (3, 100, 16, 8),
-                          (2, 112, 4, 4), (4, 127, 2, 1), (3, 128, 16, 8)):
+                          (2, 112, 4, 4), (4, 127, 2, 1), (3, 128, 16, 8), (2, 96, 8, 2), (3, 71, 12, 3)):
         qkv = (torch.randn((B, S, (HQ + 2 * HKV), 128), generator=g) * 1.2).to(torch.bfloat16).cuda()
         lens = torch.randint(1, S + 1, (B,), generator=g)
         right = (torch.arange(S)[None, :] < lens[:, None]).to(torch.int64).cuda()

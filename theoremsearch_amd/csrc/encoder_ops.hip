@@ -194,18 +194,28 @@ extern "C" int ts_attention_gqa(int device, const void* qkv, const int64_t* atte
         }                                                                                                                    \
         attention_gqa_kernel<T_, C_><<<grid, 256, lds_, st>>>(in, attention_mask, batch, seq, q_heads, kv_heads, o);         \
     } while (0)
-    // 65 .. 128 tokens: one query tile at a time against K fragments in registers and the V^T image in LDS
-#define TS_ATTN_GQA_ROWS(T_, C_)                                                                                             \
+    // 65 .. 128 tokens: one query tile at a time against K fragments in registers and a V^T image in LDS that the R query heads
+    // of a key / value group (R waves of one workgroup) share
+    const int per_kv = q_heads / kv_heads;
+    const int R = per_kv % 4 == 0 ? 4 : (per_kv % 2 == 0 ? 2 : 1);
+    const unsigned rows_grid = (unsigned)((int64_t)batch * kv_heads * (per_kv / R));
+#define TS_ATTN_GQA_ROWS_R(T_, C_, R_)                                                                                       \
     do {                                                                                                                     \
-        constexpr int lds_ = 4 * attn_gqa_rows_wave_lds(T_);                                                                 \
-        static_assert(lds_ <= 160 * 1024, "four waves' images fit the CU's LDS");                                            \
+        constexpr int lds_ = attn_gqa_rows_lds(T_, R_);                                                                      \
+        static_assert(lds_ <= 160 * 1024, "the image and the waves' tiles fit the CU's LDS");                                \
         static std::atomic<unsigned long long> attr_{0};                                                                     \
         const unsigned long long bit_ = 1ull << (device & 63);                                                               \
         if (!(attr_.load(std::memory_order_acquire) & bit_)) {                                                               \
-            HIP_TRY(hipFuncSetAttribute((const void*)attention_gqa_rows_kernel<T_, C_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_)); \
+            HIP_TRY(hipFuncSetAttribute((const void*)attention_gqa_rows_kernel<T_, C_, R_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_)); \
             attr_.fetch_or(bit_, std::memory_order_release);                                                                 \
         }                                                                                                                    \
-        attention_gqa_rows_kernel<T_, C_><<<grid, 256, lds_, st>>>(in, attention_mask, batch, seq, q_heads, kv_heads, o);    \
+        attention_gqa_rows_kernel<T_, C_, R_><<<rows_grid, 64 * R_, lds_, st>>>(in, attention_mask, batch, seq, q_heads, kv_heads, o); \
+    } while (0)
+#define TS_ATTN_GQA_ROWS(T_, C_)                                                                                             \
+    do {                                                                                                                     \
+        if (R == 4) TS_ATTN_GQA_ROWS_R(T_, C_, 4);                                                                           \
+        else if (R == 2) TS_ATTN_GQA_ROWS_R(T_, C_, 2);                                                                      \
+        else TS_ATTN_GQA_ROWS_R(T_, C_, 1);                                                                                  \
     } while (0)
     const int tiles = (seq + 15) / 16;
     if (causal) {
@@ -232,6 +242,7 @@ extern "C" int ts_attention_gqa(int device, const void* qkv, const int64_t* atte
         }
     }
 #undef TS_ATTN_GQA_ROWS
+#undef TS_ATTN_GQA_ROWS_R
 #undef TS_ATTN_GQA
     HIP_TRY(hipGetLastError());
     return TS_OK;

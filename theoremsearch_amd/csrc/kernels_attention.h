@@ -533,17 +533,23 @@ __global__ void __launch_bounds__(256, (T <= 2 ? 2 : 1)) attention_gqa_kernel(co
 // the Qwen3-shaped encoder-in-loop step).  The form of attention_rows_kernel with attention_gqa_kernel's layout: the K fragments of
 // the whole sequence (T x 4 x 4 registers) stay in registers, V^T [128][keys] stays in LDS (its fragments are read per query
 // tile: 128 more registers do not exist), the wave walks the query tiles; causal: tile qi multiplies key tiles 0 .. qi only.
-// LDS per wave: V^T image + ONE tile that is the P tile first and the O tile after P's fragments have been read.
+// LDS: one V^T image per workgroup + per wave ONE tile that is the P tile first and the O tile after P's fragments have been read.
 constexpr int kAttnGqaRowsMaxSeq = 128;
-constexpr int attn_gqa_rows_wave_lds(int T) {
+constexpr int attn_gqa_rows_tile_bytes(int T) {
     const int sp = 16 * T, ks = (sp + 31) / 32, pp = 32 * ks + 8;
-    const int tile = 16 * (pp > 136 ? pp : 136) * 2;
-    return 128 * pp * 2 + tile;
+    return 16 * (pp > 136 ? pp : 136) * 2;
+}
+constexpr int attn_gqa_rows_lds(int T, int R) {            // one V^T image per workgroup + one tile per wave
+    const int sp = 16 * T, ks = (sp + 31) / 32, pp = 32 * ks + 8;
+    return 128 * pp * 2 + R * attn_gqa_rows_tile_bytes(T);
 }
 
-template <int T, bool CAUSAL>
-__global__ void __launch_bounds__(256) attention_gqa_rows_kernel(const unsigned short* __restrict__ qkv, const int64_t* __restrict__ mask,
-                                                                  int B, int S, int HQ, int HKV, unsigned short* __restrict__ out) {
+// R = query heads per key / value head served by ONE workgroup of R waves (1, 2 or 4; grid = B * HKV * (HQ / HKV / R)): the
+// waves share the V^T image of their key / value head - each transposes its share of the rows - instead of building one each
+// (R = 2 for Qwen3's 16 / 8 heads: 43 KB of LDS per workgroup instead of 78, three workgroups per CU instead of two waves' worth).
+template <int T, bool CAUSAL, int R>
+__global__ void __launch_bounds__(64 * R) attention_gqa_rows_kernel(const unsigned short* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                                     int B, int S, int HQ, int HKV, unsigned short* __restrict__ out) {
     constexpr int HD = 128;
     constexpr int SP = 16 * T;
     constexpr int KS = (SP + 31) / 32;
@@ -551,17 +557,18 @@ __global__ void __launch_bounds__(256) attention_gqa_rows_kernel(const unsigned 
     constexpr int OP = HD + 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int bh = blockIdx.x * 4 + wave;
-    if (bh >= B * HQ) return;
-    const int b = bh / HQ, h = bh - b * HQ;
-    const int kvh = h / (HQ / HKV);
+    const int per_kv = HQ / HKV;                                  // query heads per key / value head (a multiple of R)
+    const int groups = per_kv / R;                                // workgroups per (sequence, key / value head)
+    const int bk = blockIdx.x / groups, sub = blockIdx.x - bk * groups;
+    const int b = bk / HKV, kvh = bk - b * HKV;
+    const int h = kvh * per_kv + sub * R + wave;
     const int r16 = lane & 15, g = lane >> 4;
     const int64_t tok = (int64_t)(HQ + 2 * HKV) * HD;
     const unsigned short* qb = qkv + (int64_t)b * S * tok + (int64_t)h * HD;
     const unsigned short* kb = qkv + (int64_t)b * S * tok + (int64_t)(HQ + kvh) * HD;
     const unsigned short* vb = qkv + (int64_t)b * S * tok + (int64_t)(HQ + HKV + kvh) * HD;
-    unsigned short* sVT = (unsigned short*)(attn_smem + (size_t)wave * attn_gqa_rows_wave_lds(T));
-    unsigned short* sP = sVT + HD * PP;               // P tile [16][PP], then the O tile [16][OP]
+    unsigned short* sVT = (unsigned short*)attn_smem;
+    unsigned short* sP = (unsigned short*)(attn_smem + HD * PP * 2 + (size_t)wave * attn_gqa_rows_tile_bytes(T));   // P tile, then the O tile
     unsigned short* sO = sP;
 
     bf16x8 kf[T][4], qf[4];
@@ -573,28 +580,28 @@ __global__ void __launch_bounds__(256) attention_gqa_rows_kernel(const unsigned 
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qb + min(r16, S - 1) * tok + 32 * ks + 8 * g);
-    // V rows -> V^T image: 16 lanes x 16 bytes per row, four key pairs per pass
+    // V rows -> the shared V^T image: 16 lanes x 16 bytes per row, four key pairs per pass, the passes dealt over the waves
     constexpr int KP = SP / 2;
     constexpr int VI = (KP + 3) / 4;
-    if (KS * 32 > SP)
-        for (int i = lane; i < HD * PP / 8; i += 64) ((uint4*)sVT)[i] = make_uint4(0u, 0u, 0u, 0u);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (KS * 32 > SP) {
+        for (int i = threadIdx.x; i < HD * PP / 8; i += 64 * R) ((uint4*)sVT)[i] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+    }
+    constexpr int VW = (VI + R - 1) / R;                          // passes per wave
 #pragma unroll
-    for (int i0 = 0; i0 < VI; i0 += 4) {              // four passes of loads in flight at a time (VI = 16 at T = 8)
+    for (int i0 = 0; i0 < VW; i0 += 4) {                          // four passes of loads in flight at a time
         uint4 v0[4], v1[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int kp = g + 4 * (i0 + i);
+            const int kp = g + 4 * ((i0 + i) * R + wave);
             const int k0 = min(2 * kp, S - 1), k1 = min(2 * kp + 1, S - 1);
             v0[i] = *(const uint4*)(vb + k0 * tok + 8 * r16);
             v1[i] = *(const uint4*)(vb + k1 * tok + 8 * r16);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int kp = g + 4 * (i0 + i);
-            if (i0 + i < VI && kp < KP) {
+            const int kp = g + 4 * ((i0 + i) * R + wave);
+            if (i0 + i < VW && kp < KP) {
                 const u32 a[4] = {v0[i].x, v0[i].y, v0[i].z, v0[i].w}, c[4] = {v1[i].x, v1[i].y, v1[i].z, v1[i].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -605,6 +612,7 @@ __global__ void __launch_bounds__(256) attention_gqa_rows_kernel(const unsigned 
             }
         }
     }
+    __syncthreads();                                              // the image is complete; from here on the waves go their own ways
     bool keyok[T];
 #pragma unroll
     for (int kj = 0; kj < T; ++kj) {
