@@ -44,6 +44,8 @@ from typing import Iterable, List, Optional, Sequence, Union
 import numpy as np
 import torch
 
+from .fused_forward import FusedBertForward, FusedGemma3Forward, FusedQwen3Forward   # noqa: F401  (re-exported)
+
 # Stand-in architectures for allow_random_init only (no weights offline): the published shapes of the reference's embedders
 # (ec2/generate_embeddings/embedders.py:1-4, app_create_embeddings.py:8).  family "bert": BertModel; family "qwen3": Qwen3Model
 # (decoder-style: RMSNorm, rotary positions, 16 query / 8 key-value heads of 128, gated MLP, last-token pooling); family "gemma3":
@@ -501,428 +503,6 @@ class SentenceEncoder:
             self.close()
         except Exception:
             pass
-
-
-class FusedBertForward:
-    """The forward of a BERT-family encoder (``BertModel``: what ``math-similarity/Bert-MLM_arXiv-MP-class_zbMath`` is,
-    compare_embeddings.py:11) with the launches that do not pay for themselves folded together:
-
-    * query / key / value projections as ONE GEMM over the concatenated weight (three 8,192 x 768 x 768 GEMMs fill the
-      chip a third each: 24 us apiece against 41 us for the fused one, measured per layer at 256 x 32 tokens);
-    * ``LayerNorm(dense_out + input)`` as ONE HIP kernel (``ts_add_layernorm``) instead of an add and a layer_norm launch
-      (18 + 7 us of device time twice per layer);
-    * the input layer (three embedding gathers, two adds, LayerNorm) as ONE HIP kernel (``ts_embed_layernorm``);
-    * for bf16 models with 64-wide heads and at most 128 tokens, the attention as ONE wave per (sequence, head)
-      (``ts_attention_short``; ``TS_ENCODER_ATTENTION=0`` keeps ``scaled_dot_product_attention``).
-
-    Same weights, same order of operations, exact erf GELU (whatever ``config.hidden_act`` names); the attention is
-    ``scaled_dot_product_attention`` with the padding mask, as the model's own ``sdpa`` path.  Used on a GPU for bf16 / fp32
-    models whose config this form covers; anything else runs the model's own forward."""
-
-    def __init__(self, model):
-        cfg = model.config
-        self.model, self.cfg = model, cfg
-        self.heads = cfg.num_attention_heads
-        self.eps = float(cfg.layer_norm_eps)
-        from transformers.activations import ACT2FN
-        self.act = ACT2FN[cfg.hidden_act] if isinstance(cfg.hidden_act, str) else cfg.hidden_act
-        self._stamp = None
-        self._refresh()
-
-    def _sources(self):
-        """The parameters the stacked projection weights are copies of."""
-        for layer in self.model.encoder.layer:
-            att = layer.attention.self
-            yield from (att.query.weight, att.key.weight, att.value.weight, att.query.bias, att.key.bias, att.value.bias)
-
-    def _refresh(self):
-        """(Re)build the stacked query / key / value weights when the model's own have changed (load_state_dict, .to(dtype),
-        an edit in place): the other weights are live references, the stacked ones are copies."""
-        stamp = tuple((p.data_ptr(), p._version, p.dtype) for p in self._sources())
-        if stamp == self._stamp:
-            return
-        self._stamp = stamp
-        self.layers = []
-        for layer in self.model.encoder.layer:
-            att, so = layer.attention.self, layer.attention.output
-            self.layers.append({
-                "wqkv": torch.cat([att.query.weight, att.key.weight, att.value.weight], dim=0).contiguous(),
-                "bqkv": torch.cat([att.query.bias, att.key.bias, att.value.bias], dim=0).contiguous(),
-                "wo": so.dense.weight, "bo": so.dense.bias, "ln1": so.LayerNorm,
-                "w1": layer.intermediate.dense.weight, "b1": layer.intermediate.dense.bias,
-                "w2": layer.output.dense.weight, "b2": layer.output.dense.bias, "ln2": layer.output.LayerNorm,
-            })
-
-    @staticmethod
-    def covers(model) -> bool:
-        cfg = getattr(model, "config", None)
-        if cfg is None or getattr(cfg, "model_type", "") != "bert" or not hasattr(model, "encoder"):
-            return False
-        if getattr(cfg, "position_embedding_type", "absolute") != "absolute" or getattr(cfg, "is_decoder", False):
-            return False
-        p = next(model.parameters())
-        return (p.is_cuda and p.dtype in (torch.float32, torch.bfloat16) and cfg.hidden_size % 8 == 0 and cfg.hidden_size <= 1024
-                and cfg.hidden_size % cfg.num_attention_heads == 0)
-
-    def _embed(self, input_ids: torch.Tensor, token_type_ids: Optional[torch.Tensor]) -> torch.Tensor:
-        """BertEmbeddings (word + token type + position, LayerNorm; dropout is the identity in eval) as ONE HIP kernel
-        (``ts_embed_layernorm``) instead of three gathers, two adds and a layer_norm launch.  Anything the kernel's form does not
-        cover (a sequence longer than the position table, a module without the three tables) runs the module itself."""
-        import ctypes as C
-        from . import _ffi
-        emb = self.model.embeddings
-        tables = [getattr(emb, n, None) for n in ("word_embeddings", "position_embeddings", "token_type_embeddings")]
-        ln = getattr(emb, "LayerNorm", None)
-        B, S = input_ids.shape
-        if any(t is None for t in tables) or ln is None or S > tables[1].weight.shape[0] or input_ids.dtype != torch.int64:
-            return emb(input_ids=input_ids, token_type_ids=token_type_ids)
-        w, p, t = (m.weight for m in tables)
-        ids = input_ids.contiguous()
-        tt = token_type_ids.contiguous().to(torch.int64) if token_type_ids is not None else None
-        H = w.shape[1]
-        out = torch.empty((B, S, H), dtype=w.dtype, device=w.device)
-        _ffi.check(_ffi.load().ts_embed_layernorm(
-            w.device.index or 0, C.c_void_p(ids.data_ptr()), C.c_void_p(tt.data_ptr()) if tt is not None else None,
-            C.c_void_p(w.data_ptr()), C.c_void_p(p.data_ptr()), C.c_void_p(t.data_ptr()), w.shape[0], p.shape[0], t.shape[0],
-            C.c_void_p(ln.weight.data_ptr()), C.c_void_p(ln.bias.data_ptr()), self.eps, B * S, S, H,
-            1 if w.dtype == torch.bfloat16 else 0, C.c_void_p(out.data_ptr()),
-            C.c_void_p(torch.cuda.current_stream(w.device).cuda_stream)))
-        return out
-
-    def _attention(self, qkv: torch.Tensor, key_mask: Optional[torch.Tensor], B: int, S: int) -> torch.Tensor:
-        import ctypes as C
-        from . import _ffi
-        qkv = qkv.contiguous()
-        out = torch.empty((B, S, self.heads * 64), dtype=torch.bfloat16, device=qkv.device)
-        _ffi.check(_ffi.load().ts_attention_short(
-            qkv.device.index or 0, C.c_void_p(qkv.data_ptr()), C.c_void_p(key_mask.data_ptr()) if key_mask is not None else None,
-            B, S, self.heads, 64, C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream)))
-        return out
-
-    def _add_ln(self, a: torch.Tensor, b: torch.Tensor, ln) -> torch.Tensor:
-        import ctypes as C
-        from . import _ffi
-        a, b = a.contiguous(), b.contiguous()
-        out = torch.empty_like(a)
-        rows, d = a.numel() // a.shape[-1], a.shape[-1]
-        _ffi.check(_ffi.load().ts_add_layernorm(
-            a.device.index or 0, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(ln.weight.data_ptr()),
-            C.c_void_p(ln.bias.data_ptr()), self.eps, rows, d, 1 if a.dtype == torch.bfloat16 else 0, C.c_void_p(out.data_ptr()),
-            C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)))
-        return out
-
-    def __call__(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, token_type_ids: Optional[torch.Tensor] = None,
-                 no_padding: bool = False):
-        F = torch.nn.functional
-        self._refresh()
-        x = self._embed(input_ids, token_type_ids)
-        B, S, H = x.shape
-        hd = H // self.heads
-        # padding keys are never attended to: ONE additive mask per forward (a boolean mask is expanded to a bias inside every
-        # scaled_dot_product_attention call: two fill launches per layer); none at all when the caller knows the batch has no
-        # padding (every sequence as long as the batch: 50 instead of 60 us per layer for projections + attention)
-        # short sequences (one sentence per query: app_showcase_model.py:92) of a bf16 model with 64-wide heads: the attention as
-        # ONE wave per (sequence, head), straight from the fused projection to the context layout (``ts_attention_short``)
-        short = x.dtype == torch.bfloat16 and hd == 64 and S <= 128 and os.environ.get("TS_ENCODER_ATTENTION", "1") != "0"
-        # (the most negative finite value, not -inf: a sequence without a single token would otherwise soften to NaN)
-        mask = None if (no_padding or short) else torch.zeros((B, 1, 1, S), dtype=x.dtype, device=x.device).masked_fill_(
-            ~attention_mask[:, None, None, :].to(torch.bool), torch.finfo(x.dtype).min)
-        key_mask = None if (no_padding or not short) else attention_mask.to(torch.int64).contiguous()
-        for L in self.layers:
-            qkv = F.linear(x, L["wqkv"], L["bqkv"])
-            if short:
-                ctx = self._attention(qkv, key_mask, B, S)
-            else:
-                qkv = qkv.view(B, S, 3, self.heads, hd).permute(2, 0, 3, 1, 4)
-                ctx = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], attn_mask=mask)
-                ctx = ctx.transpose(1, 2).reshape(B, S, H)
-            x = self._add_ln(F.linear(ctx, L["wo"], L["bo"]), x, L["ln1"])
-            h = self.act(F.linear(x, L["w1"], L["b1"]))
-            x = self._add_ln(F.linear(h, L["w2"], L["b2"]), x, L["ln2"])
-        return x
-
-
-class FusedQwen3Forward:
-    """The forward of a Qwen3-family encoder (``Qwen3Model``: what ``Qwen/Qwen3-Embedding-0.6B`` is, the embedder of the
-    production app, streamlit_app.py:55) with everything around its GEMMs as kernels of libtsearch:
-
-    * query / key / value projections as ONE GEMM over the stacked weight, gate / up projections as ONE;
-    * ``residual + sublayer`` followed by the next RMSNorm as ONE kernel (``ts_add_rmsnorm``: PyTorch runs an add and six
-      launches per norm, twice per layer);
-    * the per-head RMSNorm of queries and keys + the rotary embedding as ONE kernel, in place (``ts_qk_norm_rope``:
-      twenty-two launches per layer in PyTorch);
-    * ``silu(gate) * up`` as ONE kernel (``ts_swiglu``).
-
-    * causal grouped-query attention of short sequences (bf16, up to 128 tokens) as ONE kernel straight from the stacked
-      projection (``ts_attention_gqa``: one wave per (sequence, query head); torch's flash-attention launch took 202 us per
-      layer at 256 sequences x 32 tokens, 504 us at 128); longer sequences and fp32 keep ``scaled_dot_product_attention``.
-
-    Same weights, same order of operations, the roundings of the modules replaced."""
-
-    def __init__(self, model):
-        cfg = model.config
-        self.model, self.cfg = model, cfg
-        self.hq, self.hkv, self.hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
-        self.eps = float(cfg.rms_norm_eps)
-        self._stamp = None
-        self._gqa_native = True
-        self._refresh()
-
-    def _sources(self):
-        for layer in self.model.layers:
-            att, mlp = layer.self_attn, layer.mlp
-            yield from (att.q_proj.weight, att.k_proj.weight, att.v_proj.weight, mlp.gate_proj.weight, mlp.up_proj.weight)
-
-    def _refresh(self):
-        stamp = tuple((p.data_ptr(), p._version, p.dtype) for p in self._sources())
-        if stamp == self._stamp:
-            return
-        self._stamp = stamp
-        self.layers = []
-        for layer in self.model.layers:
-            att, mlp = layer.self_attn, layer.mlp
-            self.layers.append({
-                "wqkv": torch.cat([att.q_proj.weight, att.k_proj.weight, att.v_proj.weight], dim=0).contiguous(),
-                "wo": att.o_proj.weight, "qn": att.q_norm.weight, "kn": att.k_norm.weight,
-                "wgu": torch.cat([mlp.gate_proj.weight, mlp.up_proj.weight], dim=0).contiguous(), "wd": mlp.down_proj.weight,
-                "ln1": layer.input_layernorm.weight, "ln2": layer.post_attention_layernorm.weight,
-            })
-
-    @staticmethod
-    def covers(model) -> bool:
-        cfg = getattr(model, "config", None)
-        if cfg is None or getattr(cfg, "model_type", "") != "qwen3" or not hasattr(model, "layers"):
-            return False
-        if getattr(cfg, "attention_bias", False) or getattr(cfg, "head_dim", 0) != 128:
-            return False
-        if any(t != "full_attention" for t in (getattr(cfg, "layer_types", None) or [])):
-            return False
-        if getattr(cfg, "hidden_act", "silu") != "silu":
-            return False
-        p = next(model.parameters())
-        vec = 8 if p.dtype == torch.bfloat16 else 4
-        return (p.is_cuda and p.dtype in (torch.float32, torch.bfloat16) and cfg.hidden_size % vec == 0 and
-                cfg.hidden_size <= 256 * vec and cfg.intermediate_size % vec == 0 and
-                cfg.num_attention_heads % cfg.num_key_value_heads == 0)
-
-    def _add_rmsnorm(self, a: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tensor, want_sum: bool):
-        import ctypes as C
-        from . import _ffi
-        d = a.shape[-1]
-        rows = a.numel() // d
-        out = torch.empty_like(a)
-        new_res = torch.empty_like(a) if (want_sum and b is not None) else None
-        _ffi.check(_ffi.load().ts_add_rmsnorm(
-            a.device.index or 0, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()) if b is not None else None,
-            C.c_void_p(gamma.data_ptr()), self.eps, rows, d, 1 if a.dtype == torch.bfloat16 else 0,
-            C.c_void_p(new_res.data_ptr()) if new_res is not None else None, C.c_void_p(out.data_ptr()),
-            C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)))
-        return (new_res if new_res is not None else a), out
-
-    def _sdpa(self, qkv: torch.Tensor, mask: Optional[torch.Tensor], B: int, S: int, nq: int, nkv: int, hd: int) -> torch.Tensor:
-        """torch's attention on the stacked projection (longer sequences, fp32): causal, grouped-query, as the model's own sdpa path."""
-        F = torch.nn.functional
-        q = qkv[..., :nq].view(B, S, self.hq, hd).transpose(1, 2)
-        k = qkv[..., nq:nq + nkv].view(B, S, self.hkv, hd).transpose(1, 2)
-        v = qkv[..., nq + nkv:].view(B, S, self.hkv, hd).transpose(1, 2)
-        ctx = None
-        if self._gqa_native:
-            try:
-                ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, is_causal=mask is None, enable_gqa=True)
-            except (RuntimeError, TypeError):
-                self._gqa_native = False
-        if ctx is None:
-            rep = self.hq // self.hkv
-            ctx = F.scaled_dot_product_attention(q, k.repeat_interleave(rep, dim=1), v.repeat_interleave(rep, dim=1),
-                                                 attn_mask=mask, is_causal=mask is None)
-        return ctx.transpose(1, 2).reshape(B, S, nq)
-
-    def __call__(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, token_type_ids: Optional[torch.Tensor] = None,
-                 no_padding: bool = False):
-        import ctypes as C
-        from . import _ffi
-        F = torch.nn.functional
-        lib = _ffi.load()
-        self._refresh()
-        m = self.model
-        x = m.embed_tokens(input_ids).contiguous()
-        B, S, H = x.shape
-        dt = 1 if x.dtype == torch.bfloat16 else 0
-        dev = x.device.index or 0
-        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        pos = torch.arange(S, device=x.device).unsqueeze(0)              # positions count from the left edge, padding included
-        cos, sin = m.rotary_emb(x, pos)                                  # [1 x S x 128] of the model's type
-        cos, sin = cos[0].contiguous(), sin[0].contiguous()
-        mask = None
-        # short sequences in bf16: the library's own causal grouped-query attention (TS_ENCODER_ATTENTION=0 keeps torch's)
-        short = (x.dtype == torch.bfloat16 and self.hd == 128 and S <= 128 and x.is_contiguous() and
-                 os.environ.get("TS_ENCODER_ATTENTION", "1") != "0")
-        key_mask = None if (no_padding or not short) else attention_mask.to(torch.int64).contiguous()
-        if not no_padding and not short:
-            # causal, and padding keys are never attended to (the most negative finite value: rows of padding stay finite)
-            neg = torch.finfo(x.dtype).min
-            causal = torch.ones((S, S), dtype=torch.bool, device=x.device).tril_()
-            keep = causal[None, None] & attention_mask[:, None, None, :].to(torch.bool)
-            mask = torch.zeros((B, 1, S, S), dtype=x.dtype, device=x.device).masked_fill_(~keep, neg)
-        nq, nkv, hd = self.hq * self.hd, self.hkv * self.hd, self.hd
-        h = self._add_rmsnorm(x, None, self.layers[0]["ln1"], False)[1]
-        for li, L in enumerate(self.layers):
-            qkv = F.linear(h, L["wqkv"])
-            _ffi.check(lib.ts_qk_norm_rope(dev, C.c_void_p(qkv.data_ptr()), C.c_void_p(L["qn"].data_ptr()), C.c_void_p(L["kn"].data_ptr()),
-                                           C.c_void_p(cos.data_ptr()), C.c_void_p(sin.data_ptr()), self.eps, B * S, S, self.hq, self.hkv,
-                                           hd, dt, stream))
-            if short:
-                # one wave per (sequence, query head), straight from the stacked projection's output (ts_attention_gqa)
-                ctx = torch.empty((B, S, nq), dtype=x.dtype, device=x.device)
-                _ffi.check(lib.ts_attention_gqa(dev, C.c_void_p(qkv.data_ptr()), C.c_void_p(key_mask.data_ptr()) if key_mask is not None else None,
-                                               B, S, self.hq, self.hkv, hd, 1, C.c_void_p(ctx.data_ptr()), stream))
-            else:
-                ctx = self._sdpa(qkv, mask, B, S, nq, nkv, hd)
-            x, h = self._add_rmsnorm(x, F.linear(ctx, L["wo"]), L["ln2"], True)
-            gu = F.linear(h, L["wgu"])
-            inter = gu.shape[-1] // 2
-            act = torch.empty((B, S, inter), dtype=x.dtype, device=x.device)
-            _ffi.check(lib.ts_swiglu(dev, C.c_void_p(gu.data_ptr()), B * S, inter, dt, C.c_void_p(act.data_ptr()), stream))
-            last = li + 1 == len(self.layers)
-            gamma = m.norm.weight if last else self.layers[li + 1]["ln1"]
-            x, h = self._add_rmsnorm(x, F.linear(act, L["wd"]), gamma, not last)
-        return h
-
-
-class FusedGemma3Forward:
-    """The forward of a Gemma3 text encoder with bidirectional attention (``Gemma3TextModel``: what
-    ``google/embeddinggemma-300m`` is, the reference's second embedder, ec2/generate_embeddings/embedders.py:1-4) with everything
-    around its GEMMs and its attention as kernels of libtsearch:
-
-    * query / key / value projections as ONE GEMM over the stacked weight, gate / up projections as ONE;
-    * the post-sublayer RMSNorm, the residual add and the pre-norm of the next sublayer as ONE kernel (``ts_gemma_norm``:
-      PyTorch runs two norms of seven launches each and an add, twice per layer);
-    * the per-head RMSNorm of queries and keys + the rotary embedding as ONE kernel, in place (``ts_gemma_qk_norm_rope``;
-      sliding and full attention layers have their own cos / sin tables);
-    * ``gelu_tanh(gate) * up`` as ONE kernel (``ts_geglu``).
-
-    The attention is ``scaled_dot_product_attention`` (heads of 256, grouped-query, every key visible: sequences shorter than
-    the sliding window).  Same weights, same order of operations, the roundings of the modules replaced.  Longer sequences
-    than the sliding window take the model's own forward."""
-
-    def __init__(self, model):
-        cfg = model.config
-        self.model, self.cfg = model, cfg
-        self.hq, self.hkv, self.hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
-        self.eps = float(cfg.rms_norm_eps)
-        self.scaling = float(cfg.query_pre_attn_scalar) ** -0.5
-        self._stamp = None
-        self._gqa_native = True
-        self._refresh()
-
-    def _sources(self):
-        for layer in self.model.layers:
-            att, mlp = layer.self_attn, layer.mlp
-            yield from (att.q_proj.weight, att.k_proj.weight, att.v_proj.weight, mlp.gate_proj.weight, mlp.up_proj.weight)
-
-    def _refresh(self):
-        stamp = tuple((p.data_ptr(), p._version, p.dtype) for p in self._sources())
-        if stamp == self._stamp:
-            return
-        self._stamp = stamp
-        self.layers = []
-        for layer in self.model.layers:
-            att, mlp = layer.self_attn, layer.mlp
-            self.layers.append({
-                "wqkv": torch.cat([att.q_proj.weight, att.k_proj.weight, att.v_proj.weight], dim=0).contiguous(),
-                "wo": att.o_proj.weight, "qn": att.q_norm.weight, "kn": att.k_norm.weight,
-                "wgu": torch.cat([mlp.gate_proj.weight, mlp.up_proj.weight], dim=0).contiguous(), "wd": mlp.down_proj.weight,
-                "ln_in": layer.input_layernorm.weight, "ln_post_attn": layer.post_attention_layernorm.weight,
-                "ln_pre_ffn": layer.pre_feedforward_layernorm.weight, "ln_post_ffn": layer.post_feedforward_layernorm.weight,
-                "type": att.layer_type,
-            })
-
-    @staticmethod
-    def covers(model) -> bool:
-        cfg = getattr(model, "config", None)
-        if cfg is None or getattr(cfg, "model_type", "") != "gemma3_text" or not hasattr(model, "layers"):
-            return False
-        if not getattr(cfg, "use_bidirectional_attention", False) or getattr(cfg, "attention_bias", False):
-            return False
-        if getattr(cfg, "attn_logit_softcapping", None) or getattr(cfg, "head_dim", 0) != 256:
-            return False
-        if getattr(cfg, "hidden_activation", "") != "gelu_pytorch_tanh":
-            return False
-        p = next(model.parameters())
-        vec = 8 if p.dtype == torch.bfloat16 else 4
-        return (p.is_cuda and p.dtype in (torch.float32, torch.bfloat16) and cfg.hidden_size % vec == 0 and
-                cfg.hidden_size <= 256 * vec and cfg.intermediate_size % vec == 0 and
-                cfg.num_attention_heads % cfg.num_key_value_heads == 0)
-
-    def _norm(self, y: Optional[torch.Tensor], x: torch.Tensor, w_post: Optional[torch.Tensor], w_next: torch.Tensor, want_sum: bool):
-        import ctypes as C
-        from . import _ffi
-        d = x.shape[-1]
-        rows = x.numel() // d
-        out = torch.empty_like(x)
-        new_res = torch.empty_like(x) if (want_sum and y is not None) else None
-        _ffi.check(_ffi.load().ts_gemma_norm(
-            x.device.index or 0, C.c_void_p(y.data_ptr()) if y is not None else None, C.c_void_p(x.data_ptr()),
-            C.c_void_p(w_post.data_ptr()) if w_post is not None else None, C.c_void_p(w_next.data_ptr()), self.eps, rows, d,
-            1 if x.dtype == torch.bfloat16 else 0, C.c_void_p(new_res.data_ptr()) if new_res is not None else None,
-            C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
-        return (new_res if new_res is not None else x), out
-
-    def __call__(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, token_type_ids: Optional[torch.Tensor] = None,
-                 no_padding: bool = False):
-        import ctypes as C
-        from . import _ffi
-        F = torch.nn.functional
-        B, S = input_ids.shape
-        if S >= int(self.cfg.sliding_window):                        # the sliding layers would hide keys: the model's own masks
-            return self.model(input_ids=input_ids, attention_mask=attention_mask).last_hidden_state
-        lib = _ffi.load()
-        self._refresh()
-        m = self.model
-        x = m.embed_tokens(input_ids).contiguous()                    # scaled by sqrt(hidden) in the storage type, as the module does
-        dt = 1 if x.dtype == torch.bfloat16 else 0
-        dev = x.device.index or 0
-        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        pos = torch.arange(S, device=x.device).unsqueeze(0)
-        tables = {}
-        for lt in set(self.cfg.layer_types):
-            cos, sin = m.rotary_emb(x, pos, lt)                       # [1 x S x 256] of the model's type
-            tables[lt] = (cos[0].contiguous(), sin[0].contiguous())
-        mask = None
-        if not no_padding:
-            neg = torch.finfo(x.dtype).min
-            mask = torch.zeros((B, 1, 1, S), dtype=x.dtype, device=x.device).masked_fill_(~attention_mask[:, None, None, :].to(torch.bool), neg)
-        nq, nkv, hd = self.hq * self.hd, self.hkv * self.hd, self.hd
-        h = self._norm(None, x, None, self.layers[0]["ln_in"], False)[1]
-        for li, L in enumerate(self.layers):
-            qkv = F.linear(h, L["wqkv"])
-            cos, sin = tables[L["type"]]
-            _ffi.check(lib.ts_gemma_qk_norm_rope(dev, C.c_void_p(qkv.data_ptr()), C.c_void_p(L["qn"].data_ptr()), C.c_void_p(L["kn"].data_ptr()),
-                                                 C.c_void_p(cos.data_ptr()), C.c_void_p(sin.data_ptr()), self.eps, B * S, S, self.hq, self.hkv,
-                                                 hd, dt, stream))
-            q = qkv[..., :nq].view(B, S, self.hq, hd).transpose(1, 2)
-            k = qkv[..., nq:nq + nkv].view(B, S, self.hkv, hd).transpose(1, 2)
-            v = qkv[..., nq + nkv:].view(B, S, self.hkv, hd).transpose(1, 2)
-            ctx = None
-            if self._gqa_native:
-                try:
-                    ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, scale=self.scaling, enable_gqa=True)
-                except (RuntimeError, TypeError):
-                    self._gqa_native = False
-            if ctx is None:
-                rep = self.hq // self.hkv
-                ctx = F.scaled_dot_product_attention(q, k.repeat_interleave(rep, dim=1), v.repeat_interleave(rep, dim=1),
-                                                     attn_mask=mask, scale=self.scaling)
-            ctx = ctx.transpose(1, 2).reshape(B, S, nq)
-            x, h = self._norm(F.linear(ctx, L["wo"]), x, L["ln_post_attn"], L["ln_pre_ffn"], True)
-            gu = F.linear(h, L["wgu"])
-            inter = gu.shape[-1] // 2
-            act = torch.empty((B, S, inter), dtype=x.dtype, device=x.device)
-            _ffi.check(lib.ts_geglu(dev, C.c_void_p(gu.data_ptr()), B * S, inter, dt, C.c_void_p(act.data_ptr()), stream))
-            last = li + 1 == len(self.layers)
-            w_next = m.norm.weight if last else self.layers[li + 1]["ln_in"]
-            x, h = self._norm(F.linear(act, L["wd"]), x, L["ln_post_ffn"], w_next, not last)
-        return h
 
 
 def pool_reference(hidden: torch.Tensor, attention_mask: torch.Tensor, mode: str) -> torch.Tensor:
