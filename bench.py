@@ -159,22 +159,24 @@ class PowerSampler:
                 "during": "the sustained leg (back-to-back steps behind the timed region)"}
 
 
-def launch_ranks(n, share_gpu):
+def launch_ranks(n):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: this process starts the N ranks itself - one CHILD
-    process per GPU with the environment `torch.distributed.run` would give it (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_*),
-    the same argv - waits for them, hands rank 0's JSON line to its own stdout and exits with the first non-zero exit
-    code.  The parent never imports torch and never touches HIP (children are started with `subprocess`, nothing is
-    exec'ed over a process that has initialised the GPU).  A rank that dies takes the others with it (they would wait in
-    a collective for ever): the survivors get SIGTERM, then SIGKILL, by pid.
+    process per GPU with the environment `torch.distributed.run` would give it (RANK, LOCAL_RANK, WORLD_SIZE), the same
+    argv - waits for them, hands rank 0's JSON line to its own stdout and exits with the first non-zero exit code.  The
+    parent never imports torch and never touches HIP (children are started with `subprocess`, nothing is exec'ed over a
+    process that has initialised the GPU).  A rank that dies takes the others with it (they would wait in a collective for
+    ever): the survivors get SIGTERM, then SIGKILL, by pid; a parent that is killed outright takes them along too (every
+    child asks for SIGTERM on its parent's death, `rank_dies_with_parent`).
+    Rendezvous: a FILE store in a private temporary directory (TS_BENCH_INIT_FILE -> init_method file://...), not a TCP port
+    picked here: a port found free by bind-and-close can be taken by another process before rank 0 listens on it.
     SURVEY.md 8e: the reference's only multi-device call is SentenceTransformer.encode_multi_process
     (ec2/generate_embeddings/embeddings.py:32) - a worker pool started by the library from one `python -m` command."""
+    import shutil
     import signal
-    import socket
     import subprocess
+    import tempfile
     import threading
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    rdv_dir = tempfile.mkdtemp(prefix="ts_bench_rdv_")
     ncpu = len(os.sched_getaffinity(0))
     procs, lines = [], []
     lock = threading.Lock()
@@ -191,8 +193,15 @@ def launch_ranks(n, share_gpu):
     for r in range(n):
         env = dict(os.environ)
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
-                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "TS_BENCH_LAUNCHED_BY": "bench.py"})
+                    "TS_BENCH_INIT_FILE": os.path.join(rdv_dir, "store"), "TS_BENCH_LAUNCHED_BY": "bench.py"})
+        for k_ in ("MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k_, None)
+        # ROCr's IPC mode for memory shared between processes: 0 = dmabuf handles, the only kind the host driver of this
+        # image's GPU pool supports.  RCCL maps its peers' buffers through it when the ranks are separate processes; with the
+        # legacy mode its set-up fails with "hipIpcGetMemHandle: invalid argument".  The image exports the variable already;
+        # this keeps it for ranks started from an environment that was scrubbed (a driver's `env -i`, a test's own dict).
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # host threads per rank: corpus generation, the fp64 truth and the gloo rehearsal share the node's cores
         env.setdefault("OMP_NUM_THREADS", str(max(1, ncpu // n)))
         p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE)
         t = threading.Thread(target=relay, args=(p,), daemon=True)
@@ -232,10 +241,74 @@ def launch_ranks(n, share_gpu):
     if rc == 0 and len(lines) != 1:
         print(f"[bench] expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr, flush=True)
         rc = 1
+    shutil.rmtree(rdv_dir, ignore_errors=True)
     if rc == 0:
         sys.stdout.write(lines[0])
         sys.stdout.flush()
     sys.exit(rc)
+
+
+def rank_dies_with_parent():
+    """A rank started by `launch_ranks`: ask the kernel for SIGTERM when the parent goes away (prctl PR_SET_PDEATHSIG), so a
+    parent killed with SIGKILL (`timeout -k`) does not leave ranks holding their GPUs.  Called before torch is imported."""
+    import ctypes
+    import signal
+    try:
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)      # 1 = PR_SET_PDEATHSIG
+    except OSError:
+        return
+    if os.getppid() == 1:                                      # the parent went away before the request was in place
+        raise SystemExit("rank: the launching process is gone")
+
+
+def init_process_group(dist, backend, rank, world, **kw):
+    """Under `launch_ranks` the ranks meet through a file store (TS_BENCH_INIT_FILE); under torch.distributed.run through
+    the launcher's MASTER_ADDR / MASTER_PORT."""
+    path = os.environ.get("TS_BENCH_INIT_FILE")
+    if path:
+        dist.init_process_group(backend=backend, init_method=f"file://{path}", rank=rank, world_size=world, **kw)
+    else:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+
+
+def rehearse_launch(args, real_stdout):
+    """`--rehearse-launch`: the launch and host-collective plumbing of an N-rank run WITHOUT a device - what `--gpus 8` does
+    around its searches on a node nobody here has seen: the rendezvous, barriers, the max-over-ranks all-reduce of the step
+    time, the placement trial's all-reduces and `all_gather_object` of truth tables of the real shape
+    (nq x (k + 64) fp64 + int64 per rank), over gloo.  No search runs and no number is reported as one: rank 0 prints one
+    JSON line that says what was exercised.  (A one-GPU box may hold at most six processes on its card, so the eight-rank
+    case cannot be rehearsed through the kernels; `--share-gpu` covers up to five ranks that way.)"""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    init_process_group(dist, "gloo", rank, world)
+    nq = args.nq or WORKLOADS[args.workload][2]
+    t0 = time.perf_counter()
+    dist.barrier()
+    t = torch.tensor([float(rank)], dtype=torch.float64)
+    for _ in range(16):                                       # the timed region's and the placement trial's reductions
+        t.fill_(float(rank))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert int(t.item()) == world - 1
+    table = (np.full((nq, K + 64), float(rank)), np.full((nq, K + 64), rank, dtype=np.int64), np.full((nq, K), float(rank)), rank)
+    objs = [None] * world
+    dist.all_gather_object(objs, table)
+    assert [o[3] for o in objs] == list(range(world)) and all(o[0].shape == (nq, K + 64) for o in objs)
+    blk = torch.full(((nq * K * 4 + 7) // 8 * 8 + nq * K * 8,), rank, dtype=torch.uint8)
+    allb = torch.empty(world * blk.numel(), dtype=torch.uint8)
+    dist.all_gather_into_tensor(allb, blk)                    # the packed per-shard top-k block of one step
+    assert allb.view(world, -1)[:, 0].tolist() == list(range(world))
+    dist.barrier()
+    if rank == 0:
+        line = {"rehearsal": "launch + host collectives only, no device, no search", "n_ranks": world, "backend": "gloo",
+                "launched_by": os.environ.get("TS_BENCH_LAUNCHED_BY", "env"), "rendezvous": "file" if os.environ.get("TS_BENCH_INIT_FILE") else "env",
+                "omp_num_threads": os.environ.get("OMP_NUM_THREADS"), "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                "truth_table_bytes_per_rank": int(sum(a.nbytes for a in table[:3])), "packed_block_bytes": int(blk.numel()),
+                "seconds": round(time.perf_counter() - t0, 3)}
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+    dist.destroy_process_group()
 
 
 def run_c1(args, real_stdout):
@@ -369,6 +442,14 @@ def main():
     ap.add_argument("--tune-gemms", action="store_true",
                     help="c5: let PyTorch's TunableOp pick the fastest hipBLASLt / rocBLAS solution for each of the encoder's "
                          "four GEMM shapes during the warm-up (seconds of tuning per shape)")
+    ap.add_argument("--encoder-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="c5: the arithmetic of the encoder forward.  fp32 (default) is what the reference runs "
+                         "(SentenceTransformer(name) without a dtype: streamlit_app.py:55,173, app_create_embeddings.py:22,81) and what "
+                         "SentenceEncoder does for a real checkpoint; bf16 is the opt-in half-precision forward (its embeddings differ "
+                         "from the fp32 ones by the tolerance DESIGN.md section 8 states)")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="N > 1: exercise only the launch + host-collective plumbing of an N-rank run over gloo, no device, no "
+                         "search (rehearse_launch); prints what was exercised, not a benchmark line")
     ap.add_argument("--zero-queries", action="store_true", help="diagnostic: all-zero queries (power probe)")
     ap.add_argument("--zero-corpus", action="store_true", help="diagnostic: all-zero corpus (power probe)")
     args = ap.parse_args()
@@ -376,7 +457,9 @@ def main():
     D = args.dim or (1024 if (args.workload == "c3q" or (args.workload == "c5" and args.encoder == "qwen")) else 768)
     if args.workload != "c1" and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher around this process: start the ranks as child processes (before torch is imported or HIP touched)
-        return launch_ranks(args.gpus, args.share_gpu)
+        return launch_ranks(args.gpus)
+    if os.environ.get("TS_BENCH_LAUNCHED_BY") == "bench.py":
+        rank_dies_with_parent()
     # Exactly ONE line goes to stdout (the JSON): libraries print banners there (RCCL prints its version / host /
     # library path on communicator creation), so fd 1 points at stderr until the result line is written.
     sys.stdout.flush()
@@ -385,6 +468,8 @@ def main():
 
     if args.workload == "c1":
         return run_c1(args, real_stdout)
+    if args.rehearse_launch:
+        return rehearse_launch(args, real_stdout)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -410,12 +495,10 @@ def main():
                          f"--share-gpu rehearses several ranks on one GPU")
     torch.cuda.set_device(local_rank)
     if world > 1 or args.force_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
         if args.share_gpu:
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            init_process_group(dist, "gloo", rank, world)
         else:
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            init_process_group(dist, "nccl", rank, world, device_id=torch.device("cuda", local_rank))
 
     rows_total, dtype, nq = WORKLOADS[args.workload]
     if args.rows:
@@ -490,10 +573,11 @@ def main():
             tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"ts_tunableop_rank{rank}.csv"))
         enc_name = {"qwen": "Qwen/Qwen3-Embedding-0.6B", "gemma": "google/embeddinggemma-300m"}.get(
             args.encoder, "math-similarity/Bert-MLM_arXiv-MP-class_zbMath")
-        encoder = SentenceEncoder(enc_name, allow_random_init=True)
+        enc_dtype = torch.float32 if args.encoder_dtype == "fp32" else torch.bfloat16
+        encoder = SentenceEncoder(enc_name, allow_random_init=True, dtype=enc_dtype)
         if encoder.embedding_dim != D:
             raise SystemExit(f"the {args.encoder} encoder embeds into {encoder.embedding_dim} dimensions, the index has {D}")
-        log(rank, f"encoder: {type(encoder.model).__name__} ({enc_name}, random init), fused forward: {type(encoder._fused).__name__}")
+        log(rank, f"encoder: {type(encoder.model).__name__} ({enc_name}, random init, {args.encoder_dtype} forward), fused forward: {type(encoder._fused).__name__}")
         g = torch.Generator(device="cpu").manual_seed(5678)
         tok_ids = torch.randint(1000, 30000, (nq, args.seq_len), generator=g).cuda()
         tok_ids[:, 0], tok_ids[:, -1] = 101, 102
@@ -570,19 +654,25 @@ def main():
     # Where the exchange of a step runs.  On a side stream it overlaps the next step's search - but the full pass of that
     # search wants every CU (one workgroup per CU, all registers), and a collective's kernel that sits on a CU waiting for a
     # slower rank holds the pass's last workgroup back; on the search's own stream it costs its latency every step and
-    # nothing else.  Which is faster depends on the fabric and on how evenly the ranks run: with more than one rank both are
-    # tried (two rounds of `trial` steps each, interleaved, behind a warm-up; the time of a round is the slowest rank's) and
-    # the faster one is used.  One rank has no collective: overlap.
+    # nothing else.  Which is faster depends on the fabric and on how evenly the ranks run, so with more than one rank both
+    # are tried.  The trial must not decide on noise (RCCL sets its connections up lazily during the first exchanges, and the
+    # clock needs a second under load): a warm-up of >= 50 exchanges in each mode, then `rounds` rounds of `trial` steps per
+    # mode in alternating order, the first round of each mode discarded, MEDIANS compared, and `overlap` - the placement the
+    # design argues for - is kept unless `inline` wins by more than 2 %.  The time of a round is the slowest rank's.
+    # One rank has no collective: overlap.
     overlap = [args.exchange_placement != "inline"]
     placement_trial = None
     if searcher is not None and world > 1 and args.exchange_placement == "auto":
-        trial = 40
+        trial, rounds, warm = (10, 3, 5) if args.share_gpu else (200, 4, 60)      # gloo through host memory: a token trial
         times = {True: [], False: []}
-        for _ in range(trial):
-            step()
+        for mode in (True, False):
+            overlap[0] = mode
+            for _ in range(warm):
+                step()
+            torch.cuda.synchronize()
         barrier()
-        for rnd in range(2):
-            for mode in (True, False):
+        for rnd in range(rounds):
+            for mode in ((True, False) if rnd % 2 == 0 else (False, True)):
                 overlap[0] = mode
                 barrier()
                 tt = time.perf_counter()
@@ -593,9 +683,12 @@ def main():
                 t_ = torch.tensor([time.perf_counter() - tt], dtype=torch.float64, device="cuda")
                 dist.all_reduce(t_, op=dist.ReduceOp.MAX)
                 times[mode].append(float(t_.item()) / trial * 1e3)
-        overlap[0] = min(times[True]) <= min(times[False])
+        med = {m_: float(np.median(times[m_][1:])) for m_ in (True, False)}
+        overlap[0] = not (med[False] < 0.98 * med[True])
         placement_trial = {"overlap_ms_per_step": [round(x, 4) for x in times[True]], "inline_ms_per_step": [round(x, 4) for x in times[False]],
-                           "steps_per_round": trial}
+                           "steps_per_round": trial, "rounds": rounds, "rounds_discarded": 1, "warmup_exchanges_per_mode": warm,
+                           "median_overlap_ms": round(med[True], 4), "median_inline_ms": round(med[False], 4),
+                           "rule": "overlap unless the median of inline is more than 2 % below the median of overlap"}
         log(rank, f"exchange placement: {'overlap' if overlap[0] else 'inline'} ({placement_trial})")
 
     if encoder is not None and args.encoder_graph:
@@ -639,10 +732,25 @@ def main():
     # contract's K steps - 63 ms at the default; a second of back-to-back passes lets the clock settle) -----------------
     sustained, power = None, None
     sustained_steps = args.sustained_steps if (args.sustained_steps > 0 or bracket_timed) else max(20, args.steps)
+
+    def read_brackets():
+        sp_ = {"launches": 0, "total_ms": 0.0, "rows_per_launch": 0}
+        for h in prof_handles:
+            p_ = h.profile_read()
+            h.profile_enable(False)
+            sp_["launches"] += p_["launches"]
+            sp_["total_ms"] += p_["total_ms"]
+            sp_["rows_per_launch"] = max(sp_["rows_per_launch"], p_["rows_per_launch"])
+        return sp_
+
     if sustained_steps > 0 and args.workload != "c1":
         barrier()
+        # the sustained leg runs as the timed region does: with the brackets on one rank, bare on a sharded run (whose kernel
+        # time comes from a third, bracketed leg right behind; round 4 bracketed the sustained leg itself, and its step read
+        # 68 us above the timed region's at 1.25M rows per rank: each bracket is a barrier packet with a timestamp write
+        # between two kernels that otherwise dispatch back to back)
         for h in prof_handles:
-            h.profile_enable(True)
+            h.profile_enable(bracket_timed)
         try:
             props = torch.cuda.get_device_properties(local_rank)
             bus = f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
@@ -664,22 +772,29 @@ def main():
         barrier()
         dt_s = time.perf_counter() - t1
         power = sampler.summary(tw0, tw1) if sampler is not None else None
-        sp = {"launches": 0, "total_ms": 0.0, "rows_per_launch": 0}
-        for h in prof_handles:
-            p_ = h.profile_read()
-            h.profile_enable(False)
-            sp["launches"] += p_["launches"]
-            sp["total_ms"] += p_["total_ms"]
-            sp["rows_per_launch"] = max(sp["rows_per_launch"], p_["rows_per_launch"])
-        if not bracket_timed:
-            prof = dict(sp, steps=sustained_steps)
+        sp = read_brackets()
         if world > 1:
             t = torch.tensor([dt_s], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt_s = float(t.item())
         sustained = {"steps": sustained_steps, "queries_per_s": round(nq * sustained_steps / dt_s, 1),
-                     "ms_per_step": round(dt_s / sustained_steps * 1e3, 4), "kernel_brackets": True,
-                     "kernel_ms": round(sp["total_ms"] / max(1, sp["launches"]), 4), "seconds": round(dt_s, 3)}
+                     "ms_per_step": round(dt_s / sustained_steps * 1e3, 4), "kernel_brackets": bracket_timed,
+                     "kernel_ms": round(sp["total_ms"] / max(1, sp["launches"]), 4) if bracket_timed else None,
+                     "seconds": round(dt_s, 3)}
+        if not bracket_timed:
+            nb = min(sustained_steps, 100)
+            for h in prof_handles:
+                h.profile_enable(True)
+            t2 = time.perf_counter()
+            for _ in range(nb):
+                step()
+            torch.cuda.synchronize()
+            dt_b = time.perf_counter() - t2
+            barrier()
+            prof = dict(read_brackets(), steps=nb)
+            sustained["bracket_leg"] = {"steps": nb, "ms_per_step": round(dt_b / nb * 1e3, 4),
+                                        "kernel_ms": round(prof["total_ms"] / max(1, prof["launches"]), 4),
+                                        "note": "this rank's own clock; the two marker packets per step are what this leg's step has over the sustained leg's"}
 
     # ---- the exchange as the communicator saw it (N > 1): backend, world, one device per rank, and what ONE all-gather of
     # the packed per-shard top-k costs on the side stream (outside the timed region; every rank takes part) ----------------
@@ -765,7 +880,7 @@ def main():
                 "traffic": traffic,
                 "kernel_ms": round(kern_ms, 4), "launches_per_step": launches_per_step,
                 "kernel_ms_from": "hipEvent brackets over the timed region" if bracket_timed else
-                                  "hipEvent brackets over the sustained leg right behind the timed region (which runs without them)",
+                                  "hipEvent brackets over a separate leg of <= 100 steps behind the timed region and the sustained leg (which both run without them)",
                 "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_flops_per_launch": alg_flops}
 
     # ---- recall@10 of EVERY query against the oracle (fp64 scores of the same bf16/fp32 values; oracle.ChunkedTruth
@@ -851,11 +966,35 @@ def main():
             # the oracle's port of the reference formulation: util.cos_sim + np.argsort(-S)[:, :10], all host cores
             _, t_cpu = oracle.cpu_reference_topk(q_s, c_s, K, threads=ncpu)
             how = f"all {nq} queries in one call (host memory did not allow the whole corpus: MemAvailable {mem_avail >> 30} GiB)"
+        t_enc, enc_how = 0.0, ""
+        if encoder is not None:
+            # configs[4]: the reference's host path starts with model.encode (streamlit_app.py:173, app_showcase_model.py:92) -
+            # the same stand-in (same seed, same weights) in fp32 on the host cores, forward + pooling + normalisation of the
+            # very queries whose search was timed above; one untimed call on two queries first (thread pool, primitive caches)
+            from theoremsearch_amd.encoder import SentenceEncoder
+            host_enc = SentenceEncoder(enc_name, device="cpu", dtype=torch.float32, allow_random_init=True)
+            torch.set_num_threads(ncpu)
+            ids_h, mask_h = tok_ids[:nq_timed].cpu(), tok_mask[:nq_timed].cpu()
+            with torch.inference_mode():
+                host_enc.pool(host_enc.forward_hidden(ids_h[:2], mask_h[:2]), mask_h[:2], True)
+                te = time.perf_counter()
+                emb_h = host_enc.pool(host_enc.forward_hidden(ids_h, mask_h), mask_h, True)
+                t_enc = time.perf_counter() - te
+            # the host's fp32 embeddings against the device's (the fused forward at --encoder-dtype): cosine per query
+            e_dev = oracle.bf16_bits_to_f32(q_host[:nq_timed]) if bf16 else q_host[:nq_timed]
+            cosines = np.sum(emb_h.numpy() * e_dev, axis=1) / np.maximum(np.linalg.norm(e_dev, axis=1), 1e-12)
+            enc_how = (f"; host model.encode of the same {nq_timed} x {args.seq_len}-token queries (same random-init weights, fp32, "
+                       f"{ncpu} threads): {t_enc:.2f}s, included; cosine of the device's embeddings ({args.encoder_dtype} forward) "
+                       f"with the host's fp32 ones: min {float(cosines.min()):.6f}")
+            del host_enc
+            t_cpu += t_enc
         cpu = {"value": round(nq_timed / t_cpu, 3), "unit": "queries/s", "cores": ncpu, "kind": "port",
                "rows": int(c_s.shape[0]), "queries": int(nq_timed),
                "sample": f"MEASURED on {c_s.shape[0]} rows (of the workload's {rows_total}), {how}: fp32 torch-CPU "
                          f"cos_sim (F.normalize both sides + mm) + np.argsort(-S)[:, :10] in {t_cpu:.2f}s on {ncpu} host cores; "
-                         f"nothing scaled"}
+                         f"nothing scaled{enc_how}"}
+        if encoder is not None:
+            cpu["encode_seconds"] = round(t_enc, 3)
         del c_s
 
     if rank == 0:
@@ -866,8 +1005,11 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"{rows_total}x{D} {dtype} corpus, batch-{nq} queries, top-{K} "
                                    + (f"(BASELINE.json configs[{ {'c1': 0, 'c2': 1, 'c2b': 1, 'c3': 2, 'c4': 3, 'c5': 4}[args.workload] }])" if args.workload != "c3q" else
-                                      "(the reference's production table shape, theorem_embedding_qwen vector(1024): streamlit_app.py:49, rds_schema.sql:50-56; not a BASELINE.json config)") + (f", encoder forward in the loop ({args.seq_len} tokens/query, random-init " + ("Qwen3-Embedding-0.6B shape: the production embedder, streamlit_app.py:55)" if args.encoder == "qwen" else "embeddinggemma-300m shape: the reference's second embedder, embedders.py:1-4)" if args.encoder == "gemma" else "BERT-base shape)") if encoder is not None else ""),
+                                      "(the reference's production table shape, theorem_embedding_qwen vector(1024): streamlit_app.py:49, rds_schema.sql:50-56; not a BASELINE.json config)") + (f", {args.encoder_dtype} encoder forward in the loop ({args.seq_len} tokens/query, random-init " + ("Qwen3-Embedding-0.6B shape: the production embedder, streamlit_app.py:55)" if args.encoder == "qwen" else "embeddinggemma-300m shape: the reference's second embedder, embedders.py:1-4)" if args.encoder == "gemma" else "BERT-base shape)") if encoder is not None else ""),
                        "rows": rows_total, "dim": D, "batch": nq, "k": K, "searches_in_flight": P,
+                       **({"encoder": args.encoder, "encoder_dtype": args.encoder_dtype, "seq_len": args.seq_len,
+                           "encoder_forward": type(encoder._fused).__name__ if encoder._fused is not None else "the model's own"}
+                          if encoder is not None else {}),
                        **({"mask_frac": args.mask_frac} if args.mask_frac > 0 else {}),
                        "parallelism": f"corpus row-sharded x{world}" + ((", gloo rehearsal on one GPU" if args.share_gpu else (", ncclAllGather of per-shard top-k inside libtsearch (ts_comm)" if searcher.exchange == "native" else ", torch.distributed all-gather of per-shard top-k (RCCL)")) if use_dist else "")},
             "recall_at_10": recall,

@@ -107,6 +107,11 @@ int ts_index_stream(const ts_index *ix, void **stream);
  * call ran on (stream-ordered, no host wait): a side stream that consumes a search's device results - the exchange + merge
  * of the sharded search - needs no event of its own on the search's stream. */
 int ts_index_wait_order(ts_index *ix, void *stream);
+/* Device-to-device copy of `bytes` bytes on `device`, enqueued on `stream` (hipStream_t as void*; NULL = the legacy null
+ * stream): lets a Python caller that only holds raw device addresses stage a query batch in a buffer of its own before a
+ * search on another stream reads it (ShardedSearcher with several searches in flight: the caller's stream then waits for
+ * this copy, not for the whole search). */
+int ts_copy_device(int device, void *dst, const void *src, int64_t bytes, void *stream);
 /* Waits until everything this handle has enqueued (on its own stream and on the stream of its last call) is done. */
 int ts_index_synchronize(ts_index *ix);
 int ts_index_info(const ts_index *ix, int64_t *n, int32_t *d, int32_t *dtype, int32_t *metric,

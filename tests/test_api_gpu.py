@@ -286,6 +286,45 @@ def test_sharded_pipeline_reads_a_query_buffer_that_the_caller_rewrites_every_st
         searcher.close()
 
 
+def test_two_searches_in_flight_release_the_callers_stream_at_the_query_copy(ts):
+    """pipeline = 2: a search runs on a lane stream of its own and reads a copy of the query batch that the lane took first, so
+    the caller's stream is held until that COPY is done - not until the search is (which would serialise the lanes: search
+    i + 1 could not start before search i had finished, and an encoder forward for batch i + 1 could not overlap search i).
+    Timing events: one on the caller's stream right behind each call, one on the lane right behind its search; the caller's
+    must come first, by most of the search's duration."""
+    import torch
+    from theoremsearch_amd.distributed import ShardedSearcher
+    n, nq, k = 2_000_000, 256, 10
+    _, c = oracle.inputs(n, 1, 768, 23, "ip")
+    q = oracle.f32_to_bf16_bits(np.random.default_rng(7).standard_normal((nq, 768)).astype(np.float32))
+    with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as ix:
+        want = ix.search(q, k)
+        searcher = ShardedSearcher(index=ix, pipeline=2)
+        qd = torch.from_numpy(q.view(np.int16)).cuda()
+        main = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        for _ in range(4):                                   # warm: lanes, views, buffers exist
+            searcher.search_device(qd.data_ptr(), "bf16", nq, k, stream=main)
+        torch.cuda.synchronize()
+        after_call, after_search, outs = [], [], []
+        for step in range(6):
+            lane = searcher._lanes[searcher._step % 2][1]   # the lane this call will use
+            outs.append(searcher.search_device(qd.data_ptr(), "bf16", nq, k, stream=main))
+            e_main, e_lane = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e_main.record(main)
+            e_lane.record(lane)
+            after_call.append(e_main)
+            after_search.append(e_lane)
+        torch.cuda.synchronize()
+        ahead = [after_call[i].elapsed_time(after_search[i]) for i in range(6)]     # ms the caller's stream is ahead of the search's end
+        whole = after_search[0].elapsed_time(after_search[5]) / 5.0                  # ms per search, steady state
+        assert min(ahead) > 0.5 * whole, f"the caller's stream waited for the search: ahead {ahead} ms, a search takes {whole:.3f} ms"
+        for s_, i_, done in outs:
+            done.synchronize()
+            assert np.array_equal(i_.cpu().numpy(), want[1]) and np.array_equal(s_.cpu().numpy(), want[0])
+        searcher.close()
+
+
 def test_answers_do_not_move_with_the_tile_shares_of_the_full_pass(ts):
     """The full pass takes each workgroup's tile range from a table that the final select moves after every search
     (towards equal finishing times of the XCDs).  Same queries, ten searches in a row: the table moves, the answers may

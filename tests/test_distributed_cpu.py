@@ -113,3 +113,33 @@ def test_sharded_rank_of_two_gloo_ranks():
     ret = mgr.dict()
     mp.spawn(_rank_worker, args=(world, _free_port(), 501, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+def test_bench_launches_eight_ranks_and_runs_its_host_collectives():
+    """`python bench.py --gpus 8 --rehearse-launch`, bare, as the driver starts the 8-GPU run: the parent starts EIGHT rank
+    processes (file rendezvous, one relay thread each, OMP_NUM_THREADS = cores / 8), the ranks meet over gloo and run the
+    host collectives of a sharded run - barriers, the max-over-ranks reductions, all_gather_object of truth tables of the
+    real shape, one all-gather of the packed per-shard top-k block - and rank 0's single JSON line comes back through the
+    parent.  No device and no search (a one-GPU box may hold six processes on its card; tests/test_mirrors_gpu.py rehearses four
+    ranks through the kernels).  Then a rank that fails: non-zero exit code, no line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                            "HSA_ENABLE_IPC_MODE_LEGACY", "OMP_NUM_THREADS", "TS_BENCH_INIT_FILE")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--rehearse-launch"], capture_output=True,
+                         text=True, timeout=280, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    doc = json.loads(lines[0])
+    assert doc["n_ranks"] == 8 and doc["backend"] == "gloo" and doc["launched_by"] == "bench.py" and doc["rendezvous"] == "file"
+    assert doc["hsa_enable_ipc_mode_legacy"] == "0"              # set for the ranks even from an environment without it
+    assert int(doc["omp_num_threads"]) == max(1, len(os.sched_getaffinity(0)) // 8)
+    assert doc["packed_block_bytes"] == 256 * 10 * 12 and doc["truth_table_bytes_per_rank"] > 0
+    # the real run without a device: every rank refuses, the parent relays no line and a non-zero exit code
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rows", "1000", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=280, cwd=root, env=env)
+    if not __import__("conftest").gpu_available():
+        assert bad.returncode != 0 and not bad.stdout.strip(), (bad.returncode, bad.stdout)

@@ -6,6 +6,10 @@ sets, scores within 1e-5 of the fp64 truth of the same operands):
   configs[4]  encoder-in-loop over that same 10M index: encoder forward + fused pooling on the device, embeddings handed
               to the search by device pointer, all 256 answers checked
   configs[1]  1M x 768 fp32, one query, top-10                 (the streaming scan)
+  configs[3]  50M x 768 bf16 row-sharded 8 ways (ts_shards_*: routed uploads, eight searches, packed per-shard top-10,
+              merge), 256 queries: bit-identical to ONE index over the same 50M rows, and checked against the committed
+              fp64 truth of the 50M-row corpus.  A one-GPU box holds all eight shards on device 0 (288 GB of HBM: the
+              shards and the whole index together are 154 GB); the exchange is then device copies instead of RCCL
 
 plus a fixed-seed slice of the randomised sweep of tests/stress_parity.py, small and --big (1M-2.5M rows, clusters,
 masks, k up to 256).  The fp64 truth is accumulated chunk by chunk on the host (oracle.ChunkedTruth) from the same
@@ -44,9 +48,11 @@ def _threads():
     return max(1, min(16, len(os.sched_getaffinity(0))))
 
 
-def build_index(ts, rows_total, dtype, keep_rows=False):
+def build_index(ts, rows_total, dtype, keep_rows=False, digests=None, also=None):
     """Corpus of bench.py (chunks of synthetic.synth_chunk, stored as given: metric ip on unit rows).  ``keep_rows``: also
-    return the chunks' host arrays (the truth pass then does not generate them a second time)."""
+    return the chunks' host arrays (the truth pass then does not generate them a second time).  ``digests``: a dict that
+    receives the SHA-256 of every chunk as generated here (what a committed truth fixture is matched against).  ``also``:
+    a second receiver of every chunk with an ``upload(rows, row0)`` method (the row-sharded form of the same corpus)."""
     import synthetic
     bf16 = dtype == "bf16"
     ch = synthetic.CHUNK_ROWS
@@ -58,6 +64,10 @@ def build_index(ts, rows_total, dtype, keep_rows=False):
         data = synthetic.synth_chunk(c, ch, D, bf16=bf16)
         hi = min(rows_total, (c + 1) * ch)
         ix.upload(data[: hi - c * ch], c * ch)
+        if also is not None:
+            also.upload(data[: hi - c * ch], c * ch)
+        if digests is not None:
+            digests[c] = _digest(data[: hi - c * ch])
         if keep_rows:
             kept[c] = data[: hi - c * ch]
         return c
@@ -96,22 +106,24 @@ def _digest(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def cached_truth_check(q_bits, idx, scores, k, kept):
-    """The committed fp64 truth of configs[2] (tests/golden/fullsize_c3_truth.npz, oracle/gen_fullsize_truth.py: the k + 64
-    best rows of each benchmark query over the 10M x 768 bf16 corpus) in place of a pass over the corpus - after the
-    digests of the queries and of three corpus chunks have been matched against the rows generated HERE.  Returns None
-    when the file does not describe this box's inputs (the caller then computes the truth itself).  The fp64 score of a
-    returned row comes from the cached list, or - a row outside the k + 64 best - from the row itself."""
-    import synthetic
-    z = np.load(os.path.join(ROOT, "tests", "golden", "fullsize_c3_truth.npz"))
+def cached_truth_check(fixture, q_bits, idx, scores, k, digests, row_values):
+    """A committed fp64 truth (tests/golden/fullsize_c3_truth.npz / fullsize_c4_truth.npz, oracle/gen_fullsize_truth.py: the
+    k + 64 best rows of each benchmark query over the 10M / 50M x 768 bf16 corpus) in place of a pass over the corpus -
+    after the digests of the queries and of EVERY corpus chunk have been matched against the rows generated HERE
+    (``digests``: chunk id -> SHA-256, filled by `build_index`).  Returns None when the file does not describe this box's
+    inputs (the caller then computes the truth itself).  The fp64 score of a returned row comes from the cached list, or -
+    a row outside the k + 64 best - from the row itself (``row_values(r)``: its bf16 bits)."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", fixture))
     if int(z["k"]) != k or str(z["query_digest"]) != _digest(q_bits):
         return None
-    for c, want in zip(z["chunk_ids"].tolist(), z["chunk_digests"].tolist()):
-        if _digest(kept[int(c)]) != str(want):
+    ids, want = z["chunk_ids"].tolist(), z["chunk_digests"].tolist()
+    if len(ids) != len(digests):
+        return None
+    for c, w in zip(ids, want):
+        if digests.get(int(c)) != str(w):
             return None
     t = oracle.ChunkedTruth(oracle.bf16_bits_to_f32(q_bits), idx, k)
     t.best_s, t.best_i, t.n = z["best_s"], z["best_i"], int(z["n"])
-    ch = synthetic.CHUNK_ROWS
     for b in range(idx.shape[0]):
         known = {int(j): float(v) for j, v in zip(t.best_i[b], t.best_s[b])}
         for j in range(idx.shape[1]):
@@ -119,7 +131,7 @@ def cached_truth_check(q_bits, idx, scores, k, kept):
             if r in known:
                 t.got_s[b, j] = known[r]
             elif 0 <= r < t.n:
-                row = oracle.bf16_bits_to_f32(kept[r // ch][r % ch]).astype(np.float64)
+                row = oracle.bf16_bits_to_f32(row_values(r)).astype(np.float64)
                 t.got_s[b, j] = float(t.q64[b] @ row)
     return t.check(scores, gap=1e-6, score_tol=1e-5)
 
@@ -153,7 +165,8 @@ def test_config2_10m_bf16_batch256_every_query(ts):
     import synthetic
     rows_total, nq = 10_000_000, 256
     t0 = time.time()
-    ix, chunks, kept = build_index(ts, rows_total, "bf16", keep_rows=True)
+    digests = {}
+    ix, chunks, kept = build_index(ts, rows_total, "bf16", keep_rows=True, digests=digests)
     q = synthetic.synth_queries(0, nq, D, bf16=True)
     t1 = time.time()
     try:
@@ -176,7 +189,8 @@ def test_config2_10m_bf16_batch256_every_query(ts):
     t2 = time.time()
     # the benchmark's own queries: the committed fp64 truth when it describes the rows generated here; the encoder's
     # embeddings are this run's own: one pass over the kept rows
-    stats = cached_truth_check(q, idx, scores, K, kept)
+    ch = synthetic.CHUNK_ROWS
+    stats = cached_truth_check("fullsize_c3_truth.npz", q, idx, scores, K, digests, lambda r: kept[r // ch][r % ch])
     answers = [(enc_q, enc_idx, enc_scores)] + ([] if stats is not None else [(q, idx, scores)])
     checked = chunked_truth_check_many("bf16", rows_total, chunks, answers, K, kept=kept)
     enc_stats = checked[0]
@@ -188,6 +202,56 @@ def test_config2_10m_bf16_batch256_every_query(ts):
     assert stats["recall"] == 1.0 and stats["positions"] == nq * K
     assert stats["pinned"] >= 0.99 * stats["positions"]
     assert enc_stats["recall"] == 1.0 and enc_stats["positions"] == nq * K
+
+
+@pytest.mark.timeout(1500)
+def test_config3_50m_8_shards(ts):
+    """BASELINE.json configs[3] at its size: 50M x 768 bf16 rows, row-sharded 8 ways behind ts_shards_* (one
+    process, one shard and one stream per device, packed per-shard top-k, one exchange, merge), 256 queries, top-10.  The
+    reference's only multi-device call is encode_multi_process (ec2/generate_embeddings/embeddings.py:32); its search is one
+    sequential scan (streamlit_app.py:253-283), so the sharded answer must be THE answer of the whole corpus:
+      * bit-identical (ids and scores) to one TheoremIndex over the same 50M rows,
+      * every query through the oracle's protocol against the committed fp64 truth of the 50M-row corpus
+        (tests/golden/fullsize_c4_truth.npz, trusted after the SHA-256 of every one of the 200 chunks generated here matches),
+      * every shard contributes (the global top-10 of 256 queries over random rows draw from all eight row ranges).
+    One GPU holds the eight shards (76.8 GB) beside the whole index (76.8 GB); the exchange is device copies there and
+    ncclAllGather on eight devices - the searches, the packed blocks and the merge are the same code."""
+    import synthetic
+    from theoremsearch_amd.distributed import Shards
+    rows_total, nq, G = 50_000_000, 256, 8
+    ch = synthetic.CHUNK_ROWS
+    t0 = time.time()
+    digests = {}
+    sh = Shards(rows_total, D, G, dtype="bf16", metric="ip", devices=[0] * G)
+    whole = None
+    try:
+        assert [sh.bounds(g) for g in range(G)] == [(rows_total * g // G, rows_total * (g + 1) // G) for g in range(G)]
+        whole, chunks = build_index(ts, rows_total, "bf16", digests=digests, also=sh)
+        t1 = time.time()
+        q = synthetic.synth_queries(0, nq, D, bf16=True)
+        scores, idx = sh.search(q, K)
+        s2, i2 = sh.search(q, K)                                   # deterministic
+        assert np.array_equal(idx, i2) and np.array_equal(scores, s2)
+        want_s, want_i, st = whole.search(q, K, algo="auto", return_stats=True)
+        assert st["algo"] == 2 and st["fallback_queries"] == 0, st
+    finally:
+        sh.close()
+        if whole is not None:
+            whole.close()
+    t2 = time.time()
+    assert np.array_equal(idx, want_i), "the sharded search and the one-index search disagree on ids"
+    assert np.array_equal(scores, want_s), "the sharded search and the one-index search disagree on score bits"
+    owners = np.unique(idx // (rows_total // G))
+    assert owners.tolist() == list(range(G)), f"shards that contributed to the answers: {owners}"
+    stats = cached_truth_check("fullsize_c4_truth.npz", q, idx, scores, K, digests,
+                               lambda r: synthetic.synth_chunk(r // ch, ch, D, bf16=True)[r % ch])
+    cached = stats is not None
+    if not cached:                                                 # another generator stream on this box: the truth computed here
+        stats = chunked_truth_check(q, "bf16", rows_total, chunks, idx, scores, K)
+    print(f"[fullsize c4] build {t1 - t0:.0f}s, searches {t2 - t1:.0f}s, truth {time.time() - t2:.0f}s "
+          f"({'committed fixture' if cached else 'computed here'}), {stats}")
+    assert stats["recall"] == 1.0 and stats["positions"] == nq * K
+    assert stats["pinned"] >= 0.99 * stats["positions"]
 
 
 @pytest.mark.timeout(600)

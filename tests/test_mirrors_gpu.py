@@ -686,25 +686,36 @@ def test_bench_under_torch_distributed_run_with_two_ranks_sharing_the_gpu():
 
 
 def test_bench_starts_its_own_ranks_when_no_launcher_is_around():
-    """`python bench.py --gpus 2` bare (no torch.distributed.run around it, WORLD_SIZE unset): the process starts the two
-    ranks as child processes itself, relays rank 0's single JSON line and its exit code; the line names what the
-    communicator saw (backend, world, one device per rank) and what one all-gather of the packed top-k costs."""
+    """`python bench.py --gpus 4` bare (no torch.distributed.run around it, WORLD_SIZE unset), the command shape the driver
+    uses for its 2 / 4 / 8-GPU runs: the process starts the ranks as child processes itself, relays rank 0's single JSON line
+    and its exit code; the line names what the communicator saw (backend, world, one device per rank), what one all-gather of
+    the packed top-k costs, and every round of the exchange-placement trial.  FOUR ranks share the box's GPU here: with this
+    test's own process that is five on the card, and a box allows six - the eight-rank launch is rehearsed without a device in
+    tests/test_distributed_cpu.py (`--rehearse-launch`)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--rows", "600000", "--nq", "64",
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--share-gpu", "--rows", "800000", "--nq", "64",
            "--steps", "3", "--warmup", "1", "--sustained-steps", "4"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=root, env=env)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, out.stdout
     doc = json.loads(lines[0])
-    assert doc["n_gpus"] == 2 and doc["steps"] == 3 and doc["recall_at_10"] == 1.0 and doc["parity"]["violations"] == 0
+    assert doc["n_gpus"] == 4 and doc["steps"] == 3 and doc["recall_at_10"] == 1.0 and doc["parity"]["violations"] == 0
+    assert doc["parity"]["queries_checked"] == 64 and doc["config"]["rows"] == 800000 and "x4" in doc["config"]["parallelism"]
     ex = doc["exchange"]
-    assert ex["world"] == 2 and ex["backend"] == "gloo" and ex["native"] is False and ex["launched_by"] == "bench.py"
-    assert ex["allgather_us"] > 0 and len(ex["devices"]) == 2 and sorted(d_[0] for d_ in ex["devices"]) == [0, 1]
-    assert ex["distinct_gpus"] == 1                      # the rehearsal: both ranks on the box's one GPU
+    assert ex["world"] == 4 and ex["backend"] == "gloo" and ex["native"] is False and ex["launched_by"] == "bench.py"
+    assert ex["allgather_us"] > 0 and len(ex["devices"]) == 4 and sorted(d_[0] for d_ in ex["devices"]) == [0, 1, 2, 3]
+    assert ex["distinct_gpus"] == 1                      # the rehearsal: every rank on the box's one GPU
+    trial = ex["placement_trial"]
+    assert trial["rounds"] >= 3 and trial["rounds_discarded"] == 1
+    assert len(trial["overlap_ms_per_step"]) == trial["rounds"] == len(trial["inline_ms_per_step"])
+    assert ex["placement"].startswith("overlap") == (not trial["median_inline_ms"] < 0.98 * trial["median_overlap_ms"])
+    # a sharded run times bare and takes its kernel time from a bracketed leg of its own
+    assert doc["sustained"]["kernel_brackets"] is False and doc["sustained"]["bracket_leg"]["kernel_ms"] > 0
+    assert doc["roofline"]["kernel_ms"] == doc["sustained"]["bracket_leg"]["kernel_ms"]
     # a rank that fails takes the job down with a non-zero exit code and no JSON line
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rows", "600000", "--nq", "64", "--steps", "1",
                           "--warmup", "0"], capture_output=True, text=True, timeout=300, cwd=root, env=env)

@@ -47,6 +47,7 @@ _SIGNATURES = {
     "ts_index_set_row_offset": (C.c_int, [C.c_void_p, C.c_int64]),
     "ts_index_synchronize": (C.c_int, [C.c_void_p]),
     "ts_index_wait_order": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ts_copy_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "ts_index_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "ts_index_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                 C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64),

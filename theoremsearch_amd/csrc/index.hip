@@ -230,6 +230,15 @@ extern "C" int ts_index_wait_order(ts_index* ix, void* stream) {
     return TS_OK;
 }
 
+extern "C" int ts_copy_device(int device, void* dst, const void* src, int64_t bytes, void* stream) {
+    if (bytes < 0 || ((!dst || !src) && bytes > 0)) return fail(TS_ERR_INVALID, "bad argument");
+    if (bytes == 0) return TS_OK;
+    TS_TRY(check_device(device));
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return TS_OK;
+}
+
 extern "C" int ts_index_stream(const ts_index* ix, void** stream) {
     if (!ix || !stream) return fail(TS_ERR_INVALID, "NULL argument");
     *stream = (void*)ix->stream;

@@ -202,6 +202,8 @@ class ShardedSearcher:
                 "fin_s": [torch.empty((nq, k), dtype=torch.float32, device=dev) for _ in range(nb)],
                 "fin_i": [torch.empty((nq, k), dtype=torch.int64, device=dev) for _ in range(nb)],
                 "ready": [torch.cuda.Event() for _ in range(nb)],
+                "qread": [torch.cuda.Event() for _ in range(nb)],
+                "qstage": [None] * nb,                            # pipeline > 1: the lane's own copy of the query batch
                 "done": [torch.cuda.Event() for _ in range(nb)],
                 "used": [False] * nb,
             }
@@ -230,8 +232,9 @@ class ShardedSearcher:
         side stream, so that they overlap the next call's search (``overlap=False``: everything on ``stream``).  Returns
         ``(scores, idx, done)``: merged global results as device tensors ``[nq x k]`` (four blocks in rotation: valid
         until the fourth-next call) and the ``torch.cuda.Event`` that marks them complete.  The query buffer may be
-        rewritten by work enqueued on ``stream`` after this call returns (with ``pipeline`` > 1 the caller's stream is made
-        to wait for the lane's read of it); work on OTHER streams must wait for ``done``.
+        rewritten by work enqueued on ``stream`` after this call returns (with ``pipeline`` > 1 the lane copies the batch into
+        a buffer of its own first and the caller's stream waits for that copy, not for the search); work on OTHER streams
+        must wait for ``done``.
         Marker packets cost the search's stream a few microseconds each (a 1.25M-row shard's step is 0.5 ms), so the
         search's stream carries none of this class's: the side stream waits on the library's own end-of-call event
         (``ts_index_wait_order``), and the wait for the block's previous reader is skipped when that reader is known
@@ -249,14 +252,23 @@ class ShardedSearcher:
             lane.wait_event(b["ready"][p])
         if b["used"][p] and not b["done"][p].query():
             lane.wait_event(b["done"][p])              # the exchange of four calls ago has not consumed mine[p] yet
+        if own_stream:
+            # The search may read its queries in place, up to its last launch - and what the caller enqueues next on ITS stream
+            # (the next batch's encoder writing the same buffer) must come after that read.  Waiting for the END of the
+            # search would serialise the lanes (search i + 1 could not start before search i had finished), so the lane takes
+            # its own copy of the batch first (a few hundred KB, device to device) and the caller's stream waits for that
+            # copy only: the lanes then really run side by side.
+            nbytes = int(nq) * self.index.d * (2 if q_dtype in ("bf16", "bfloat16") else 4)
+            if b["qstage"][p] is None or b["qstage"][p].numel() < nbytes:
+                b["qstage"][p] = torch.empty(nbytes, dtype=torch.uint8, device=torch.device("cuda", self.index.device))
+            _ffi.check(lib.ts_copy_device(self.index.device, C.c_void_p(b["qstage"][p].data_ptr()), C.c_void_p(q_ptr), nbytes,
+                                          C.c_void_p(lane.cuda_stream)))
+            b["qread"][p].record(lane)
+            main.wait_event(b["qread"][p])
+            q_ptr = b["qstage"][p].data_ptr()
         blk, off = packed_bytes(nq, k), packed_idx_off(nq, k)
         base = b["mine"][p].data_ptr()
         ix.search_device(q_ptr, q_dtype, nq, k, base, base + off, lane.cuda_stream, algo=algo, mask_ptr=mask_ptr)
-        if own_stream:
-            # the search may read the caller's query buffer in place (queries in the index's own form): what the caller
-            # enqueues next on ITS stream - the next batch's encoder writing the same buffer - must come after that read.
-            # A wait on the handle's end-of-call event, not a marker packet on the lane.
-            _ffi.check(lib.ts_index_wait_order(ix.handle, C.c_void_p(main.cuda_stream)))
         side = self._side if overlap else main
         if overlap:
             _ffi.check(lib.ts_index_wait_order(ix.handle, C.c_void_p(side.cuda_stream)))   # behind the search just enqueued
