@@ -34,16 +34,20 @@ FAMILIES = {
 # (family, dtype) -> hidden max / hidden mean (relative to the largest |hidden| of the model's own output), min cosine of the
 # sentence embeddings fused vs own.  fp32: the two forwards differ by the summation order of the stacked GEMMs only.
 TOL = {
-    ("bert", "fp32"): dict(hmax=1e-3, hmean=1e-4, cos=1 - 1e-5),
-    ("qwen3", "fp32"): dict(hmax=1e-3, hmean=1e-4, cos=1 - 1e-5),
-    ("gemma3", "fp32"): dict(hmax=1e-3, hmean=1e-4, cos=1 - 1e-5),
-    ("bert", "bf16"): dict(hmax=0.08, hmean=0.006, cos=0.999),
-    ("qwen3", "bf16"): dict(hmax=0.25, hmean=0.02, cos=0.995),
-    ("gemma3", "bf16"): dict(hmax=0.25, hmean=0.02, cos=0.995),
+    # measured (profiles/r05_fulldepth.txt): fp32 hmax 1.2e-6 .. 2.8e-6, hmean 2.0e-7 .. 4.7e-7, cosine 1.0 to seven digits
+    ("bert", "fp32"): dict(hmax=1e-4, hmean=1e-5, cos=1 - 1e-5),
+    ("qwen3", "fp32"): dict(hmax=1e-4, hmean=1e-5, cos=1 - 1e-5),
+    ("gemma3", "fp32"): dict(hmax=1e-4, hmean=1e-5, cos=1 - 1e-5),
+    # measured: bf16 hmax 0.020 .. 0.032, hmean 0.0017 .. 0.0032 of the largest hidden value, cosine >= 0.9999
+    ("bert", "bf16"): dict(hmax=0.08, hmean=0.008, cos=0.9995),
+    ("qwen3", "bf16"): dict(hmax=0.08, hmean=0.008, cos=0.9995),
+    ("gemma3", "bf16"): dict(hmax=0.08, hmean=0.008, cos=0.9995),
 }
 # the opt-in bf16 forward against the fp32 one (both fused): min cosine of the embeddings - the "embedding tolerance" a
-# caller accepts with dtype=torch.bfloat16
-TOL_BF16_VS_FP32 = {"bert": 0.995, "qwen3": 0.98, "gemma3": 0.98}
+# caller accepts with dtype=torch.bfloat16.  Measured: 0.999983 (BERT), 0.999866 (Qwen3), 0.999859 (Gemma3) on random-init
+# weights at full depth; at 10M random rows the 10th and 11th best scores of a query lie ~1e-3 apart, so embeddings 1.4e-4
+# away in cosine (an angle of ~1.7e-2) DO reorder near-ties of the top-10: bf16 is a speed option, not the reference's answer.
+TOL_BF16_VS_FP32 = {"bert": 0.9995, "qwen3": 0.9995, "gemma3": 0.9995}
 
 
 def texts():

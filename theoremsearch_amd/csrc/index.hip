@@ -122,7 +122,7 @@ extern "C" int ts_index_destroy(ts_index* ix) {
     }
     if (ix->attached) ix->rows = nullptr;
     void* ptrs[] = {ix->rows,  ix->stage,   ix->qstore,   ix->qf32,     ix->cand,       ix->count,  ix->thr, ix->priv, ix->pcount, ix->sample, ix->mask_dev, ix->bias_dev, ix->rank_buf, ix->id_map,
-                    ix->fb_list, ix->fb_count, ix->stat, ix->partial, ix->partial2, ix->res_scores, ix->res_idx, ix->dbg, ix->part, ix->wg_ticks};
+                    ix->fb_list, ix->fb_count, ix->stat, ix->partial, ix->partial2, ix->res_scores, ix->res_idx, ix->dbg, ix->part, ix->wg_ticks, ix->pair_pos};
     for (void* p : ptrs)
         if (p) hipFree(p);
     for (hipEvent_t e : ix->ev_pool) hipEventDestroy(e);

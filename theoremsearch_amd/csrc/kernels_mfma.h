@@ -109,6 +109,10 @@ struct MfmaArgs {
     // dispatch, so the second reader of a tile finds it in that XCD's L2 / the memory-side cache); part / wg_ticks are
     // then indexed by pair
     int pair;
+    // ... and pace each other: pair_pos[2 * pair + half] = the tile that workgroup has reached (kernels_mfma16.h, PAIR);
+    // pair_lag = 0 switches the pacing off (a workgroup then never looks at its partner)
+    unsigned* pair_pos;
+    int pair_lag;
 };
 
 __device__ __forceinline__ float mfma_level_thr(const MfmaArgs& a, int qid) {

@@ -48,6 +48,9 @@ constexpr int kMfma16PrivCap = 16;   // entries of a lane-private candidate list
 // shard's pass at 160 candidates per query, which is why the threshold estimate aims at 6 k of them (search_mfma.hip).
 constexpr int kMfma16StageCap = 192;                                 // entries per wave (~40 expected at k = 10)
 constexpr int kMfma16StageBytes = 4 * kMfma16StageCap * 16 + 16;     // + one counter per wave
+// paired full pass: 64 dwords behind the staged candidates, where the partner workgroup's position lands (one LDS-DMA dword
+// per lane of wave 0, all from the same address)
+constexpr int kMfma16PaceBytes = 256;
 
 // MFMA statements with pinned register classes: accumulator and corpus fragment in VGPRs, query fragment in a VGPR
 // ("v" forms) or an AGPR ("a" forms) quadruple.  No pads inside: the A fragment comes from a ds_read behind the k-step's
@@ -192,6 +195,30 @@ __device__ __forceinline__ void mfma16_append_block(const f32x4& a0, const f32x4
     }
 }
 
+// Pacing of a workgroup pair (PAIR).  Both halves of a pair stream the same tiles; the second reader of a tile is served by
+// the XCD's L2 only while the two stay within what that L2 holds of the stream - 4 MB turn over in ~7 us at 535 GB/s per XCD,
+// about 15 units of 16 KB per pair.  Left alone they drift (an append, a slow barrier) and a pair that is further apart reads
+// every tile twice from the fabric: 24.9 GB per launch for a 20.5 GB corpus (profiles/r04_traffic_notes.txt).  So once per
+// tile wave 0 of each workgroup publishes the tile it has reached and looks at its partner's word; whoever is AHEAD by more
+// than the allowed lag sleeps a few hundred cycles before its next barrier.  No spin, no hard wait: a partner that is not
+// resident yet, or whose word never changes, slows nobody.  Everything is asynchronous and joins the counted queues on the
+// strict side only: the publish is a store and the look an LDS-DMA dword (both older than the DMA pieces that follow: a counted
+// vmcnt wait certifies MORE than before), the LDS word is read by a ds_read one unit before its value is used.
+__device__ __forceinline__ void pair_publish_and_fetch(unsigned* mine, const unsigned* partner, unsigned tile, unsigned lds_word) {
+    const unsigned zero = 0;
+    asm volatile(
+        "global_store_dword %0, %1, %2 sc1\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %0, %3 sc1"
+        :
+        : "v"(zero), "v"(tile), "s"(mine), "s"(partner), "s"(lds_word)
+        : "memory");
+}
+__device__ __forceinline__ void pair_read_word(unsigned& dst, unsigned lds_word) {
+    asm volatile("ds_read_b32 %0, %1" : "=v"(dst) : "v"(lds_word));
+}
+
 // NB = query blocks (of 16) per wave: the launch serves 64 * NB queries.
 // VARIANT 0 = the product kernel.  Timing-only diagnostics (wrong results): 1 = no epilogue, 2 = DMA stream only,
 // 7 = no DMA (MFMA + LDS reads), 4 = threshold test without the append path, 5 = product + per-unit cycle stamps around
@@ -259,6 +286,12 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     uint4* stage = (uint4*)(smem + dims::kLds) + wave * kMfma16StageCap;          // this wave's staged candidates
     u32* stage_cnt = (u32*)(smem + dims::kLds + 4 * kMfma16StageCap * 16) + wave;
     if (kStaged && lane == 0) *stage_cnt = 0;
+    // pair pacing (see pair_publish_and_fetch): wave 0 only; `pace_word` = LDS address of the partner's position
+    const bool pace = PAIR && a.pair_pos != nullptr && a.pair_lag > 0 && wave == 0;
+    unsigned* const pace_mine = PAIR ? a.pair_pos + 2 * wg + qhalf : nullptr;
+    const unsigned* const pace_partner = PAIR ? a.pair_pos + 2 * wg + (1 - qhalf) : nullptr;
+    unsigned pace_seen = 0, pace_prev = 0, pace_v;
+    if (PAIR && wave == 0) ((u32*)(smem + dims::kLds + kMfma16StageBytes))[lane] = 0;   // visible behind the first barrier
     // Tile range of this workgroup: equal shares, or the table the previous search's final select left (the XCDs of one
     // device run this pass at rates 3-4 % apart; the launch ends with its slowest workgroup)
     const unsigned long long wg_start = (!SPARSE && a.wg_ticks) ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -287,6 +320,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     int issue_u = 0, issue_ui = 0, issue_slot = 0;
     const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
     const unsigned lds0 = lds_base + wave * 1024;
+    const unsigned pace_word = __builtin_amdgcn_readfirstlane(lds_base + dims::kLds + kMfma16StageBytes);
 
     // operand read offsets inside a unit image: row block rb, k-step s -> (s >> 1) * 4096 + rb * 2048 + xo[s & 1]
     const int lane_off = (r16 >> 3) * 1024 + (r16 & 7) * 128;
@@ -491,8 +525,21 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         ua[0] = lds_base + soff + xo[0]; ua[1] = lds_base + soff + xo[1];                                  \
         na[0] = lds_base + noff + xo[0]; na[1] = lds_base + noff + xo[1];                                  \
         if constexpr (!kNoDma) wait_vmcnt<(kSlots - 3) * kPieces>();   /* own pieces of unit u + 1 */       \
+        if constexpr (PAIR && (UI) == (2 % kUnits)) {                   /* ahead of the partner: give way */ \
+            /* (the read and its use are unconditional: a value defined under a branch would reach this point through a */ \
+            /* copy the compiler is free to place right behind the asynchronous ds_read) */                \
+            asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(pace_seen) : "v"(pace_v));                   \
+            const int ahead_ = (int)((unsigned)t - pace_seen);                                             \
+            if (pace && pace_seen != pace_prev && ahead_ > a.pair_lag && ahead_ < (1 << 20))               \
+                for (int z_ = 0; z_ < ahead_ - a.pair_lag && z_ < 4; ++z_) __builtin_amdgcn_s_sleep(5);    \
+            pace_prev = pace_seen;                                                                         \
+        }                                                                                                  \
         __builtin_amdgcn_s_barrier();                                   /* ... and everyone's */            \
         asm volatile("" ::: "memory");                                                                     \
+        if constexpr (PAIR && (UI) == 0) {                                                                 \
+            if (pace) pair_publish_and_fetch(pace_mine, pace_partner, (unsigned)t, pace_word);            \
+        }                                                                                                  \
+        if constexpr (PAIR && (UI) == (1 % kUnits)) pair_read_word(pace_v, pace_word);                     \
         if (VARIANT == 6) __builtin_amdgcn_s_sleep(4);                                                     \
         constexpr bool do_issue = !kNoDma;                                                                 \
         constexpr bool steady_ = true;                                                                     \

@@ -57,7 +57,8 @@ static int launch_mfma16(bool full_pass, int variant, int grid, hipStream_t st, 
 
 // The paired full pass of d = 1024 (MfmaArgs::pair): 128 queries per workgroup, two workgroups per tile range.
 static int launch_mfma16_pair(int grid, hipStream_t st, const MfmaArgs& a) {
-    constexpr int lds = Mfma16Dims<1024>::kLds + kMfma16StageBytes;
+    constexpr int lds = Mfma16Dims<1024>::kLds + kMfma16StageBytes + kMfma16PaceBytes;
+    static_assert(lds <= 160 * 1024, "DMA ring + staged candidates + the pair's word must fit the CU's LDS");
     static std::atomic<unsigned long long> attr_done{0};
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));

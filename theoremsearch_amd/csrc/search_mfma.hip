@@ -291,6 +291,16 @@ int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* out_idx
         a.part = (balance && full_pass) ? ix->part : nullptr;
         a.wg_ticks = (balance && full_pass) ? ix->wg_ticks : nullptr;
         a.pair = (pair && full_pass) ? 1 : 0;
+        a.pair_pos = nullptr;
+        a.pair_lag = 0;
+        if (a.pair && ix->knobs.get(K_MFMA_PAIR_LAG, 1) > 0) {
+            if (!ix->pair_pos) {
+                HIP_TRY(hipMalloc((void**)&ix->pair_pos, 2 * 256 * sizeof(unsigned)));
+                HIP_TRY(hipMemsetAsync(ix->pair_pos, 0, 2 * 256 * sizeof(unsigned), st));
+            }
+            a.pair_pos = ix->pair_pos;
+            a.pair_lag = ix->knobs.get(K_MFMA_PAIR_LAG, 1);
+        }
         a.dbg = nullptr;
 #ifdef TS_DIAG
         if (variant >= 3) {

@@ -452,7 +452,9 @@ extern "C" int ts_shards_create(int32_t ngpu, const int32_t* devices, int64_t n_
             return fail(TS_ERR_HIP, "ncclCommInitAll over %d devices failed: %s", ngpu, api->GetErrorString(r));
         }
     }
-    if (ngpu > 1)
+    // TS_SHARDS_THREADS=0: every device's enqueue from the caller's thread, in order (the A/B of tools/shards_call.py)
+    const char* thr_env = getenv("TS_SHARDS_THREADS");
+    if (ngpu > 1 && !(thr_env && atoi(thr_env) == 0))
         for (int g = 0; g < ngpu; ++g) {
             std::unique_ptr<ShardWorker> w(new (std::nothrow) ShardWorker());
             if (!w) {
@@ -542,8 +544,8 @@ extern "C" int ts_shards_search(ts_shards* s, const void* queries, int q_dtype, 
         if (!s->use_rccl) HIP_TRY(hipEventRecord(s->done[g], st[g]));
         return TS_OK;
     };
-    if (G == 1) {
-        TS_TRY(enqueue(0));
+    if (s->worker.empty()) {
+        for (int g = 0; g < G; ++g) TS_TRY(enqueue(g));
     } else {
         for (int g = 0; g < G; ++g) s->worker[g]->post([enqueue, g] { return enqueue(g); });
         int rc_all = TS_OK;
