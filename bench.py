@@ -732,6 +732,11 @@ def main():
     # contract's K steps - 63 ms at the default; a second of back-to-back passes lets the clock settle) -----------------
     sustained, power = None, None
     sustained_steps = args.sustained_steps if (args.sustained_steps > 0 or bracket_timed) else max(20, args.steps)
+    if args.sustained_steps >= 100 and ms_per_step > 0:
+        # ... and at least a second of them: behind the idle gap between the legs the power controller needs ~20 steps to settle
+        # (a 1.25M-row shard's pass: 363 us in the first steps, 557 us eight steps later, 420 us from step 20 on), and 300
+        # steps of such a shard are 0.15 s - round 4's sustained leg read 13 % above its own timed region for that reason
+        sustained_steps = max(sustained_steps, int(1000.0 / ms_per_step) + 1)
 
     def read_brackets():
         sp_ = {"launches": 0, "total_ms": 0.0, "rows_per_launch": 0}

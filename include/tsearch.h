@@ -107,6 +107,16 @@ int ts_index_stream(const ts_index *ix, void **stream);
  * call ran on (stream-ordered, no host wait): a side stream that consumes a search's device results - the exchange + merge
  * of the sharded search - needs no event of its own on the search's stream. */
 int ts_index_wait_order(ts_index *ix, void *stream);
+/* The ONE host-only entry (SURVEY.md 8b "ts_search_cpu"; BASELINE.json configs[0], the reference's CPU-runnable case:
+ * util.cos_sim + argsort over ~1k theorems, compare_embeddings.py:24-31,55-92).  Stateless and explicit: no device entry
+ * falls back to it, nothing selects it by itself; Python reaches it only through TheoremIndex(..., device=-1).
+ * rows [n x d] and queries [nq x d] are HOST arrays (fp32, or bf16 bit patterns), prepared on every call exactly as
+ * ts_index_upload / ts_search prepare them on the device (metric cos: x / max(||x||, 1e-12) with the norm in fp64; store_dtype
+ * TS_BF16: rounded to nearest even); scores are fp32 dot products of the prepared values; results in the library's order
+ * (score descending, row ascending; NaN never ranks), padded with (-inf, -1).  threads <= 0: one per hardware thread. */
+int ts_search_cpu(const void *rows, int rows_dtype, int64_t n, int32_t d, int store_dtype, int metric,
+                  const void *queries, int q_dtype, int32_t nq, int32_t k, float *out_scores, int64_t *out_idx,
+                  int32_t threads);
 /* Device-to-device copy of `bytes` bytes on `device`, enqueued on `stream` (hipStream_t as void*; NULL = the legacy null
  * stream): lets a Python caller that only holds raw device addresses stage a query batch in a buffer of its own before a
  * search on another stream reads it (ShardedSearcher with several searches in flight: the caller's stream then waits for
@@ -368,6 +378,11 @@ int ts_add_rmsnorm(int device, const void *a, const void *b, const void *gamma, 
 int ts_qk_norm_rope(int device, void *qkv, const void *q_weight, const void *k_weight, const void *cos_table, const void *sin_table,
                     float eps, int64_t tokens, int32_t seq, int32_t q_heads, int32_t kv_heads, int32_t head_dim, int dtype,
                     void *stream);
+/* fp32 values as bf16 pieces for an fp32-class GEMM on the bf16 matrix pipe (encoder forward at the reference's fp32 storage,
+ * streamlit_app.py:55,173): hi = bf16(x), lo = bf16(x - hi); out [rows x 3k] bf16 = [hi | lo | hi] (pattern 0, activations) or
+ * [hi | hi | lo] (pattern 1, weights), so that ONE bf16 GEMM with fp32 accumulation over depth 3k yields
+ * x_hi w_hi + x_lo w_hi + x_hi w_lo - the fp32 product up to ~2^-17 |x||w| per term.  x fp32 [rows x k], k a multiple of 4. */
+int ts_split_pieces(int device, const void *x, int64_t rows, int32_t k, int pattern, void *out, void *stream);
 /* Gated-MLP activation (Qwen3MLP: SiLU(gate_proj(x)) * up_proj(x)) on the output of ONE GEMM over the stacked gate / up
  * weights: gate_up device [rows][2 * inter] (gate columns, then up columns) -> out device [rows][inter]. */
 int ts_swiglu(int device, const void *gate_up, int64_t rows, int32_t inter, int dtype, void *out, void *stream);

@@ -48,6 +48,8 @@ _SIGNATURES = {
     "ts_index_synchronize": (C.c_int, [C.c_void_p]),
     "ts_index_wait_order": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ts_copy_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "ts_search_cpu": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int32, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int32, C.c_int32,
+                                C.c_void_p, C.c_void_p, C.c_int32]),
     "ts_index_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "ts_index_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                 C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
@@ -111,6 +113,7 @@ _SIGNATURES = {
                                  C.c_void_p, C.c_void_p]),
     "ts_qk_norm_rope": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_int, C.c_void_p]),
+    "ts_split_pieces": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_void_p, C.c_void_p]),
     "ts_swiglu": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_void_p, C.c_void_p]),
     "ts_geglu": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_void_p, C.c_void_p]),
     "ts_gemma_norm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_int32, C.c_int,

@@ -342,6 +342,22 @@ static int gated_act_launch(int device, const void* gate_up, int64_t rows, int32
     return TS_OK;
 }
 
+extern "C" int ts_split_pieces(int device, const void* x, int64_t rows, int32_t k, int pattern, void* out, void* stream) {
+    if (!x || !out) return fail(TS_ERR_INVALID, "NULL argument");
+    if (rows < 0 || k < 4 || k % 4 || (pattern != 0 && pattern != 1)) return fail(TS_ERR_INVALID, "k = %d must be a multiple of 4, pattern 0 or 1", k);
+    if ((((uintptr_t)x) & 15) != 0 || (((uintptr_t)out) & 7) != 0) return fail(TS_ERR_INVALID, "x must be 16-byte, out 8-byte aligned");
+    if (rows == 0) return TS_OK;
+    TS_TRY(check_device(device));
+    HIP_TRY(hipSetDevice(device));
+    const int64_t total = rows * (k / 4);
+    const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 16384);
+    hipStream_t st = (hipStream_t)stream;
+    if (pattern == 0) split3_kernel<0><<<grid, 256, 0, st>>>((const float*)x, rows, k, (unsigned short*)out);
+    else split3_kernel<1><<<grid, 256, 0, st>>>((const float*)x, rows, k, (unsigned short*)out);
+    HIP_TRY(hipGetLastError());
+    return TS_OK;
+}
+
 extern "C" int ts_swiglu(int device, const void* gate_up, int64_t rows, int32_t inter, int dtype, void* out, void* stream) {
     return gated_act_launch(device, gate_up, rows, inter, dtype, false, out, stream);
 }

@@ -484,7 +484,8 @@ __global__ void __launch_bounds__(256) qk_norm_rope_kernel(void* qkv, const void
     const int pos = (int)(tok % seq);
     const int64_t width = (int64_t)(hq + 2 * hkv) * HD;
     uint4* px = (uint4*)((char*)qkv + (tok * width + (int64_t)h * HD) * (DT == 0 ? 4 : 2)) + j;
-    const uint4 rx = *px;
+    // (idle groups load nothing: item 0 is being rewritten in place by the wave that owns it)
+    const uint4 rx = live ? *px : make_uint4(0u, 0u, 0u, 0u);
     const uint4 rw = ((const uint4*)(h < hq ? wq : wk))[j];
     const uint4 rc = ((const uint4*)cos_t)[(int64_t)pos * LPH + j];
     const uint4 rs = ((const uint4*)sin_t)[(int64_t)pos * LPH + j];
@@ -533,8 +534,37 @@ __global__ void __launch_bounds__(256) swiglu_kernel(const void* __restrict__ ga
         enc_unpack<DT>(g4, g);
         enc_unpack<DT>(u4, u);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) y[e] = enc_round<DT>(g[e] / (1.0f + __expf(-g[e]))) * u[e];
+        for (int e = 0; e < VEC; ++e) y[e] = enc_round<DT>(g[e] / (1.0f + expf(-g[e]))) * u[e];   // expf, not the fast intrinsic: torch's SiLU
         ((uint4*)out)[i] = enc_pack<DT>(y);
+    }
+}
+
+// fp32 values as bf16 PIECES for an fp32-class GEMM on the bf16 matrix pipe: hi = bf16(x), lo = bf16(x - hi) - sixteen bits of
+// significand between them - laid out so that ONE bf16 GEMM with fp32 accumulation over the three-fold depth computes
+//     x . w  ~  x_hi w_hi + x_lo w_hi + x_hi w_lo        (what is dropped: x_lo w_lo and the pieces' own residuals, ~2^-17 |x||w|)
+//   PATTERN 0 (activations): out[r] = [ hi(x_r) | lo(x_r) | hi(x_r) ]      PATTERN 1 (weights): out[r] = [ hi | hi | lo ]
+// x [rows][k] fp32, out [rows][3 k] bf16; k a multiple of 4; 16 bytes in, 3 x 8 bytes out per thread.
+template <int PATTERN>
+__global__ void __launch_bounds__(256) split3_kernel(const float* __restrict__ x, int64_t rows, int k, unsigned short* __restrict__ out) {
+    const int per_row = k / 4;
+    const int64_t total = rows * per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / per_row;
+        const int c = (int)(i - r * per_row);
+        const float4 v = ((const float4*)x)[i];
+        const float f[4] = {v.x, v.y, v.z, v.w};
+        float hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hi[e] = bf16_to_f32(f32_to_bf16(f[e]));
+            lo[e] = f[e] - hi[e];                       // exact in fp32: hi is f rounded to 8 significant bits
+        }
+        const uint2 ph = make_uint2(pack_bf16_hw(hi[0], hi[1]), pack_bf16_hw(hi[2], hi[3]));
+        const uint2 pl = make_uint2(pack_bf16_hw(lo[0], lo[1]), pack_bf16_hw(lo[2], lo[3]));
+        uint2* o = (uint2*)(out + r * 3 * (int64_t)k) + c;
+        o[0] = ph;
+        o[per_row] = PATTERN == 0 ? pl : ph;
+        o[2 * per_row] = PATTERN == 0 ? ph : pl;
     }
 }
 

@@ -204,13 +204,17 @@ __device__ __forceinline__ void mfma16_append_block(const f32x4& a0, const f32x4
 // resident yet, or whose word never changes, slows nobody.  Everything is asynchronous and joins the counted queues on the
 // strict side only: the publish is a store and the look an LDS-DMA dword (both older than the DMA pieces that follow: a counted
 // vmcnt wait certifies MORE than before), the LDS word is read by a ds_read one unit before its value is used.
+// Cache scope: the two workgroups sit on ONE XCD (w and w + 8 under round-robin dispatch) and meet in its L2 - a plain store
+// (the vector L1 writes through) and an `sc0` look (past the L1).  Agent scope (`sc1`) sends both to memory: microseconds
+// each, and vmcnt retires in order, so every DMA piece behind them waits that long to be counted - the first cut, 4-6 %
+// slower than no pacing at all (profiles/r05_c3q_pair_pacing.txt).  On another dispatch order the word simply never changes.
 __device__ __forceinline__ void pair_publish_and_fetch(unsigned* mine, const unsigned* partner, unsigned tile, unsigned lds_word) {
     const unsigned zero = 0;
     asm volatile(
-        "global_store_dword %0, %1, %2 sc1\n\t"
+        "global_store_dword %0, %1, %2\n\t"
         "s_mov_b32 m0, %4\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dword %0, %3 sc1"
+        "global_load_lds_dword %0, %3 sc0"
         :
         : "v"(zero), "v"(tile), "s"(mine), "s"(partner), "s"(lds_word)
         : "memory");
