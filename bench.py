@@ -442,11 +442,13 @@ def main():
     ap.add_argument("--tune-gemms", action="store_true",
                     help="c5: let PyTorch's TunableOp pick the fastest hipBLASLt / rocBLAS solution for each of the encoder's "
                          "four GEMM shapes during the warm-up (seconds of tuning per shape)")
-    ap.add_argument("--encoder-dtype", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--encoder-dtype", default="fp32", choices=["fp32", "fp32x3", "bf16"],
                     help="c5: the arithmetic of the encoder forward.  fp32 (default) is what the reference runs "
                          "(SentenceTransformer(name) without a dtype: streamlit_app.py:55,173, app_create_embeddings.py:22,81) and what "
-                         "SentenceEncoder does for a real checkpoint; bf16 is the opt-in half-precision forward (its embeddings differ "
-                         "from the fp32 ones by the tolerance DESIGN.md section 8 states)")
+                         "SentenceEncoder does for a real checkpoint; fp32x3 keeps fp32 weights and activations and runs the GEMMs on "
+                         "the bf16 matrix pipe from bf16 pieces (SentenceEncoder(fp32_gemm='bf16x3'): 16 significant bits per factor, "
+                         "fp32 accumulation); bf16 is the opt-in half-precision forward (DESIGN.md section 8 states how far the "
+                         "embeddings of either lie from the fp32 ones)")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="N > 1: exercise only the launch + host-collective plumbing of an N-rank run over gloo, no device, no "
                          "search (rehearse_launch); prints what was exercised, not a benchmark line")
@@ -573,8 +575,9 @@ def main():
             tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"ts_tunableop_rank{rank}.csv"))
         enc_name = {"qwen": "Qwen/Qwen3-Embedding-0.6B", "gemma": "google/embeddinggemma-300m"}.get(
             args.encoder, "math-similarity/Bert-MLM_arXiv-MP-class_zbMath")
-        enc_dtype = torch.float32 if args.encoder_dtype == "fp32" else torch.bfloat16
-        encoder = SentenceEncoder(enc_name, allow_random_init=True, dtype=enc_dtype)
+        enc_dtype = torch.bfloat16 if args.encoder_dtype == "bf16" else torch.float32
+        encoder = SentenceEncoder(enc_name, allow_random_init=True, dtype=enc_dtype,
+                                  fp32_gemm="bf16x3" if args.encoder_dtype == "fp32x3" else "blas")
         if encoder.embedding_dim != D:
             raise SystemExit(f"the {args.encoder} encoder embeds into {encoder.embedding_dim} dimensions, the index has {D}")
         log(rank, f"encoder: {type(encoder.model).__name__} ({enc_name}, random init, {args.encoder_dtype} forward), fused forward: {type(encoder._fused).__name__}")

@@ -38,6 +38,9 @@ TOL = {
     ("bert", "fp32"): dict(hmax=1e-4, hmean=1e-5, cos=1 - 1e-5),
     ("qwen3", "fp32"): dict(hmax=1e-4, hmean=1e-5, cos=1 - 1e-5),
     ("gemma3", "fp32"): dict(hmax=1e-4, hmean=1e-5, cos=1 - 1e-5),
+    ("bert", "fp32x3"): dict(hmax=1e-3, hmean=1e-4, cos=1 - 1e-5),
+    ("qwen3", "fp32x3"): dict(hmax=1e-3, hmean=1e-4, cos=1 - 1e-5),
+    ("gemma3", "fp32x3"): dict(hmax=1e-3, hmean=1e-4, cos=1 - 1e-5),
     # measured: bf16 hmax 0.020 .. 0.032, hmean 0.0017 .. 0.0032 of the largest hidden value, cosine >= 0.9999
     ("bert", "bf16"): dict(hmax=0.08, hmean=0.008, cos=0.9995),
     ("qwen3", "bf16"): dict(hmax=0.08, hmean=0.008, cos=0.9995),
@@ -48,6 +51,9 @@ TOL = {
 # weights at full depth; at 10M random rows the 10th and 11th best scores of a query lie ~1e-3 apart, so embeddings 1.4e-4
 # away in cosine (an angle of ~1.7e-2) DO reorder near-ties of the top-10: bf16 is a speed option, not the reference's answer.
 TOL_BF16_VS_FP32 = {"bert": 0.9995, "qwen3": 0.9995, "gemma3": 0.9995}
+# fp32 storage with the GEMMs on the bf16 matrix pipe from bf16 pieces (fp32_gemm="bf16x3") against the fp32-GEMM forward
+# (both fused): 1 - min cosine of the embeddings; and against the model's own fp32 forward (TOL below)
+TOL_X3_VS_FP32 = {"bert": 1e-6, "qwen3": 1e-6, "gemma3": 1e-6}
 
 
 def texts():
@@ -60,8 +66,9 @@ def measure(family, dtype_name):
     import torch
     from theoremsearch_amd import encoder as E
     name, depth, fused_cls = FAMILIES[family]
-    dtype = torch.float32 if dtype_name == "fp32" else torch.bfloat16
-    enc = E.SentenceEncoder(name, allow_random_init=True, dtype=dtype)
+    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+    enc = E.SentenceEncoder(name, allow_random_init=True, dtype=dtype, fp32_gemm="bf16x3" if dtype_name == "fp32x3" else "blas")
+    assert enc._fused.pieces == (dtype_name == "fp32x3")
     assert type(enc._fused).__name__ == fused_cls, type(enc._fused)
     layers = enc.model.encoder.layer if family == "bert" else enc.model.layers
     assert len(layers) == depth
@@ -100,10 +107,14 @@ def measure(family, dtype_name):
 @pytest.mark.parametrize("family", sorted(FAMILIES))
 def test_fused_forward_at_the_published_depth(family):
     stats32, e32 = measure(family, "fp32")
+    stats3, e3 = measure(family, "fp32x3")
     stats16, e16 = measure(family, "bf16")
     between = float(np.min(np.sum(e32 * e16, axis=1)))
-    print(f"[fulldepth] {family}: fp32 {stats32}; bf16 {stats16}; bf16 vs fp32 embeddings: min cosine {between:.6f}")
-    for dtype_name, st in (("fp32", stats32), ("bf16", stats16)):
+    between3 = float(np.min(np.sum(e32.astype(np.float64) * e3.astype(np.float64), axis=1)))
+    print(f"[fulldepth] {family}: fp32 {stats32}; fp32x3 {stats3}; bf16 {stats16}; embeddings vs the fp32 forward's: "
+          f"bf16 min cosine {between:.6f}, fp32x3 1 - min cosine {1.0 - between3:.3e}")
+    assert 1.0 - between3 <= TOL_X3_VS_FP32[family], (family, between3)
+    for dtype_name, st in (("fp32", stats32), ("fp32x3", stats3), ("bf16", stats16)):
         tol = TOL[(family, dtype_name)]
         assert st["hmax"] <= tol["hmax"] and st["hmean"] <= tol["hmean"], (family, dtype_name, st)
         assert st["hmax_unpadded"] <= tol["hmax"] and st["hmean_unpadded"] <= tol["hmean"], (family, dtype_name, st)
@@ -115,6 +126,13 @@ if __name__ == "__main__":
     for fam in sorted(FAMILIES):
         s32, e32 = measure(fam, "fp32")
         s16, e16 = measure(fam, "bf16")
+        try:
+            s3, e3 = measure(fam, "fp32x3")
+            print(fam, "fp32x3", {k: float(f"{v:.3g}") for k, v in s3.items()})
+            print(fam, "fp32x3 vs fp32 embeddings (both fused): 1 - min cosine",
+                  float(f"{1.0 - float(np.min(np.sum(e32.astype(np.float64) * e3.astype(np.float64), axis=1))):.3e}"))
+        except Exception as e:          # noqa: BLE001
+            print(fam, "fp32x3 FAILED", type(e).__name__, str(e)[:300])
         print(fam, "fp32", {k: float(f"{v:.3g}") for k, v in s32.items()})
         print(fam, "bf16", {k: float(f"{v:.3g}") for k, v in s16.items()})
         print(fam, "bf16 vs fp32 embeddings (both fused): min cosine", round(float(np.min(np.sum(e32 * e16, axis=1))), 6), flush=True)

@@ -983,3 +983,39 @@ def test_fused_gemma3_forward_matches_the_models_own():
         w32 = f32.model(input_ids=e32["input_ids"], attention_mask=e32["attention_mask"]).last_hidden_state
         g32 = f32.forward_hidden(e32["input_ids"], e32["attention_mask"])
     assert (w32 - g32)[e32["attention_mask"].bool()].abs().max().item() < 5e-4 * max(1.0, w32.abs().max().item())
+
+
+# ---- round 5: fp32-class GEMMs of the encoder on the bf16 matrix pipe ---------------------------------------------------------
+def test_split_pieces_kernel_and_the_three_piece_linear():
+    """ts_split_pieces: hi = bf16(x) exactly as torch rounds, lo = bf16(x - hi), laid out [hi | lo | hi] (activations) and
+    [hi | hi | lo] (weights); hi + lo carries x to 2^-16 of its magnitude.  pieces_linear (ONE bf16 GEMM with fp32 accumulation
+    over the three-fold depth) against fp64: within 2e-5 of |x||w| per entry - where the library's fp32 GEMM lands within
+    ~1e-6 and a plain bf16 GEMM within ~4e-3 - with and without a bias, on a 3-D input."""
+    import ctypes as C
+    import torch
+    from theoremsearch_amd import _ffi
+    from theoremsearch_amd.fused_forward import pieces_linear, split_pieces
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = (torch.randn(300, 768, generator=g) * torch.logspace(-3, 2, 300)[:, None]).cuda()
+    for pattern in (0, 1):
+        p = split_pieces(x, pattern).float()
+        hi = x.bfloat16().float()
+        lo = (x - hi).bfloat16().float()
+        assert torch.equal(p[:, :768], hi)
+        assert torch.equal(p[:, 768:1536], lo if pattern == 0 else hi)
+        assert torch.equal(p[:, 1536:], hi if pattern == 0 else lo)
+        assert ((hi + lo - x).abs() <= x.abs() * 2.0 ** -16).all()
+    with pytest.raises(_ffi.TSearchError):
+        _ffi.check(_ffi.load().ts_split_pieces(0, C.c_void_p(x.data_ptr()), 300, 766, 0, C.c_void_p(x.data_ptr()), None))
+    w = (torch.randn(512, 768, generator=g) * 0.05).cuda()
+    b = torch.randn(512, generator=g).cuda()
+    x3d = torch.randn(5, 60, 768, generator=g).cuda()
+    ref = x3d.double() @ w.double().t()
+    scale = x3d.double().norm(dim=-1, keepdim=True) * w.double().norm(dim=1)
+    got = pieces_linear(x3d, split_pieces(w, 1))
+    assert got.shape == (5, 60, 512) and got.dtype == torch.float32
+    assert ((got.double() - ref).abs() / scale).max().item() < 2e-5
+    got_b = pieces_linear(x3d, split_pieces(w, 1), b)
+    assert ((got_b.double() - ref - b.double()).abs() / scale).max().item() < 2e-5
+    plain = torch.nn.functional.linear(x3d.bfloat16(), w.bfloat16()).double()
+    assert ((plain - ref).abs() / scale).max().item() > 20 * ((got.double() - ref).abs() / scale).max().item()

@@ -197,11 +197,19 @@ class SentenceEncoder:
 
     def __init__(self, model_name: str = "math-similarity/Bert-MLM_arXiv-MP-class_zbMath", device: Optional[str] = None,
                  dtype: Optional[torch.dtype] = None, seed: int = 0, num_layers: Optional[int] = None,
-                 allow_random_init: Optional[bool] = None, trust_remote_code: bool = False):
+                 allow_random_init: Optional[bool] = None, trust_remote_code: bool = False, fp32_gemm: Optional[str] = None):
+        """``fp32_gemm`` (fp32 models on a GPU): ``"blas"`` = the library's fp32 GEMMs (default: the reference's arithmetic,
+        SentenceTransformer(name) without a dtype) or ``"bf16x3"`` = the same fp32 weights and activations as bf16 pieces on the
+        bf16 matrix pipe (`fused_forward.pieces_linear`: sixteen significant bits per factor, fp32 accumulation; embeddings
+        within the cosine DESIGN.md section 8 states of the fp32-GEMM forward); ``TS_ENCODER_FP32_GEMM`` sets the default."""
         self.model_name = model_name
         self.device = torch.device(device or ("cuda" if torch.cuda.is_available() else "cpu"))
+        fp32_gemm = fp32_gemm or os.environ.get("TS_ENCODER_FP32_GEMM", "") or "blas"
+        if fp32_gemm not in ("blas", "bf16x3"):
+            raise ValueError(f"fp32_gemm must be 'blas' or 'bf16x3', got {fp32_gemm!r}")
+        self.fp32_gemm = fp32_gemm
         self._ctor = dict(model_name=model_name, dtype=dtype, seed=seed, num_layers=num_layers,
-                          allow_random_init=allow_random_init, trust_remote_code=trust_remote_code)
+                          allow_random_init=allow_random_init, trust_remote_code=trust_remote_code, fp32_gemm=fp32_gemm)
         self._pool = None
         local = _local_dir(model_name)
         if allow_random_init is None:
@@ -282,6 +290,9 @@ class SentenceEncoder:
                 self._fused = FusedQwen3Forward(self.model)
             elif FusedGemma3Forward.covers(self.model):
                 self._fused = FusedGemma3Forward(self.model)
+        if self._fused is not None and fp32_gemm == "bf16x3" and next(self.model.parameters()).dtype == torch.float32:
+            self._fused.pieces = True
+            self._fused._refresh()
         for m in self.pipeline.dense:
             m.to(self.device, dtype=torch.float32).eval()
         self.embedding_dim = (self.pipeline.dense[-1][0].out_features if self.pipeline.dense

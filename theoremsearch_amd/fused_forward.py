@@ -18,6 +18,34 @@ from typing import Optional
 import torch
 
 
+def split_pieces(x: torch.Tensor, pattern: int) -> torch.Tensor:
+    """``x`` fp32 ``[rows x k]`` -> bf16 ``[rows x 3k]``: ``[hi | lo | hi]`` (pattern 0, activations) or ``[hi | hi | lo]``
+    (pattern 1, weights), hi = bf16(x), lo = bf16(x - hi) (``ts_split_pieces``)."""
+    import ctypes as C
+    from . import _ffi
+    x = x.contiguous()
+    rows, k = x.shape
+    out = torch.empty((rows, 3 * k), dtype=torch.bfloat16, device=x.device)
+    _ffi.check(_ffi.load().ts_split_pieces(x.device.index or 0, C.c_void_p(x.data_ptr()), rows, k, pattern, C.c_void_p(out.data_ptr()),
+                                           C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+    return out
+
+
+def pieces_linear(x: torch.Tensor, w_pieces: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``F.linear(x, w, bias)`` for fp32 ``x`` and an fp32 weight given as its pieces (``split_pieces(w, 1)``), computed on the
+    bf16 matrix pipe: ONE bf16 GEMM with fp32 accumulation over the three-fold depth (hipBLASLt through ``torch.mm(..,
+    out_dtype=float32)``) = x_hi w_hi + x_lo w_hi + x_hi w_lo - the fp32 product up to ~2^-17 |x||w| per term, at a third of
+    the bf16 GEMM rate instead of the fp32 matrix rate (157 TF against 2.5 PF dense on MI355X).  The encoder forward at the
+    reference's fp32 storage (SentenceTransformer(name) without a dtype, streamlit_app.py:55,173) with ``fp32_gemm="bf16x3"``."""
+    shape = x.shape
+    x3 = split_pieces(x.reshape(-1, shape[-1]), 0)
+    if bias is not None:
+        y = torch.addmm(bias, x3, w_pieces.t(), out_dtype=torch.float32)
+    else:
+        y = torch.mm(x3, w_pieces.t(), out_dtype=torch.float32)
+    return y.view(*shape[:-1], w_pieces.shape[0])
+
+
 class FusedBertForward:
     """The forward of a BERT-family encoder (``BertModel``: what ``math-similarity/Bert-MLM_arXiv-MP-class_zbMath`` is,
     compare_embeddings.py:11) with the launches that do not pay for themselves folded together:
@@ -41,6 +69,7 @@ class FusedBertForward:
         self.eps = float(cfg.layer_norm_eps)
         from transformers.activations import ACT2FN
         self.act = ACT2FN[cfg.hidden_act] if isinstance(cfg.hidden_act, str) else cfg.hidden_act
+        self.pieces = False           # fp32 models: the GEMMs on the bf16 matrix pipe from bf16 pieces (pieces_linear)
         self._stamp = None
         self._refresh()
 
@@ -53,7 +82,7 @@ class FusedBertForward:
     def _refresh(self):
         """(Re)build the stacked query / key / value weights when the model's own have changed (load_state_dict, .to(dtype),
         an edit in place): the other weights are live references, the stacked ones are copies."""
-        stamp = tuple((p.data_ptr(), p._version, p.dtype) for p in self._sources())
+        stamp = tuple((p.data_ptr(), p._version, p.dtype) for p in self._sources()) + (self.pieces,)
         if stamp == self._stamp:
             return
         self._stamp = stamp
@@ -67,6 +96,10 @@ class FusedBertForward:
                 "w1": layer.intermediate.dense.weight, "b1": layer.intermediate.dense.bias,
                 "w2": layer.output.dense.weight, "b2": layer.output.dense.bias, "ln2": layer.output.LayerNorm,
             })
+            if self.pieces and self.layers[-1]["wo"].dtype == torch.float32:
+                L = self.layers[-1]
+                for name in ("wqkv", "wo", "w1", "w2"):
+                    L[name + "_p"] = split_pieces(L[name].detach(), 1)
 
     @staticmethod
     def covers(model) -> bool:
@@ -143,17 +176,22 @@ class FusedBertForward:
         mask = None if (no_padding or short) else torch.zeros((B, 1, 1, S), dtype=x.dtype, device=x.device).masked_fill_(
             ~attention_mask[:, None, None, :].to(torch.bool), torch.finfo(x.dtype).min)
         key_mask = None if (no_padding or not short) else attention_mask.to(torch.int64).contiguous()
+        pieces = self.pieces and x.dtype == torch.float32 and "wo_p" in self.layers[0]
+
+        def lin(t, L_, w, b):
+            return pieces_linear(t, L_[w + "_p"], L_[b]) if pieces else F.linear(t, L_[w], L_[b])
+
         for L in self.layers:
-            qkv = F.linear(x, L["wqkv"], L["bqkv"])
+            qkv = lin(x, L, "wqkv", "bqkv")
             if short:
                 ctx = self._attention(qkv, key_mask, B, S)
             else:
                 qkv = qkv.view(B, S, 3, self.heads, hd).permute(2, 0, 3, 1, 4)
                 ctx = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], attn_mask=mask)
                 ctx = ctx.transpose(1, 2).reshape(B, S, H)
-            x = self._add_ln(F.linear(ctx, L["wo"], L["bo"]), x, L["ln1"])
-            h = self.act(F.linear(x, L["w1"], L["b1"]))
-            x = self._add_ln(F.linear(h, L["w2"], L["b2"]), x, L["ln2"])
+            x = self._add_ln(lin(ctx, L, "wo", "bo"), x, L["ln1"])
+            h = self.act(lin(x, L, "w1", "b1"))
+            x = self._add_ln(lin(h, L, "w2", "b2"), x, L["ln2"])
         return x
 
 
@@ -179,6 +217,7 @@ class FusedQwen3Forward:
         self.model, self.cfg = model, cfg
         self.hq, self.hkv, self.hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         self.eps = float(cfg.rms_norm_eps)
+        self.pieces = False           # fp32 models: the GEMMs on the bf16 matrix pipe from bf16 pieces (pieces_linear)
         self._stamp = None
         self._gqa_native = True
         self._refresh()
@@ -189,7 +228,7 @@ class FusedQwen3Forward:
             yield from (att.q_proj.weight, att.k_proj.weight, att.v_proj.weight, mlp.gate_proj.weight, mlp.up_proj.weight)
 
     def _refresh(self):
-        stamp = tuple((p.data_ptr(), p._version, p.dtype) for p in self._sources())
+        stamp = tuple((p.data_ptr(), p._version, p.dtype) for p in self._sources()) + (self.pieces,)
         if stamp == self._stamp:
             return
         self._stamp = stamp
@@ -202,6 +241,10 @@ class FusedQwen3Forward:
                 "wgu": torch.cat([mlp.gate_proj.weight, mlp.up_proj.weight], dim=0).contiguous(), "wd": mlp.down_proj.weight,
                 "ln1": layer.input_layernorm.weight, "ln2": layer.post_attention_layernorm.weight,
             })
+            if self.pieces and self.layers[-1]["wo"].dtype == torch.float32:
+                L = self.layers[-1]
+                for name in ("wqkv", "wo", "wgu", "wd"):
+                    L[name + "_p"] = split_pieces(L[name].detach(), 1)
 
     @staticmethod
     def covers(model) -> bool:
@@ -280,9 +323,14 @@ class FusedQwen3Forward:
             keep = causal[None, None] & attention_mask[:, None, None, :].to(torch.bool)
             mask = torch.zeros((B, 1, S, S), dtype=x.dtype, device=x.device).masked_fill_(~keep, neg)
         nq, nkv, hd = self.hq * self.hd, self.hkv * self.hd, self.hd
+        pieces = self.pieces and x.dtype == torch.float32 and "wo_p" in self.layers[0]
+
+        def lin(t, L_, w):
+            return pieces_linear(t, L_[w + "_p"]) if pieces else F.linear(t, L_[w])
+
         h = self._add_rmsnorm(x, None, self.layers[0]["ln1"], False)[1]
         for li, L in enumerate(self.layers):
-            qkv = F.linear(h, L["wqkv"])
+            qkv = lin(h, L, "wqkv")
             _ffi.check(lib.ts_qk_norm_rope(dev, C.c_void_p(qkv.data_ptr()), C.c_void_p(L["qn"].data_ptr()), C.c_void_p(L["kn"].data_ptr()),
                                            C.c_void_p(cos.data_ptr()), C.c_void_p(sin.data_ptr()), self.eps, B * S, S, self.hq, self.hkv,
                                            hd, dt, stream))
@@ -293,14 +341,14 @@ class FusedQwen3Forward:
                                                B, S, self.hq, self.hkv, hd, 1, C.c_void_p(ctx.data_ptr()), stream))
             else:
                 ctx = self._sdpa(qkv, mask, B, S, nq, nkv, hd)
-            x, h = self._add_rmsnorm(x, F.linear(ctx, L["wo"]), L["ln2"], True)
-            gu = F.linear(h, L["wgu"])
+            x, h = self._add_rmsnorm(x, lin(ctx, L, "wo"), L["ln2"], True)
+            gu = lin(h, L, "wgu")
             inter = gu.shape[-1] // 2
             act = torch.empty((B, S, inter), dtype=x.dtype, device=x.device)
             _ffi.check(lib.ts_swiglu(dev, C.c_void_p(gu.data_ptr()), B * S, inter, dt, C.c_void_p(act.data_ptr()), stream))
             last = li + 1 == len(self.layers)
             gamma = m.norm.weight if last else self.layers[li + 1]["ln1"]
-            x, h = self._add_rmsnorm(x, F.linear(act, L["wd"]), gamma, not last)
+            x, h = self._add_rmsnorm(x, lin(act, L, "wd"), gamma, not last)
         return h
 
 
@@ -326,6 +374,7 @@ class FusedGemma3Forward:
         self.hq, self.hkv, self.hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         self.eps = float(cfg.rms_norm_eps)
         self.scaling = float(cfg.query_pre_attn_scalar) ** -0.5
+        self.pieces = False           # fp32 models: the GEMMs on the bf16 matrix pipe from bf16 pieces (pieces_linear)
         self._stamp = None
         self._gqa_native = True
         self._refresh()
@@ -336,7 +385,7 @@ class FusedGemma3Forward:
             yield from (att.q_proj.weight, att.k_proj.weight, att.v_proj.weight, mlp.gate_proj.weight, mlp.up_proj.weight)
 
     def _refresh(self):
-        stamp = tuple((p.data_ptr(), p._version, p.dtype) for p in self._sources())
+        stamp = tuple((p.data_ptr(), p._version, p.dtype) for p in self._sources()) + (self.pieces,)
         if stamp == self._stamp:
             return
         self._stamp = stamp
@@ -351,6 +400,10 @@ class FusedGemma3Forward:
                 "ln_pre_ffn": layer.pre_feedforward_layernorm.weight, "ln_post_ffn": layer.post_feedforward_layernorm.weight,
                 "type": att.layer_type,
             })
+            if self.pieces and self.layers[-1]["wo"].dtype == torch.float32:
+                L = self.layers[-1]
+                for name in ("wqkv", "wo", "wgu", "wd"):
+                    L[name + "_p"] = split_pieces(L[name].detach(), 1)
 
     @staticmethod
     def covers(model) -> bool:
@@ -408,9 +461,14 @@ class FusedGemma3Forward:
             neg = torch.finfo(x.dtype).min
             mask = torch.zeros((B, 1, 1, S), dtype=x.dtype, device=x.device).masked_fill_(~attention_mask[:, None, None, :].to(torch.bool), neg)
         nq, nkv, hd = self.hq * self.hd, self.hkv * self.hd, self.hd
+        pieces = self.pieces and x.dtype == torch.float32 and "wo_p" in self.layers[0]
+
+        def lin(t, L_, w):
+            return pieces_linear(t, L_[w + "_p"]) if pieces else F.linear(t, L_[w])
+
         h = self._norm(None, x, None, self.layers[0]["ln_in"], False)[1]
         for li, L in enumerate(self.layers):
-            qkv = F.linear(h, L["wqkv"])
+            qkv = lin(h, L, "wqkv")
             cos, sin = tables[L["type"]]
             _ffi.check(lib.ts_gemma_qk_norm_rope(dev, C.c_void_p(qkv.data_ptr()), C.c_void_p(L["qn"].data_ptr()), C.c_void_p(L["kn"].data_ptr()),
                                                  C.c_void_p(cos.data_ptr()), C.c_void_p(sin.data_ptr()), self.eps, B * S, S, self.hq, self.hkv,
@@ -429,12 +487,12 @@ class FusedGemma3Forward:
                 ctx = F.scaled_dot_product_attention(q, k.repeat_interleave(rep, dim=1), v.repeat_interleave(rep, dim=1),
                                                      attn_mask=mask, scale=self.scaling)
             ctx = ctx.transpose(1, 2).reshape(B, S, nq)
-            x, h = self._norm(F.linear(ctx, L["wo"]), x, L["ln_post_attn"], L["ln_pre_ffn"], True)
-            gu = F.linear(h, L["wgu"])
+            x, h = self._norm(lin(ctx, L, "wo"), x, L["ln_post_attn"], L["ln_pre_ffn"], True)
+            gu = lin(h, L, "wgu")
             inter = gu.shape[-1] // 2
             act = torch.empty((B, S, inter), dtype=x.dtype, device=x.device)
             _ffi.check(lib.ts_geglu(dev, C.c_void_p(gu.data_ptr()), B * S, inter, dt, C.c_void_p(act.data_ptr()), stream))
             last = li + 1 == len(self.layers)
             w_next = m.norm.weight if last else self.layers[li + 1]["ln_in"]
-            x, h = self._norm(F.linear(act, L["wd"]), x, L["ln_post_ffn"], w_next, not last)
+            x, h = self._norm(lin(act, L, "wd"), x, L["ln_post_ffn"], w_next, not last)
         return h
