@@ -1019,3 +1019,45 @@ def test_split_pieces_kernel_and_the_three_piece_linear():
     assert ((got_b.double() - ref - b.double()).abs() / scale).max().item() < 2e-5
     plain = torch.nn.functional.linear(x3d.bfloat16(), w.bfloat16()).double()
     assert ((plain - ref).abs() / scale).max().item() > 20 * ((got.double() - ref).abs() / scale).max().item()
+
+
+def test_float_attention_kernel_matches_fp64():
+    """ts_attention_float (fp32 in / out, exact-fp32 matrix instructions) against softmax(Q K^T * scale + masks) V in fp64 for the
+    three families' head shapes - BERT 12 x 64, Qwen3 16 / 8 x 128 causal grouped-query, Gemma3 3 / 1 x 256 with its own scale -
+    at 5 ... 128 tokens, with and without a key mask; the optional pieces are exactly ts_split_pieces of the output; shapes the
+    kernel does not serve are refused."""
+    import ctypes as C
+    import torch
+    from theoremsearch_amd import _ffi
+    from theoremsearch_amd.fused_forward import attention_float, split_pieces
+    g = torch.Generator(device="cpu").manual_seed(77)
+    for hq, hkv, hd, causal, scale in ((12, 12, 64, False, 64 ** -0.5), (16, 8, 128, True, 128 ** -0.5), (3, 1, 256, False, 0.0625)):
+        for B, S in ((3, 5), (2, 16), (3, 33), (2, 128)):
+            qkv = (torch.randn(B, S, (hq + 2 * hkv) * hd, generator=g) * 1.5).cuda()
+            q = qkv[..., :hq * hd].view(B, S, hq, hd).double()
+            k = qkv[..., hq * hd:(hq + hkv) * hd].view(B, S, hkv, hd).double().repeat_interleave(hq // hkv, dim=2)
+            v = qkv[..., (hq + hkv) * hd:].view(B, S, hkv, hd).double().repeat_interleave(hq // hkv, dim=2)
+            for use_mask in (False, True):
+                mask = None
+                if use_mask:
+                    mask = torch.ones(B, S, dtype=torch.int64)
+                    mask[0, S // 2 + 1:] = 0                                   # a padded sequence
+                    mask = mask.cuda()
+                s_ = torch.einsum("bqhd,bkhd->bhqk", q, k) * scale
+                if causal:
+                    s_ = s_.masked_fill(~torch.ones(S, S, dtype=torch.bool, device="cuda").tril_()[None, None], float("-inf"))
+                if mask is not None:
+                    s_ = s_.masked_fill(mask[:, None, None, :] == 0, float("-inf"))
+                want = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s_, dim=-1), v).reshape(B, S, hq * hd)
+                got, pieces = attention_float(qkv, mask, B, S, hq, hkv, hd, causal, scale, want_pieces=True)
+                torch.cuda.synchronize()
+                real = torch.ones(B, S, dtype=torch.bool, device="cuda") if mask is None else mask.bool()
+                err = (got.double() - want)[real].abs().max().item()
+                assert err < 2e-5, (hq, hkv, hd, causal, B, S, use_mask, err)
+                assert torch.equal(pieces.view(B, S, -1)[real], split_pieces(got.view(B * S, -1), 0).view(B, S, -1)[real])
+    out = torch.empty(1, 4, 64, device="cuda")
+    x = torch.randn(1, 200, 3 * 64, device="cuda")
+    for S, hd in ((200, 64), (4, 32)):
+        with pytest.raises(_ffi.TSearchError):
+            _ffi.check(_ffi.load().ts_attention_float(0, C.c_void_p(x.data_ptr()), None, 1, S, 1, 1, hd, 0, 0.125, C.c_void_p(out.data_ptr()),
+                                                      None, None))

@@ -53,48 +53,53 @@ def theorem_records(data: dict) -> list:
     return out
 
 
+def read_parsed_papers(papers_dir: str) -> list:
+    """Theorem records of every ``*.json`` under ``papers_dir``, in directory order; a file that cannot be read or lacks a
+    field is skipped with one line on stderr (the reference warns and goes on, app_create_embeddings.py:73-74)."""
+    import sys
+    records = []
+    for name in os.listdir(papers_dir):
+        if not name.endswith(".json"):
+            continue
+        path = os.path.join(papers_dir, name)
+        try:
+            with open(path, "r", encoding="utf-8") as f:
+                records.extend(theorem_records(json.load(f)))
+        except Exception as e:                                   # noqa: BLE001
+            print(f"skipped {path}: {e}", file=sys.stderr)
+    return records
+
+
+def write_library(out_dir: str, embeddings, records: list) -> tuple:
+    """The two files the apps load (app_create_embeddings.py:85-93): the tensor as ``torch.save`` writes it, the records pickled."""
+    os.makedirs(out_dir, exist_ok=True)
+    paths = os.path.join(out_dir, "corpus_embeddings.pt"), os.path.join(out_dir, "theorems_data.pkl")
+    torch.save(embeddings, paths[0])
+    with open(paths[1], "wb") as f:
+        pickle.dump(records, f)
+    return paths
+
+
 def create_embedding_library(model=None):
-    """Builds ``OUTPUT_DIR/corpus_embeddings.pt`` and ``OUTPUT_DIR/theorems_data.pkl``."""
-    print("Starting the embedding library creation process...")
-    print(f"Loading sentence transformer model: '{MODEL_NAME}'...")
+    """``PARSED_PAPERS_DIR/*.json`` -> ``OUTPUT_DIR/corpus_embeddings.pt`` + ``OUTPUT_DIR/theorems_data.pkl`` (the reference's
+    contract: module constants in, two files out, ``None`` back; a missing model, directory or corpus ends the call with a
+    message instead of an exception, as the script does).  ``model``: an encoder to reuse (default: ``SentenceEncoder(MODEL_NAME)``)."""
     if model is None:
         try:
             model = SentenceEncoder(MODEL_NAME)
-        except Exception as e:
-            print(f"Error loading model: {e}")
+        except Exception as e:                                   # noqa: BLE001
+            print(f"cannot load {MODEL_NAME!r}: {e}")
             return
-    if not os.path.exists(PARSED_PAPERS_DIR):
-        print(f"Error: The directory '{PARSED_PAPERS_DIR}' was not found.")
+    if not os.path.isdir(PARSED_PAPERS_DIR):
+        print(f"no parsed papers: {PARSED_PAPERS_DIR!r} is not a directory")
         return
-    json_files = [os.path.join(PARSED_PAPERS_DIR, f) for f in os.listdir(PARSED_PAPERS_DIR) if f.endswith(".json")]
-    if not json_files:
-        print(f"No parsed JSON files found in '{PARSED_PAPERS_DIR}'.")
+    records = read_parsed_papers(PARSED_PAPERS_DIR)
+    if not records:
+        print(f"no theorems under {PARSED_PAPERS_DIR!r}: nothing written")
         return
-    print(f"Found {len(json_files)} parsed paper(s). Loading and preparing data for embedding...")
-    all_theorems_data = []
-    for file_path in json_files:
-        try:
-            with open(file_path, "r", encoding="utf-8") as f:
-                all_theorems_data.extend(theorem_records(json.load(f)))
-        except Exception as e:
-            print(f"Warning: Could not process file {file_path}. Error: {e}")
-    if not all_theorems_data:
-        print("No theorems were extracted from the JSON files. Aborting.")
-        return
-    print(f"Embedding {len(all_theorems_data)} total theorems. This may take a while...")
-    corpus_texts = [item["text_to_embed"] for item in all_theorems_data]
-    corpus_embeddings = model.encode(corpus_texts, convert_to_tensor=True, show_progress_bar=True)
-    os.makedirs(OUTPUT_DIR, exist_ok=True)
-    embeddings_path = os.path.join(OUTPUT_DIR, "corpus_embeddings.pt")
-    data_path = os.path.join(OUTPUT_DIR, "theorems_data.pkl")
-    print(f"Saving embeddings tensor to '{embeddings_path}'...")
-    torch.save(corpus_embeddings, embeddings_path)
-    print(f"Saving theorem metadata to '{data_path}'...")
-    with open(data_path, "wb") as f:
-        pickle.dump(all_theorems_data, f)
-    print("\nEmbedding library created successfully!")
-    print(f"   - {len(all_theorems_data)} theorems embedded.")
-    print(f"   - Files saved in the '{OUTPUT_DIR}' directory.")
+    embeddings = model.encode([r["text_to_embed"] for r in records], convert_to_tensor=True, show_progress_bar=True)
+    paths = write_library(OUTPUT_DIR, embeddings, records)
+    print(f"{len(records)} theorems embedded -> {paths[0]}, {paths[1]}")
 
 
 def load_embedding_library(directory):

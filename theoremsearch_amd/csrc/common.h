@@ -59,6 +59,24 @@ __device__ __forceinline__ void round2_bf16_hw(float& a, float& b) {
     b = bf16_hi(p);
 }
 
+// Four consecutive fp32 values of a row as bf16 pieces for the fp32-class GEMM that reads them (split3_kernel below; activation
+// pattern [hi | lo | hi]): `prow` = the row's 3 d bf16 elements, `c` = the values' 4-element chunk.  fp32 producers write them
+// next to (or instead of) their fp32 output, so the GEMM's operand never makes a round trip through ts_split_pieces.
+__device__ __forceinline__ void store_pieces4(unsigned short* prow, int d, int c, const float* y) {
+    float hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hi[e] = bf16_to_f32(f32_to_bf16(y[e]));
+        lo[e] = y[e] - hi[e];
+    }
+    const uint2 ph = make_uint2(pack_bf16_hw(hi[0], hi[1]), pack_bf16_hw(hi[2], hi[3]));
+    const uint2 pl = make_uint2(pack_bf16_hw(lo[0], lo[1]), pack_bf16_hw(lo[2], lo[3]));
+    uint2* o = (uint2*)prow + c;
+    o[0] = ph;
+    o[d / 4] = pl;
+    o[2 * (d / 4)] = ph;
+}
+
 // ---- wave helpers ---------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

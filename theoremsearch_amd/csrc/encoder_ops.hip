@@ -34,9 +34,10 @@ extern "C" int ts_pool_normalize(int device, const void* hidden, int h_dtype, co
     return TS_OK;
 }
 
-extern "C" int ts_add_layernorm(int device, const void* a, const void* b, const void* gamma, const void* beta, float eps, int64_t rows,
-                                int32_t d, int dtype, void* out, void* stream) {
+static int add_layernorm_impl(int device, const void* a, const void* b, const void* gamma, const void* beta, float eps, int64_t rows,
+                              int32_t d, int dtype, void* out, unsigned short* pieces, void* stream) {
     if (!a || !b || !gamma || !beta || !out) return fail(TS_ERR_INVALID, "NULL argument");
+    if (pieces && (dtype != TS_F32 || ((uintptr_t)pieces & 7) != 0)) return fail(TS_ERR_INVALID, "pieces come from fp32 rows, 8-byte aligned");
     if (dtype != TS_F32 && dtype != TS_BF16) return fail(TS_ERR_INVALID, "dtype %d", dtype);
     const int vec = dtype == TS_BF16 ? 8 : 4;
     if (rows < 0 || d < vec || d % vec || d > 64 * kLnMax * vec)
@@ -51,15 +52,26 @@ extern "C" int ts_add_layernorm(int device, const void* a, const void* b, const 
     hipStream_t st = (hipStream_t)stream;
 #define TS_LN_LAUNCH(DT_)                                                                                        \
     do {                                                                                                         \
-        if (per_lane <= 1) add_layernorm_kernel<DT_, 1><<<grid, 256, 0, st>>>(a, b, gamma, beta, eps, rows, d, out); \
-        else if (per_lane <= 2) add_layernorm_kernel<DT_, 2><<<grid, 256, 0, st>>>(a, b, gamma, beta, eps, rows, d, out); \
-        else add_layernorm_kernel<DT_, 4><<<grid, 256, 0, st>>>(a, b, gamma, beta, eps, rows, d, out);           \
+        if (per_lane <= 1) add_layernorm_kernel<DT_, 1><<<grid, 256, 0, st>>>(a, b, gamma, beta, eps, rows, d, out, pieces); \
+        else if (per_lane <= 2) add_layernorm_kernel<DT_, 2><<<grid, 256, 0, st>>>(a, b, gamma, beta, eps, rows, d, out, pieces); \
+        else add_layernorm_kernel<DT_, 4><<<grid, 256, 0, st>>>(a, b, gamma, beta, eps, rows, d, out, pieces);   \
     } while (0)
     if (dtype == TS_F32) TS_LN_LAUNCH(0);
     else TS_LN_LAUNCH(1);
 #undef TS_LN_LAUNCH
     HIP_TRY(hipGetLastError());
     return TS_OK;
+}
+
+extern "C" int ts_add_layernorm(int device, const void* a, const void* b, const void* gamma, const void* beta, float eps, int64_t rows,
+                                int32_t d, int dtype, void* out, void* stream) {
+    return add_layernorm_impl(device, a, b, gamma, beta, eps, rows, d, dtype, out, nullptr, stream);
+}
+
+extern "C" int ts_add_layernorm_pieces(int device, const void* a, const void* b, const void* gamma, const void* beta, float eps,
+                                       int64_t rows, int32_t d, void* out, void* pieces, void* stream) {
+    if (!pieces) return fail(TS_ERR_INVALID, "NULL argument");
+    return add_layernorm_impl(device, a, b, gamma, beta, eps, rows, d, TS_F32, out, (unsigned short*)pieces, stream);
 }
 
 extern "C" int ts_embed_layernorm(int device, const int64_t* ids, const int64_t* type_ids, const void* word, const void* pos,
@@ -139,9 +151,10 @@ extern "C" int ts_attention_short(int device, const void* qkv, const int64_t* at
 }
 
 
-extern "C" int ts_add_rmsnorm(int device, const void* a, const void* b, const void* gamma, float eps, int64_t rows, int32_t d, int dtype,
-                              void* out_sum, void* out_norm, void* stream) {
+static int add_rmsnorm_impl(int device, const void* a, const void* b, const void* gamma, float eps, int64_t rows, int32_t d, int dtype,
+                            void* out_sum, void* out_norm, unsigned short* pieces, void* stream) {
     if (!a || !gamma || !out_norm) return fail(TS_ERR_INVALID, "NULL argument");
+    if (pieces && (dtype != TS_F32 || ((uintptr_t)pieces & 7) != 0)) return fail(TS_ERR_INVALID, "pieces come from fp32 rows, 8-byte aligned");
     if (dtype != TS_F32 && dtype != TS_BF16) return fail(TS_ERR_INVALID, "dtype %d", dtype);
     const int vec = dtype == TS_BF16 ? 8 : 4;
     if (rows < 0 || d < vec || d % vec || d > 64 * kLnMax * vec)
@@ -156,13 +169,64 @@ extern "C" int ts_add_rmsnorm(int device, const void* a, const void* b, const vo
     hipStream_t st = (hipStream_t)stream;
 #define TS_RMS_LAUNCH(DT_)                                                                                               \
     do {                                                                                                                 \
-        if (per_lane <= 1) add_rmsnorm_kernel<DT_, 1><<<grid, 256, 0, st>>>(a, b, gamma, eps, rows, d, out_sum, out_norm); \
-        else if (per_lane <= 2) add_rmsnorm_kernel<DT_, 2><<<grid, 256, 0, st>>>(a, b, gamma, eps, rows, d, out_sum, out_norm); \
-        else add_rmsnorm_kernel<DT_, 4><<<grid, 256, 0, st>>>(a, b, gamma, eps, rows, d, out_sum, out_norm);             \
+        if (per_lane <= 1) add_rmsnorm_kernel<DT_, 1><<<grid, 256, 0, st>>>(a, b, gamma, eps, rows, d, out_sum, out_norm, pieces); \
+        else if (per_lane <= 2) add_rmsnorm_kernel<DT_, 2><<<grid, 256, 0, st>>>(a, b, gamma, eps, rows, d, out_sum, out_norm, pieces); \
+        else add_rmsnorm_kernel<DT_, 4><<<grid, 256, 0, st>>>(a, b, gamma, eps, rows, d, out_sum, out_norm, pieces);     \
     } while (0)
     if (dtype == TS_F32) TS_RMS_LAUNCH(0);
     else TS_RMS_LAUNCH(1);
 #undef TS_RMS_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return TS_OK;
+}
+
+extern "C" int ts_add_rmsnorm(int device, const void* a, const void* b, const void* gamma, float eps, int64_t rows, int32_t d, int dtype,
+                              void* out_sum, void* out_norm, void* stream) {
+    return add_rmsnorm_impl(device, a, b, gamma, eps, rows, d, dtype, out_sum, out_norm, nullptr, stream);
+}
+
+extern "C" int ts_add_rmsnorm_pieces(int device, const void* a, const void* b, const void* gamma, float eps, int64_t rows, int32_t d,
+                                     void* out_sum, void* out_norm, void* pieces, void* stream) {
+    if (!pieces) return fail(TS_ERR_INVALID, "NULL argument");
+    return add_rmsnorm_impl(device, a, b, gamma, eps, rows, d, TS_F32, out_sum, out_norm, (unsigned short*)pieces, stream);
+}
+
+extern "C" int ts_attention_float(int device, const void* qkv, const int64_t* attention_mask, int32_t batch, int32_t seq, int32_t q_heads,
+                                int32_t kv_heads, int32_t head_dim, int causal, float scale, void* out, void* pieces, void* stream) {
+    if (!qkv || !out) return fail(TS_ERR_INVALID, "NULL argument");
+    if (batch < 0 || seq < 1 || q_heads < 1 || kv_heads < 1 || q_heads % kv_heads != 0)
+        return fail(TS_ERR_INVALID, "batch = %d, seq = %d, heads = %d over %d", batch, seq, q_heads, kv_heads);
+    if ((head_dim != 64 && head_dim != 128 && head_dim != 256) || seq > kAttnF32MaxSeq)
+        return fail(TS_ERR_UNSUPPORTED, "head size %d / %d tokens: this kernel serves head sizes 64, 128, 256 and at most %d tokens", head_dim,
+                    seq, kAttnF32MaxSeq);
+    if ((((uintptr_t)qkv | (uintptr_t)out) & 15) != 0 || (((uintptr_t)pieces) & 7) != 0)
+        return fail(TS_ERR_INVALID, "qkv and out must be 16-byte aligned, pieces 8-byte");
+    if (!(scale > 0.0f)) return fail(TS_ERR_INVALID, "scale must be positive");
+    if (batch == 0) return TS_OK;
+    TS_TRY(check_device(device));
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    const int T = (seq + 15) / 16;
+    const unsigned grid = (unsigned)((int64_t)batch * q_heads);
+    const unsigned threads = 64u * (unsigned)std::min(T, 4);
+    const float scale_log2e = scale * 1.4426950408889634f;
+#define TS_ATTN_F32(HD_, C_)                                                                                                  \
+    do {                                                                                                                      \
+        const int lds_ = attn_f32_lds(HD_, T);                                                                                \
+        static std::atomic<unsigned long long> attr_{0};                                                                      \
+        const unsigned long long bit_ = 1ull << (device & 63);                                                                \
+        if (!(attr_.load(std::memory_order_acquire) & bit_)) {                                                                \
+            HIP_TRY(hipFuncSetAttribute((const void*)attention_f32_kernel<HD_, C_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        attn_f32_lds(HD_, kAttnF32MaxSeq / 16)));                                             \
+            attr_.fetch_or(bit_, std::memory_order_release);                                                                  \
+        }                                                                                                                     \
+        attention_f32_kernel<HD_, C_><<<grid, threads, lds_, st>>>((const float*)qkv, attention_mask, batch, seq, q_heads, kv_heads, \
+                                                                     scale_log2e, (float*)out, (unsigned short*)pieces);     \
+    } while (0)
+    if (head_dim == 64) { if (causal) TS_ATTN_F32(64, true); else TS_ATTN_F32(64, false); }
+    else if (head_dim == 128) { if (causal) TS_ATTN_F32(128, true); else TS_ATTN_F32(128, false); }
+    else { if (causal) TS_ATTN_F32(256, true); else TS_ATTN_F32(256, false); }
+#undef TS_ATTN_F32
     HIP_TRY(hipGetLastError());
     return TS_OK;
 }
@@ -291,9 +355,10 @@ extern "C" int ts_gemma_qk_norm_rope(int device, void* qkv, const void* q_weight
                                true, stream);
 }
 
-extern "C" int ts_gemma_norm(int device, const void* y, const void* x, const void* w_post, const void* w_next, float eps, int64_t rows,
-                             int32_t d, int dtype, void* out_sum, void* out_norm, void* stream) {
+static int gemma_norm_impl(int device, const void* y, const void* x, const void* w_post, const void* w_next, float eps, int64_t rows,
+                           int32_t d, int dtype, void* out_sum, void* out_norm, unsigned short* pieces, void* stream) {
     if (!x || !w_next || !out_norm || (y && !w_post)) return fail(TS_ERR_INVALID, "NULL argument");
+    if (pieces && (dtype != TS_F32 || ((uintptr_t)pieces & 7) != 0)) return fail(TS_ERR_INVALID, "pieces come from fp32 rows, 8-byte aligned");
     if (dtype != TS_F32 && dtype != TS_BF16) return fail(TS_ERR_INVALID, "dtype %d", dtype);
     const int vec = dtype == TS_BF16 ? 8 : 4;
     if (rows < 0 || d < vec || d % vec || d > 64 * kLnMax * vec)
@@ -308,13 +373,41 @@ extern "C" int ts_gemma_norm(int device, const void* y, const void* x, const voi
     hipStream_t st = (hipStream_t)stream;
 #define TS_GN_LAUNCH(DT_)                                                                                                      \
     do {                                                                                                                       \
-        if (per_lane <= 1) gemma_norm_kernel<DT_, 1><<<grid, 256, 0, st>>>(y, x, w_post, w_next, eps, rows, d, out_sum, out_norm); \
-        else if (per_lane <= 2) gemma_norm_kernel<DT_, 2><<<grid, 256, 0, st>>>(y, x, w_post, w_next, eps, rows, d, out_sum, out_norm); \
-        else gemma_norm_kernel<DT_, 4><<<grid, 256, 0, st>>>(y, x, w_post, w_next, eps, rows, d, out_sum, out_norm);           \
+        if (per_lane <= 1) gemma_norm_kernel<DT_, 1><<<grid, 256, 0, st>>>(y, x, w_post, w_next, eps, rows, d, out_sum, out_norm, pieces); \
+        else if (per_lane <= 2) gemma_norm_kernel<DT_, 2><<<grid, 256, 0, st>>>(y, x, w_post, w_next, eps, rows, d, out_sum, out_norm, pieces); \
+        else gemma_norm_kernel<DT_, 4><<<grid, 256, 0, st>>>(y, x, w_post, w_next, eps, rows, d, out_sum, out_norm, pieces);   \
     } while (0)
     if (dtype == TS_F32) TS_GN_LAUNCH(0);
     else TS_GN_LAUNCH(1);
 #undef TS_GN_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return TS_OK;
+}
+
+extern "C" int ts_gemma_norm(int device, const void* y, const void* x, const void* w_post, const void* w_next, float eps, int64_t rows,
+                             int32_t d, int dtype, void* out_sum, void* out_norm, void* stream) {
+    return gemma_norm_impl(device, y, x, w_post, w_next, eps, rows, d, dtype, out_sum, out_norm, nullptr, stream);
+}
+
+extern "C" int ts_gemma_norm_pieces(int device, const void* y, const void* x, const void* w_post, const void* w_next, float eps,
+                                    int64_t rows, int32_t d, void* out_sum, void* out_norm, void* pieces, void* stream) {
+    if (!pieces) return fail(TS_ERR_INVALID, "NULL argument");
+    return gemma_norm_impl(device, y, x, w_post, w_next, eps, rows, d, TS_F32, out_sum, out_norm, (unsigned short*)pieces, stream);
+}
+
+extern "C" int ts_act_pieces(int device, const void* x, int64_t rows, int32_t n, int kind, void* pieces, void* stream) {
+    if (!x || !pieces) return fail(TS_ERR_INVALID, "NULL argument");
+    if (rows < 0 || n < 4 || n % 4 || kind < 0 || kind > 2) return fail(TS_ERR_INVALID, "n = %d must be a multiple of 4, kind 0 / 1 / 2", n);
+    if ((((uintptr_t)x) & 15) != 0 || (((uintptr_t)pieces) & 7) != 0) return fail(TS_ERR_INVALID, "x must be 16-byte, pieces 8-byte aligned");
+    if (rows == 0) return TS_OK;
+    TS_TRY(check_device(device));
+    HIP_TRY(hipSetDevice(device));
+    const int64_t total = rows * (n / 4);
+    const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 16384);
+    hipStream_t st = (hipStream_t)stream;
+    if (kind == 0) act_pieces_kernel<0><<<grid, 256, 0, st>>>((const float*)x, rows, n, (unsigned short*)pieces);
+    else if (kind == 1) act_pieces_kernel<1><<<grid, 256, 0, st>>>((const float*)x, rows, n, (unsigned short*)pieces);
+    else act_pieces_kernel<2><<<grid, 256, 0, st>>>((const float*)x, rows, n, (unsigned short*)pieces);
     HIP_TRY(hipGetLastError());
     return TS_OK;
 }

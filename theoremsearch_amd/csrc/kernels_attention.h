@@ -709,4 +709,135 @@ __global__ void __launch_bounds__(64 * R) attention_gqa_rows_kernel(const unsign
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// fp32 attention (the encoder at the reference's fp32 storage: SentenceTransformer(name) without a dtype, streamlit_app.py:55,173)
+// for sequences of at most 128 tokens, any of the three families: softmax(Q K^T * scale + key mask [+ causal]) V with every
+// product on v_mfma_f32_16x16x4_f32 - exact fp32 multiplies, fp32 accumulation - straight from the stacked projection's output
+// [B][S][(HQ + 2 HKV) HD] into the context layout [B][S][HQ HD] (and, for the fp32-class GEMM behind it, its bf16 pieces).
+// torch's attention on this layout first copies q, k, v and the context (four launches of 34 us each per BERT layer at 256 x 128
+// tokens, r05_c5 kernel stats) around a 317 us flash launch; here a workgroup per (sequence, query head) holds V^T in LDS and
+// each wave walks query tiles of 16:
+//   * S^T = K Q^T per key tile: A = K rows (lane (key r16, g): K[key][16 s + 4 g .. + 4), 16 bytes from global / L2), B = Q rows of
+//     the tile (same chunks, loaded once per tile); MFMA i of a chunk multiplies float i of both: k = 16 s + 4 g + i - a fixed
+//     permutation of the head dimension in the fp32 sum;  D[key 4 g + r][query r16];
+//   * softmax over the keys of a query = over r, the key tiles (registers) and the four lane groups (xor 16, 32), in fp32;
+//   * O^T = V^T P^T: B = P^T is the score registers as they lie (MFMA r of key tile kj takes keys 16 kj + 4 g + r), A = V^T
+//     [d r16][those four keys] = ONE ds_read_b128 of the transposed image (pitch SP + 4 floats: conflict-free);
+//     D[d 4 g + r][query r16]: four consecutive d per lane, stored as 16 bytes.
+// HD = head size (64 BERT, 128 Qwen3, 256 Gemma3); CAUSAL skips key tiles past the query tile; grouped-query: KV head = h / (HQ / HKV).
+constexpr int kAttnF32MaxSeq = 128;
+constexpr int attn_f32_lds(int HD, int T) { return HD * (16 * T + 4) * 4; }
+
+template <int HD, bool CAUSAL>
+__global__ void __launch_bounds__(256) attention_f32_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ mask, int B, int S,
+                                                             int HQ, int HKV, float scale_log2e, float* __restrict__ out,
+                                                             unsigned short* __restrict__ pieces) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_attn[];
+    float* sVT = (float*)smem_attn;
+    const int T = (S + 15) / 16, SP = 16 * T, PP = SP + 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int b = blockIdx.x / HQ, h = blockIdx.x - b * HQ;
+    const int hk = h / (HQ / HKV);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int64_t tok = (int64_t)(HQ + 2 * HKV) * HD;                   // floats per token of the projection's output
+    const float* base = qkv + (int64_t)b * S * tok;
+    const float* qb = base + (int64_t)h * HD;
+    const float* kb = base + (int64_t)(HQ + hk) * HD;
+    const float* vb = base + (int64_t)(HQ + HKV + hk) * HD;
+    // V^T [d][key] in LDS (keys past the sequence: zeros - 0 x P = 0): 16 bytes of a V row per thread, four 4-byte stores
+    for (int i = threadIdx.x; i < SP * (HD / 4); i += blockDim.x) {
+        const int key = i / (HD / 4), c = i - key * (HD / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (key < S) v = *(const float4*)(vb + (int64_t)key * tok + 4 * c);
+        sVT[(4 * c + 0) * PP + key] = v.x;
+        sVT[(4 * c + 1) * PP + key] = v.y;
+        sVT[(4 * c + 2) * PP + key] = v.z;
+        sVT[(4 * c + 3) * PP + key] = v.w;
+    }
+    __syncthreads();
+    constexpr int KC = HD / 16;                                          // 16-float chunks of a row
+    constexpr int TM = kAttnF32MaxSeq / 16;
+    for (int qi = wave; qi < T; qi += nwaves) {
+        const int qrow = min(16 * qi + r16, S - 1);
+        float4 qf[KC];
+#pragma unroll
+        for (int s = 0; s < KC; ++s) qf[s] = *(const float4*)(qb + (int64_t)qrow * tok + 16 * s + 4 * g);
+        const int kt_end = CAUSAL ? qi + 1 : T;                          // key tiles that hold an allowed key
+        f32x4 sc[TM];
+#pragma unroll
+        for (int kj = 0; kj < TM; ++kj) {
+            sc[kj] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kj < kt_end) {
+                const int krow = min(16 * kj + r16, S - 1);
+                float4 kf[KC];
+#pragma unroll
+                for (int s = 0; s < KC; ++s) kf[s] = *(const float4*)(kb + (int64_t)krow * tok + 16 * s + 4 * g);
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KC; ++s) {
+                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].x, qf[s].x, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].y, qf[s].y, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].z, qf[s].z, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].w, qf[s].w, a, 0, 0, 0);
+                }
+                sc[kj] = a;
+            }
+        }
+        // lane (g, r16): scores of keys 16 kj + 4 g + r for query 16 qi + r16
+        const int qpos = 16 * qi + r16;
+        float m = -INFINITY;
+#pragma unroll
+        for (int kj = 0; kj < TM; ++kj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * kj + 4 * g + r;
+                const bool ok = kj < kt_end && key < S && (!mask || mask[(int64_t)b * S + key] != 0) && (!CAUSAL || key <= qpos);
+                sc[kj][r] = ok ? sc[kj][r] : -INFINITY;
+                m = fmaxf(m, sc[kj][r]);
+            }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.0f;
+#pragma unroll
+        for (int kj = 0; kj < TM; ++kj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = sc[kj][r] > -INFINITY ? exp2f((sc[kj][r] - m) * scale_log2e) : 0.0f;
+                sc[kj][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;                // a query without a single allowed key: zeros
+#pragma unroll
+        for (int kj = 0; kj < TM; ++kj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[kj][r] *= inv;
+        // O^T[d][q]
+        const bool live = qpos < S;
+        float* orow = out + ((int64_t)b * S + min(qpos, S - 1)) * HQ * HD + (int64_t)h * HD;
+#pragma unroll
+        for (int dj = 0; dj < KC; ++dj) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kj = 0; kj < TM; ++kj)
+                if (kj < kt_end) {
+                    const float4 vf = *(const float4*)(sVT + (16 * dj + r16) * PP + 16 * kj + 4 * g);
+                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.x, sc[kj][0], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.y, sc[kj][1], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.z, sc[kj][2], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.w, sc[kj][3], a, 0, 0, 0);
+                }
+            if (live) {
+                *(float4*)(orow + 16 * dj + 4 * g) = make_float4(a[0], a[1], a[2], a[3]);
+                if (pieces) {
+                    const float y[4] = {a[0], a[1], a[2], a[3]};
+                    const int dtot = HQ * HD;
+                    store_pieces4(pieces + ((int64_t)b * S + qpos) * 3 * dtot, dtot, (h * HD + 16 * dj + 4 * g) / 4, y);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace ts

@@ -175,7 +175,7 @@ constexpr int kLnMax = 4;
 template <int DT, int LN = kLnMax>
 __global__ void __launch_bounds__(256) add_layernorm_kernel(const void* a, const void* b,      // `out` may alias a or b: no restrict
                                                              const void* __restrict__ gamma, const void* __restrict__ beta, float eps,
-                                                             int64_t rows, int d, void* out) {
+                                                             int64_t rows, int d, void* out, unsigned short* pieces = nullptr) {
     constexpr int VEC = DT == 0 ? 4 : 8;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -257,6 +257,7 @@ __global__ void __launch_bounds__(256) add_layernorm_kernel(const void* a, const
                 o.w = (u32)f32_to_bf16(y[6]) | ((u32)f32_to_bf16(y[7]) << 16);
             }
             po[c] = o;
+            if (DT == 0 && pieces) store_pieces4(pieces + row * 3 * (int64_t)d, d, c, y);
         }
     }
 }
@@ -398,7 +399,7 @@ __device__ __forceinline__ float enc_round(float v) { return DT == 0 ? v : bf16_
 // b may be NULL (a plain RMSNorm: the first norm of the first layer).  One wave per row, LN 16-byte accesses per lane.
 template <int DT, int LN>
 __global__ void __launch_bounds__(256) add_rmsnorm_kernel(const void* a, const void* b, const void* __restrict__ gamma, float eps,
-                                                           int64_t rows, int d, void* out_sum, void* out_norm) {
+                                                           int64_t rows, int d, void* out_sum, void* out_norm, unsigned short* pieces = nullptr) {
     constexpr int VEC = DT == 0 ? 4 : 8;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -447,6 +448,7 @@ __global__ void __launch_bounds__(256) add_rmsnorm_kernel(const void* a, const v
             for (int e = 0; e < VEC; ++e) y[e] = g[e] * enc_round<DT>(x[j][e] * rstd);
             if (ps) ps[c] = enc_pack<DT>(x[j]);
             po[c] = enc_pack<DT>(y);
+            if (DT == 0 && pieces) store_pieces4(pieces + row * 3 * (int64_t)d, d, c, y);
         }
     }
 }
@@ -575,7 +577,7 @@ __global__ void __launch_bounds__(256) split3_kernel(const float* __restrict__ x
 template <int DT, int LN>
 __global__ void __launch_bounds__(256) gemma_norm_kernel(const void* y, const void* x, const void* __restrict__ w_post,
                                                           const void* __restrict__ w_next, float eps, int64_t rows, int d, void* out_sum,
-                                                          void* out_norm) {
+                                                          void* out_norm, unsigned short* pieces = nullptr) {
     constexpr int VEC = DT == 0 ? 4 : 8;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -646,6 +648,7 @@ __global__ void __launch_bounds__(256) gemma_norm_kernel(const void* y, const vo
             for (int e = 0; e < VEC; ++e) h[e] = (s[j][e] * rstd) * (1.0f + wn[e]);
             if (ps) ps[c] = enc_pack<DT>(s[j]);
             po[c] = enc_pack<DT>(h);
+            if (DT == 0 && pieces) store_pieces4(pieces + row * 3 * (int64_t)d, d, c, h);
         }
     }
 }
@@ -672,6 +675,42 @@ __global__ void __launch_bounds__(256) geglu_kernel(const void* __restrict__ gat
             y[e] = enc_round<DT>(0.5f * v * (1.0f + tanhf(inner))) * u[e];
         }
         ((uint4*)out)[i] = enc_pack<DT>(y);
+    }
+}
+
+// fp32 activations straight into the pieces of the GEMM that follows (fp32_gemm = "bf16x3"): one pass instead of the activation's
+// own (read + write fp32) and ts_split_pieces' (read fp32 + write pieces).
+//   KIND 0: y = gelu(x) (exact erf form: BertIntermediate with hidden_act = "gelu"), x [rows][n]
+//   KIND 1: y = silu(gate) * up (Qwen3MLP),  KIND 2: y = gelu_tanh(gate) * up (Gemma3MLP), x = [rows][2 n]: gate columns, then up
+// out [rows][3 n] bf16 = [hi | lo | hi] of y.
+template <int KIND>
+__global__ void __launch_bounds__(256) act_pieces_kernel(const float* __restrict__ x, int64_t rows, int n, unsigned short* __restrict__ out) {
+    const int per_row = n / 4;
+    const int64_t total = rows * per_row;
+    const int in_row = (KIND == 0 ? 1 : 2) * per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / per_row;
+        const int c = (int)(i - r * per_row);
+        const float4 g4 = ((const float4*)x)[r * in_row + c];
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+        float y[4];
+        if (KIND == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = 0.5f * g[e] * (1.0f + erff(g[e] * 0.7071067811865476f));
+        } else {
+            const float4 u4 = ((const float4*)x)[r * in_row + per_row + c];
+            const float u[4] = {u4.x, u4.y, u4.z, u4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (KIND == 1) {
+                    y[e] = (g[e] / (1.0f + expf(-g[e]))) * u[e];
+                } else {
+                    const float inner = 0.7978845608028654f * (g[e] + 0.044715f * g[e] * g[e] * g[e]);
+                    y[e] = (0.5f * g[e] * (1.0f + tanhf(inner))) * u[e];
+                }
+            }
+        }
+        store_pieces4(out + r * 3 * (int64_t)n, n, c, y);
     }
 }
 

@@ -46,6 +46,48 @@ def pieces_linear(x: torch.Tensor, w_pieces: torch.Tensor, bias: Optional[torch.
     return y.view(*shape[:-1], w_pieces.shape[0])
 
 
+def pieces_mm(x_pieces: torch.Tensor, w_pieces: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The GEMM of `pieces_linear` on operands that already are pieces (``[rows x 3k]`` bf16 each): fp32 ``[rows x n]``."""
+    if bias is not None:
+        return torch.addmm(bias, x_pieces, w_pieces.t(), out_dtype=torch.float32)
+    return torch.mm(x_pieces, w_pieces.t(), out_dtype=torch.float32)
+
+
+def act_pieces(x: torch.Tensor, kind: int) -> torch.Tensor:
+    """fp32 activation straight into pieces (``ts_act_pieces``): kind 0 = gelu (erf) of ``[rows x n]``; 1 = silu(gate) * up,
+    2 = gelu_tanh(gate) * up of ``[rows x 2n]``.  Returns bf16 ``[rows x 3n]``."""
+    import ctypes as C
+    from . import _ffi
+    x = x.contiguous()
+    rows = x.numel() // x.shape[-1]
+    n = x.shape[-1] if kind == 0 else x.shape[-1] // 2
+    out = torch.empty((rows, 3 * n), dtype=torch.bfloat16, device=x.device)
+    _ffi.check(_ffi.load().ts_act_pieces(x.device.index or 0, C.c_void_p(x.data_ptr()), rows, n, kind, C.c_void_p(out.data_ptr()),
+                                         C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+    return out
+
+
+def attention_float(qkv: torch.Tensor, key_mask: Optional[torch.Tensor], B: int, S: int, hq: int, hkv: int, hd: int, causal: bool,
+                    scale: float, want_pieces: bool = False):
+    """fp32 attention of at most 128 tokens on the exact-fp32 matrix instructions, straight from the stacked projection's output
+    ``qkv [B x S x (hq + 2 hkv) hd]`` (``ts_attention_float``): ``(context fp32 [B x S x hq hd], its bf16 pieces or None)``."""
+    import ctypes as C
+    from . import _ffi
+    qkv = qkv.contiguous()
+    ctx = torch.empty((B, S, hq * hd), dtype=torch.float32, device=qkv.device)
+    pieces = torch.empty((B * S, 3 * hq * hd), dtype=torch.bfloat16, device=qkv.device) if want_pieces else None
+    _ffi.check(_ffi.load().ts_attention_float(
+        qkv.device.index or 0, C.c_void_p(qkv.data_ptr()), C.c_void_p(key_mask.data_ptr()) if key_mask is not None else None, B, S, hq,
+        hkv, hd, 1 if causal else 0, float(scale), C.c_void_p(ctx.data_ptr()), C.c_void_p(pieces.data_ptr()) if pieces is not None else None,
+        C.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream)))
+    return ctx, pieces
+
+
+def float_attention_applies(x: torch.Tensor, S: int, hd: int) -> bool:
+    """fp32 hidden states, at most 128 tokens, a head size the kernel serves; TS_ENCODER_ATTENTION=0 keeps torch's attention."""
+    return (x.dtype == torch.float32 and hd in (64, 128, 256) and S <= 128 and os.environ.get("TS_ENCODER_ATTENTION", "1") != "0")
+
+
 class FusedBertForward:
     """The forward of a BERT-family encoder (``BertModel``: what ``math-similarity/Bert-MLM_arXiv-MP-class_zbMath`` is,
     compare_embeddings.py:11) with the launches that do not pay for themselves folded together:
@@ -147,6 +189,20 @@ class FusedBertForward:
             B, S, self.heads, 64, C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream)))
         return out
 
+    def _add_ln_pieces(self, a: torch.Tensor, b: torch.Tensor, ln):
+        """`_add_ln` of fp32 operands that also writes the pieces of its output: ``(out fp32, pieces bf16 [rows x 3d])``."""
+        import ctypes as C
+        from . import _ffi
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty_like(a)
+        rows, d = a.numel() // a.shape[-1], a.shape[-1]
+        pieces = torch.empty((rows, 3 * d), dtype=torch.bfloat16, device=a.device)
+        _ffi.check(_ffi.load().ts_add_layernorm_pieces(
+            a.device.index or 0, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(ln.weight.data_ptr()),
+            C.c_void_p(ln.bias.data_ptr()), self.eps, rows, d, C.c_void_p(out.data_ptr()), C.c_void_p(pieces.data_ptr()),
+            C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)))
+        return out, pieces
+
     def _add_ln(self, a: torch.Tensor, b: torch.Tensor, ln) -> torch.Tensor:
         import ctypes as C
         from . import _ffi
@@ -173,25 +229,48 @@ class FusedBertForward:
         # ONE wave per (sequence, head), straight from the fused projection to the context layout (``ts_attention_short``)
         short = x.dtype == torch.bfloat16 and hd == 64 and S <= 128 and os.environ.get("TS_ENCODER_ATTENTION", "1") != "0"
         # (the most negative finite value, not -inf: a sequence without a single token would otherwise soften to NaN)
-        mask = None if (no_padding or short) else torch.zeros((B, 1, 1, S), dtype=x.dtype, device=x.device).masked_fill_(
+        short32 = float_attention_applies(x, S, hd)          # fp32: the library's fp32 attention (ts_attention_float)
+        mask = None if (no_padding or short or short32) else torch.zeros((B, 1, 1, S), dtype=x.dtype, device=x.device).masked_fill_(
             ~attention_mask[:, None, None, :].to(torch.bool), torch.finfo(x.dtype).min)
-        key_mask = None if (no_padding or not short) else attention_mask.to(torch.int64).contiguous()
+        key_mask = None if (no_padding or not (short or short32)) else attention_mask.to(torch.int64).contiguous()
         pieces = self.pieces and x.dtype == torch.float32 and "wo_p" in self.layers[0]
-
-        def lin(t, L_, w, b):
-            return pieces_linear(t, L_[w + "_p"], L_[b]) if pieces else F.linear(t, L_[w], L_[b])
-
+        if pieces:
+            return self._forward_pieces(x, mask, key_mask, short32, B, S, H, hd)
         for L in self.layers:
-            qkv = lin(x, L, "wqkv", "bqkv")
+            qkv = F.linear(x, L["wqkv"], L["bqkv"])
             if short:
                 ctx = self._attention(qkv, key_mask, B, S)
+            elif short32:
+                ctx = attention_float(qkv, key_mask, B, S, self.heads, self.heads, hd, False, hd ** -0.5)[0]
             else:
                 qkv = qkv.view(B, S, 3, self.heads, hd).permute(2, 0, 3, 1, 4)
                 ctx = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], attn_mask=mask)
                 ctx = ctx.transpose(1, 2).reshape(B, S, H)
-            x = self._add_ln(lin(ctx, L, "wo", "bo"), x, L["ln1"])
-            h = self.act(lin(x, L, "w1", "b1"))
-            x = self._add_ln(lin(h, L, "w2", "b2"), x, L["ln2"])
+            x = self._add_ln(F.linear(ctx, L["wo"], L["bo"]), x, L["ln1"])
+            h = self.act(F.linear(x, L["w1"], L["b1"]))
+            x = self._add_ln(F.linear(h, L["w2"], L["b2"]), x, L["ln2"])
+        return x
+
+    def _forward_pieces(self, x: torch.Tensor, mask: Optional[torch.Tensor], key_mask: Optional[torch.Tensor], short32: bool, B: int,
+                        S: int, H: int, hd: int) -> torch.Tensor:
+        """The layers of an fp32 model with every GEMM on the bf16 matrix pipe (``fp32_gemm="bf16x3"``): weights are pieces
+        (``_refresh``), every activation reaches its GEMM as pieces written by the kernel that produced it (LayerNorm, GELU, the
+        fp32 attention up to 128 tokens; beyond, torch's attention output passes through ``ts_split_pieces``)."""
+        F = torch.nn.functional
+        exact_gelu = self.cfg.hidden_act == "gelu"
+        xp = split_pieces(x.view(B * S, H), 0)
+        for L in self.layers:
+            qkv = pieces_mm(xp, L["wqkv_p"], L["bqkv"])
+            if short32:                # the attention writes the pieces of its output itself
+                cp = attention_float(qkv, key_mask, B, S, self.heads, self.heads, hd, False, hd ** -0.5, want_pieces=True)[1]
+            else:
+                qkv = qkv.view(B, S, 3, self.heads, hd).permute(2, 0, 3, 1, 4)
+                ctx = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], attn_mask=mask)
+                cp = split_pieces(ctx.transpose(1, 2).reshape(B * S, H), 0)
+            x, xp = self._add_ln_pieces(pieces_mm(cp, L["wo_p"], L["bo"]).view(B, S, H), x, L["ln1"])
+            h = pieces_mm(xp, L["w1_p"], L["b1"])
+            hp = act_pieces(h, 0) if exact_gelu else split_pieces(self.act(h), 0)
+            x, xp = self._add_ln_pieces(pieces_mm(hp, L["w2_p"], L["b2"]).view(B, S, H), x, L["ln2"])
         return x
 
 
@@ -277,6 +356,21 @@ class FusedQwen3Forward:
             C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)))
         return (new_res if new_res is not None else a), out
 
+    def _add_rmsnorm_pieces(self, a: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tensor, want_sum: bool):
+        """`_add_rmsnorm` of fp32 operands that also writes the pieces of the normalised rows: ``(residual, normed, pieces)``."""
+        import ctypes as C
+        from . import _ffi
+        d = a.shape[-1]
+        rows = a.numel() // d
+        out = torch.empty_like(a)
+        new_res = torch.empty_like(a) if (want_sum and b is not None) else None
+        pieces = torch.empty((rows, 3 * d), dtype=torch.bfloat16, device=a.device)
+        _ffi.check(_ffi.load().ts_add_rmsnorm_pieces(
+            a.device.index or 0, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()) if b is not None else None,
+            C.c_void_p(gamma.data_ptr()), self.eps, rows, d, C.c_void_p(new_res.data_ptr()) if new_res is not None else None,
+            C.c_void_p(out.data_ptr()), C.c_void_p(pieces.data_ptr()), C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)))
+        return (new_res if new_res is not None else a), out, pieces
+
     def _sdpa(self, qkv: torch.Tensor, mask: Optional[torch.Tensor], B: int, S: int, nq: int, nkv: int, hd: int) -> torch.Tensor:
         """torch's attention on the stacked projection (longer sequences, fp32): causal, grouped-query, as the model's own sdpa path."""
         F = torch.nn.functional
@@ -315,8 +409,9 @@ class FusedQwen3Forward:
         # short sequences in bf16: the library's own causal grouped-query attention (TS_ENCODER_ATTENTION=0 keeps torch's)
         short = (x.dtype == torch.bfloat16 and self.hd == 128 and S <= 128 and x.is_contiguous() and
                  os.environ.get("TS_ENCODER_ATTENTION", "1") != "0")
-        key_mask = None if (no_padding or not short) else attention_mask.to(torch.int64).contiguous()
-        if not no_padding and not short:
+        short32 = float_attention_applies(x, S, self.hd)      # fp32: the library's fp32 attention (causal, grouped-query)
+        key_mask = None if (no_padding or not (short or short32)) else attention_mask.to(torch.int64).contiguous()
+        if not no_padding and not short and not short32:
             # causal, and padding keys are never attended to (the most negative finite value: rows of padding stay finite)
             neg = torch.finfo(x.dtype).min
             causal = torch.ones((S, S), dtype=torch.bool, device=x.device).tril_()
@@ -324,13 +419,28 @@ class FusedQwen3Forward:
             mask = torch.zeros((B, 1, S, S), dtype=x.dtype, device=x.device).masked_fill_(~keep, neg)
         nq, nkv, hd = self.hq * self.hd, self.hkv * self.hd, self.hd
         pieces = self.pieces and x.dtype == torch.float32 and "wo_p" in self.layers[0]
-
-        def lin(t, L_, w):
-            return pieces_linear(t, L_[w + "_p"]) if pieces else F.linear(t, L_[w])
-
+        if pieces:
+            # every GEMM on the bf16 matrix pipe from pieces: weights split once (`_refresh`), activations written as pieces by
+            # the kernel that produces them (RMSNorm, SwiGLU); only torch's attention output passes through ts_split_pieces
+            _, h, hp = self._add_rmsnorm_pieces(x, None, self.layers[0]["ln1"], False)
+            for li, L in enumerate(self.layers):
+                qkv = pieces_mm(hp, L["wqkv_p"]).view(B, S, -1)
+                _ffi.check(lib.ts_qk_norm_rope(dev, C.c_void_p(qkv.data_ptr()), C.c_void_p(L["qn"].data_ptr()), C.c_void_p(L["kn"].data_ptr()),
+                                               C.c_void_p(cos.data_ptr()), C.c_void_p(sin.data_ptr()), self.eps, B * S, S, self.hq, self.hkv,
+                                               hd, dt, stream))
+                if short32:
+                    cp = attention_float(qkv, key_mask, B, S, self.hq, self.hkv, hd, True, hd ** -0.5, want_pieces=True)[1]
+                else:
+                    cp = split_pieces(self._sdpa(qkv, mask, B, S, nq, nkv, hd).reshape(B * S, nq), 0)
+                x, h, hp = self._add_rmsnorm_pieces(x, pieces_mm(cp, L["wo_p"]).view(B, S, H), L["ln2"], True)
+                ap = act_pieces(pieces_mm(hp, L["wgu_p"]), 1)
+                last = li + 1 == len(self.layers)
+                gamma = m.norm.weight if last else self.layers[li + 1]["ln1"]
+                x, h, hp = self._add_rmsnorm_pieces(x, pieces_mm(ap, L["wd_p"]).view(B, S, H), gamma, not last)
+            return h
         h = self._add_rmsnorm(x, None, self.layers[0]["ln1"], False)[1]
         for li, L in enumerate(self.layers):
-            qkv = lin(h, L, "wqkv")
+            qkv = F.linear(h, L["wqkv"])
             _ffi.check(lib.ts_qk_norm_rope(dev, C.c_void_p(qkv.data_ptr()), C.c_void_p(L["qn"].data_ptr()), C.c_void_p(L["kn"].data_ptr()),
                                            C.c_void_p(cos.data_ptr()), C.c_void_p(sin.data_ptr()), self.eps, B * S, S, self.hq, self.hkv,
                                            hd, dt, stream))
@@ -339,16 +449,18 @@ class FusedQwen3Forward:
                 ctx = torch.empty((B, S, nq), dtype=x.dtype, device=x.device)
                 _ffi.check(lib.ts_attention_gqa(dev, C.c_void_p(qkv.data_ptr()), C.c_void_p(key_mask.data_ptr()) if key_mask is not None else None,
                                                B, S, self.hq, self.hkv, hd, 1, C.c_void_p(ctx.data_ptr()), stream))
+            elif short32:
+                ctx = attention_float(qkv, key_mask, B, S, self.hq, self.hkv, hd, True, hd ** -0.5)[0]
             else:
                 ctx = self._sdpa(qkv, mask, B, S, nq, nkv, hd)
-            x, h = self._add_rmsnorm(x, lin(ctx, L, "wo"), L["ln2"], True)
-            gu = lin(h, L, "wgu")
+            x, h = self._add_rmsnorm(x, F.linear(ctx, L["wo"]), L["ln2"], True)
+            gu = F.linear(h, L["wgu"])
             inter = gu.shape[-1] // 2
             act = torch.empty((B, S, inter), dtype=x.dtype, device=x.device)
             _ffi.check(lib.ts_swiglu(dev, C.c_void_p(gu.data_ptr()), B * S, inter, dt, C.c_void_p(act.data_ptr()), stream))
             last = li + 1 == len(self.layers)
             gamma = m.norm.weight if last else self.layers[li + 1]["ln1"]
-            x, h = self._add_rmsnorm(x, lin(act, L, "wd"), gamma, not last)
+            x, h = self._add_rmsnorm(x, F.linear(act, L["wd"]), gamma, not last)
         return h
 
 
@@ -436,6 +548,34 @@ class FusedGemma3Forward:
             C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
         return (new_res if new_res is not None else x), out
 
+    def _sdpa(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: Optional[torch.Tensor]) -> torch.Tensor:
+        """torch's attention (sequences past 128 tokens, bf16): every key visible, grouped-query, Gemma3's own scaling."""
+        F = torch.nn.functional
+        if self._gqa_native:
+            try:
+                return F.scaled_dot_product_attention(q, k, v, attn_mask=mask, scale=self.scaling, enable_gqa=True)
+            except (RuntimeError, TypeError):
+                self._gqa_native = False
+        rep = self.hq // self.hkv
+        return F.scaled_dot_product_attention(q, k.repeat_interleave(rep, dim=1), v.repeat_interleave(rep, dim=1), attn_mask=mask,
+                                              scale=self.scaling)
+
+    def _norm_pieces(self, y: Optional[torch.Tensor], x: torch.Tensor, w_post: Optional[torch.Tensor], w_next: torch.Tensor, want_sum: bool):
+        """`_norm` of fp32 operands that also writes the pieces of the pre-normed rows: ``(residual, normed, pieces)``."""
+        import ctypes as C
+        from . import _ffi
+        d = x.shape[-1]
+        rows = x.numel() // d
+        out = torch.empty_like(x)
+        new_res = torch.empty_like(x) if (want_sum and y is not None) else None
+        pieces = torch.empty((rows, 3 * d), dtype=torch.bfloat16, device=x.device)
+        _ffi.check(_ffi.load().ts_gemma_norm_pieces(
+            x.device.index or 0, C.c_void_p(y.data_ptr()) if y is not None else None, C.c_void_p(x.data_ptr()),
+            C.c_void_p(w_post.data_ptr()) if w_post is not None else None, C.c_void_p(w_next.data_ptr()), self.eps, rows, d,
+            C.c_void_p(new_res.data_ptr()) if new_res is not None else None, C.c_void_p(out.data_ptr()), C.c_void_p(pieces.data_ptr()),
+            C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        return (new_res if new_res is not None else x), out, pieces
+
     def __call__(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, token_type_ids: Optional[torch.Tensor] = None,
                  no_padding: bool = False):
         import ctypes as C
@@ -457,42 +597,47 @@ class FusedGemma3Forward:
             cos, sin = m.rotary_emb(x, pos, lt)                       # [1 x S x 256] of the model's type
             tables[lt] = (cos[0].contiguous(), sin[0].contiguous())
         mask = None
-        if not no_padding:
+        short32 = float_attention_applies(x, S, self.hd)      # fp32: the library's fp32 attention (every key visible, heads of 256)
+        key_mask = attention_mask.to(torch.int64).contiguous() if (short32 and not no_padding) else None
+        if not no_padding and not short32:
             neg = torch.finfo(x.dtype).min
             mask = torch.zeros((B, 1, 1, S), dtype=x.dtype, device=x.device).masked_fill_(~attention_mask[:, None, None, :].to(torch.bool), neg)
         nq, nkv, hd = self.hq * self.hd, self.hkv * self.hd, self.hd
         pieces = self.pieces and x.dtype == torch.float32 and "wo_p" in self.layers[0]
-
-        def lin(t, L_, w):
-            return pieces_linear(t, L_[w + "_p"]) if pieces else F.linear(t, L_[w])
-
-        h = self._norm(None, x, None, self.layers[0]["ln_in"], False)[1]
+        H = x.shape[-1]
+        hp = None
+        if pieces:
+            _, h, hp = self._norm_pieces(None, x, None, self.layers[0]["ln_in"], False)
+        else:
+            h = self._norm(None, x, None, self.layers[0]["ln_in"], False)[1]
         for li, L in enumerate(self.layers):
-            qkv = lin(h, L, "wqkv")
+            qkv = pieces_mm(hp, L["wqkv_p"]).view(B, S, -1) if pieces else F.linear(h, L["wqkv"])
             cos, sin = tables[L["type"]]
             _ffi.check(lib.ts_gemma_qk_norm_rope(dev, C.c_void_p(qkv.data_ptr()), C.c_void_p(L["qn"].data_ptr()), C.c_void_p(L["kn"].data_ptr()),
                                                  C.c_void_p(cos.data_ptr()), C.c_void_p(sin.data_ptr()), self.eps, B * S, S, self.hq, self.hkv,
                                                  hd, dt, stream))
-            q = qkv[..., :nq].view(B, S, self.hq, hd).transpose(1, 2)
-            k = qkv[..., nq:nq + nkv].view(B, S, self.hkv, hd).transpose(1, 2)
-            v = qkv[..., nq + nkv:].view(B, S, self.hkv, hd).transpose(1, 2)
-            ctx = None
-            if self._gqa_native:
-                try:
-                    ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, scale=self.scaling, enable_gqa=True)
-                except (RuntimeError, TypeError):
-                    self._gqa_native = False
-            if ctx is None:
-                rep = self.hq // self.hkv
-                ctx = F.scaled_dot_product_attention(q, k.repeat_interleave(rep, dim=1), v.repeat_interleave(rep, dim=1),
-                                                     attn_mask=mask, scale=self.scaling)
-            ctx = ctx.transpose(1, 2).reshape(B, S, nq)
-            x, h = self._norm(lin(ctx, L, "wo"), x, L["ln_post_attn"], L["ln_pre_ffn"], True)
-            gu = lin(h, L, "wgu")
+            cp = None
+            if short32:
+                ctx, cp = attention_float(qkv, key_mask, B, S, self.hq, self.hkv, hd, False, self.scaling, want_pieces=pieces)
+            else:
+                q = qkv[..., :nq].view(B, S, self.hq, hd).transpose(1, 2)
+                k = qkv[..., nq:nq + nkv].view(B, S, self.hkv, hd).transpose(1, 2)
+                v = qkv[..., nq + nkv:].view(B, S, self.hkv, hd).transpose(1, 2)
+                ctx = self._sdpa(q, k, v, mask).transpose(1, 2).reshape(B, S, nq)
+            last = li + 1 == len(self.layers)
+            w_next = m.norm.weight if last else self.layers[li + 1]["ln_in"]
+            if pieces:
+                # GEMMs on the bf16 matrix pipe from pieces; the norms and the GeGLU write the pieces of what they produce
+                if cp is None:
+                    cp = split_pieces(ctx.reshape(B * S, nq), 0)
+                x, h, hp = self._norm_pieces(pieces_mm(cp, L["wo_p"]).view(B, S, H), x, L["ln_post_attn"], L["ln_pre_ffn"], True)
+                ap = act_pieces(pieces_mm(hp, L["wgu_p"]), 2)
+                x, h, hp = self._norm_pieces(pieces_mm(ap, L["wd_p"]).view(B, S, H), x, L["ln_post_ffn"], w_next, not last)
+                continue
+            x, h = self._norm(F.linear(ctx, L["wo"]), x, L["ln_post_attn"], L["ln_pre_ffn"], True)
+            gu = F.linear(h, L["wgu"])
             inter = gu.shape[-1] // 2
             act = torch.empty((B, S, inter), dtype=x.dtype, device=x.device)
             _ffi.check(lib.ts_geglu(dev, C.c_void_p(gu.data_ptr()), B * S, inter, dt, C.c_void_p(act.data_ptr()), stream))
-            last = li + 1 == len(self.layers)
-            w_next = m.norm.weight if last else self.layers[li + 1]["ln_in"]
-            x, h = self._norm(lin(act, L, "wd"), x, L["ln_post_ffn"], w_next, not last)
+            x, h = self._norm(F.linear(act, L["wd"]), x, L["ln_post_ffn"], w_next, not last)
         return h

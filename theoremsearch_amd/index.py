@@ -45,19 +45,21 @@ def _host_rows(x) -> np.ndarray:
 class TheoremIndex:
     """Device-resident embedding matrix with brute-force exact top-k search."""
 
+    _cpu_rows = None          # only the explicit host-only index (device=-1) holds its rows in a numpy array
+
     def __init__(self, n: int, d: int, dtype: str = "f32", metric: str = "cos", device: int = 0,
                  row_offset: int = 0):
         self._lib = _ffi.load()
         self._h = C.c_void_p()
         self.n, self.d = int(n), int(d)
         self.dtype, self.metric, self.device = dtype, metric, int(device)
-        self._host_rows = None
+        self._cpu_rows = None
         if self.device == -1:
             # The explicit host-only index (BASELINE.json configs[0]: the reference's CPU-runnable plumbing case,
             # compare_embeddings.py:55-92): rows stay in a numpy array, `search` calls ts_search_cpu.  Never chosen by the
             # library itself - a missing GPU still raises for every other device number - and only upload / search / close exist.
             _DTYPES[dtype], _METRICS[metric]                      # validate the names
-            self._host_rows = np.zeros((self.n, self.d), dtype=np.float32)
+            self._cpu_rows = np.zeros((self.n, self.d), dtype=np.float32)
             self.row_offset = int(row_offset)
             return
         _ffi.check(self._lib.ts_index_create(self.device, self.n, self.d, _DTYPES[dtype], _METRICS[metric],
@@ -107,11 +109,11 @@ class TheoremIndex:
         rows = _host_rows(rows)
         if rows.shape[1] != self.d:
             raise ValueError(f"rows have d={rows.shape[1]}, index has d={self.d}")
-        if self._host_rows is not None:
+        if self._cpu_rows is not None:
             if row0 < 0 or row0 + rows.shape[0] > self.n:
                 raise ValueError("rows outside the index")
             vals = rows if rows.dtype == np.float32 else (rows.astype(np.uint32) << np.uint32(16)).view(np.float32)
-            self._host_rows[row0:row0 + rows.shape[0]] = vals
+            self._cpu_rows[row0:row0 + rows.shape[0]] = vals
             return
         _ffi.check(self._lib.ts_index_upload(self._h, _ffi.as_ptr(rows), _ffi.np_dtype_code(rows), int(row0),
                                              rows.shape[0]))
@@ -206,10 +208,10 @@ class TheoremIndex:
         nq, k = q.shape[0], int(k)
         scores = np.empty((nq, k), dtype=np.float32)
         idx = np.empty((nq, k), dtype=np.int64)
-        if self._host_rows is not None:
+        if self._cpu_rows is not None:
             if mask is not None or algo != "auto":
                 raise ValueError("the host-only index (device=-1) has one algorithm and no filters")
-            _ffi.check(self._lib.ts_search_cpu(_ffi.as_ptr(self._host_rows), TS_F32, self.n, self.d, _DTYPES[self.dtype],
+            _ffi.check(self._lib.ts_search_cpu(_ffi.as_ptr(self._cpu_rows), TS_F32, self.n, self.d, _DTYPES[self.dtype],
                                                _METRICS[self.metric], _ffi.as_ptr(q), _ffi.np_dtype_code(q), nq, k,
                                                _ffi.as_ptr(scores), _ffi.as_ptr(idx), 0))
             if self.row_offset:
@@ -344,7 +346,7 @@ class TheoremIndex:
 
     # -- lifetime ---------------------------------------------------------------------------
     def close(self) -> None:
-        self._host_rows = None
+        self._cpu_rows = None
         if getattr(self, "_h", None) is not None and self._h.value:
             _ffi.check(self._lib.ts_index_destroy(self._h))      # refused while views of this index are alive
             self._h = C.c_void_p()
