@@ -356,8 +356,8 @@ int ts_attention_short(int device, const void *qkv, const int64_t *attention_mas
  * [batch][seq] key mask or NULL.  pieces (may be NULL): also the bf16 pieces [batch * seq][3 * q_heads * head_dim] of the output
  * (ts_split_pieces pattern 0) for the fp32-class GEMM behind it.  Replaces torch's scaled_dot_product_attention and the four
  * layout copies around it in the three fused forwards. */
-int ts_attention_float(int device, const void *qkv, const int64_t *attention_mask, int32_t batch, int32_t seq, int32_t q_heads,
-                     int32_t kv_heads, int32_t head_dim, int causal, float scale, void *out, void *pieces, void *stream);
+int ts_attention_float(int device, const void *qkv, const void *qkv_bias, const int64_t *attention_mask, int32_t batch, int32_t seq,
+                       int32_t q_heads, int32_t kv_heads, int32_t head_dim, int causal, float scale, void *out, void *pieces, void *stream);
 /* The same for the decoder-style encoder the production app embeds with (Qwen/Qwen3-Embedding-0.6B, streamlit_app.py:55;
  * Qwen3Attention: grouped-query, causal, head size 128): out = softmax(Q K^T / sqrt(128) + causal + key mask) V per (sequence,
  * query head); query head h reads key / value head h / (q_heads / kv_heads).  qkv: device bf16 [batch * seq][(q_heads + 2 kv_heads)
@@ -394,16 +394,18 @@ int ts_qk_norm_rope(int device, void *qkv, const void *q_weight, const void *k_w
 int ts_split_pieces(int device, const void *x, int64_t rows, int32_t k, int pattern, void *out, void *stream);
 /* The producers of the encoder forward writing the pieces of their fp32 output themselves ([hi | lo | hi], 3 d bf16 per row), next
  * to the fp32 output the residual path needs: the GEMM that follows reads them without a ts_split_pieces pass in between.  Same
- * arithmetic as ts_add_layernorm / ts_add_rmsnorm / ts_gemma_norm with dtype TS_F32. */
-int ts_add_layernorm_pieces(int device, const void *a, const void *b, const void *gamma, const void *beta, float eps, int64_t rows,
-                            int32_t d, void *out, void *pieces, void *stream);
+ * arithmetic as ts_add_layernorm / ts_add_rmsnorm / ts_gemma_norm with dtype TS_F32.  a_bias / bias / qkv_bias (each may be NULL): the
+ * bias of the GEMM that produced the input, added on the way in - that GEMM then runs without one (torch.addmm with an output type
+ * copies the broadcast bias into its result before the GEMM: one more pass over the output per GEMM). */
+int ts_add_layernorm_pieces(int device, const void *a, const void *a_bias, const void *b, const void *gamma, const void *beta, float eps,
+                            int64_t rows, int32_t d, void *out, void *pieces, void *stream);
 int ts_add_rmsnorm_pieces(int device, const void *a, const void *b, const void *gamma, float eps, int64_t rows, int32_t d,
                           void *out_sum, void *out_norm, void *pieces, void *stream);
 int ts_gemma_norm_pieces(int device, const void *y, const void *x, const void *w_post, const void *w_next, float eps, int64_t rows,
                          int32_t d, void *out_sum, void *out_norm, void *pieces, void *stream);
 /* fp32 activation straight into pieces [rows x 3n]: kind 0 = gelu (erf form) of x [rows x n] (BertIntermediate behind its GEMM + bias);
  * kind 1 = silu(gate) * up, kind 2 = gelu_tanh(gate) * up of x [rows x 2n] (gate columns, then up columns). */
-int ts_act_pieces(int device, const void *x, int64_t rows, int32_t n, int kind, void *pieces, void *stream);
+int ts_act_pieces(int device, const void *x, const void *bias, int64_t rows, int32_t n, int kind, void *pieces, void *stream);
 /* Gated-MLP activation (Qwen3MLP: SiLU(gate_proj(x)) * up_proj(x)) on the output of ONE GEMM over the stacked gate / up
  * weights: gate_up device [rows][2 * inter] (gate columns, then up columns) -> out device [rows][inter]. */
 int ts_swiglu(int device, const void *gate_up, int64_t rows, int32_t inter, int dtype, void *out, void *stream);

@@ -1059,5 +1059,11 @@ def test_float_attention_kernel_matches_fp64():
     x = torch.randn(1, 200, 3 * 64, device="cuda")
     for S, hd in ((200, 64), (4, 32)):
         with pytest.raises(_ffi.TSearchError):
-            _ffi.check(_ffi.load().ts_attention_float(0, C.c_void_p(x.data_ptr()), None, 1, S, 1, 1, hd, 0, 0.125, C.c_void_p(out.data_ptr()),
-                                                      None, None))
+            _ffi.check(_ffi.load().ts_attention_float(0, C.c_void_p(x.data_ptr()), None, None, 1, S, 1, 1, hd, 0, 0.125,
+                                                      C.c_void_p(out.data_ptr()), None, None))
+    # the stacked projection's bias added on the way in (the GEMM in front then runs without one): the same answer as on qkv + bias
+    qkv = torch.randn(2, 40, 3 * 12 * 64, generator=g).cuda()
+    bias = torch.randn(3 * 12 * 64, generator=g).cuda()
+    want = attention_float(qkv + bias, None, 2, 40, 12, 12, 64, False, 0.125)[0]
+    got = attention_float(qkv, None, 2, 40, 12, 12, 64, False, 0.125, bias=bias)[0]
+    assert (got - want).abs().max().item() < 1e-5

@@ -107,21 +107,21 @@ _SIGNATURES = {
     "ts_embed_layernorm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                      C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_int32, C.c_int32, C.c_int, C.c_void_p, C.c_void_p]),
     "ts_attention_short": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
-    "ts_attention_float": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int, C.c_float,
-                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ts_attention_float": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int,
+                                     C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ts_attention_gqa": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int,
                                    C.c_void_p, C.c_void_p]),
     "ts_add_rmsnorm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_int32, C.c_int, C.c_void_p,
                                  C.c_void_p, C.c_void_p]),
     "ts_qk_norm_rope": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_int, C.c_void_p]),
-    "ts_add_layernorm_pieces": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_int32,
+    "ts_add_layernorm_pieces": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_int32,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
     "ts_add_rmsnorm_pieces": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_int32, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p]),
     "ts_gemma_norm_pieces": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_int32,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "ts_act_pieces": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_void_p, C.c_void_p]),
+    "ts_act_pieces": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_void_p, C.c_void_p]),
     "ts_split_pieces": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_void_p, C.c_void_p]),
     "ts_swiglu": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_void_p, C.c_void_p]),
     "ts_geglu": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_void_p, C.c_void_p]),

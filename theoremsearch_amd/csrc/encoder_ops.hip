@@ -35,7 +35,8 @@ extern "C" int ts_pool_normalize(int device, const void* hidden, int h_dtype, co
 }
 
 static int add_layernorm_impl(int device, const void* a, const void* b, const void* gamma, const void* beta, float eps, int64_t rows,
-                              int32_t d, int dtype, void* out, unsigned short* pieces, void* stream) {
+                              int32_t d, int dtype, void* out, unsigned short* pieces, void* stream, const float* a_bias = nullptr) {
+    if (a_bias && (dtype != TS_F32 || ((uintptr_t)a_bias & 15) != 0)) return fail(TS_ERR_INVALID, "a_bias: fp32 rows only, 16-byte aligned");
     if (!a || !b || !gamma || !beta || !out) return fail(TS_ERR_INVALID, "NULL argument");
     if (pieces && (dtype != TS_F32 || ((uintptr_t)pieces & 7) != 0)) return fail(TS_ERR_INVALID, "pieces come from fp32 rows, 8-byte aligned");
     if (dtype != TS_F32 && dtype != TS_BF16) return fail(TS_ERR_INVALID, "dtype %d", dtype);
@@ -52,9 +53,9 @@ static int add_layernorm_impl(int device, const void* a, const void* b, const vo
     hipStream_t st = (hipStream_t)stream;
 #define TS_LN_LAUNCH(DT_)                                                                                        \
     do {                                                                                                         \
-        if (per_lane <= 1) add_layernorm_kernel<DT_, 1><<<grid, 256, 0, st>>>(a, b, gamma, beta, eps, rows, d, out, pieces); \
-        else if (per_lane <= 2) add_layernorm_kernel<DT_, 2><<<grid, 256, 0, st>>>(a, b, gamma, beta, eps, rows, d, out, pieces); \
-        else add_layernorm_kernel<DT_, 4><<<grid, 256, 0, st>>>(a, b, gamma, beta, eps, rows, d, out, pieces);   \
+        if (per_lane <= 1) add_layernorm_kernel<DT_, 1><<<grid, 256, 0, st>>>(a, b, gamma, beta, eps, rows, d, out, pieces, a_bias); \
+        else if (per_lane <= 2) add_layernorm_kernel<DT_, 2><<<grid, 256, 0, st>>>(a, b, gamma, beta, eps, rows, d, out, pieces, a_bias); \
+        else add_layernorm_kernel<DT_, 4><<<grid, 256, 0, st>>>(a, b, gamma, beta, eps, rows, d, out, pieces, a_bias); \
     } while (0)
     if (dtype == TS_F32) TS_LN_LAUNCH(0);
     else TS_LN_LAUNCH(1);
@@ -68,10 +69,10 @@ extern "C" int ts_add_layernorm(int device, const void* a, const void* b, const 
     return add_layernorm_impl(device, a, b, gamma, beta, eps, rows, d, dtype, out, nullptr, stream);
 }
 
-extern "C" int ts_add_layernorm_pieces(int device, const void* a, const void* b, const void* gamma, const void* beta, float eps,
-                                       int64_t rows, int32_t d, void* out, void* pieces, void* stream) {
+extern "C" int ts_add_layernorm_pieces(int device, const void* a, const void* a_bias, const void* b, const void* gamma, const void* beta,
+                                       float eps, int64_t rows, int32_t d, void* out, void* pieces, void* stream) {
     if (!pieces) return fail(TS_ERR_INVALID, "NULL argument");
-    return add_layernorm_impl(device, a, b, gamma, beta, eps, rows, d, TS_F32, out, (unsigned short*)pieces, stream);
+    return add_layernorm_impl(device, a, b, gamma, beta, eps, rows, d, TS_F32, out, (unsigned short*)pieces, stream, (const float*)a_bias);
 }
 
 extern "C" int ts_embed_layernorm(int device, const int64_t* ids, const int64_t* type_ids, const void* word, const void* pos,
@@ -191,9 +192,11 @@ extern "C" int ts_add_rmsnorm_pieces(int device, const void* a, const void* b, c
     return add_rmsnorm_impl(device, a, b, gamma, eps, rows, d, TS_F32, out_sum, out_norm, (unsigned short*)pieces, stream);
 }
 
-extern "C" int ts_attention_float(int device, const void* qkv, const int64_t* attention_mask, int32_t batch, int32_t seq, int32_t q_heads,
-                                int32_t kv_heads, int32_t head_dim, int causal, float scale, void* out, void* pieces, void* stream) {
+extern "C" int ts_attention_float(int device, const void* qkv, const void* qkv_bias, const int64_t* attention_mask, int32_t batch, int32_t seq,
+                                  int32_t q_heads, int32_t kv_heads, int32_t head_dim, int causal, float scale, void* out, void* pieces,
+                                  void* stream) {
     if (!qkv || !out) return fail(TS_ERR_INVALID, "NULL argument");
+    if (((uintptr_t)qkv_bias & 15) != 0) return fail(TS_ERR_INVALID, "qkv_bias must be 16-byte aligned");
     if (batch < 0 || seq < 1 || q_heads < 1 || kv_heads < 1 || q_heads % kv_heads != 0)
         return fail(TS_ERR_INVALID, "batch = %d, seq = %d, heads = %d over %d", batch, seq, q_heads, kv_heads);
     if ((head_dim != 64 && head_dim != 128 && head_dim != 256) || seq > kAttnF32MaxSeq)
@@ -221,7 +224,8 @@ extern "C" int ts_attention_float(int device, const void* qkv, const int64_t* at
             attr_.fetch_or(bit_, std::memory_order_release);                                                                  \
         }                                                                                                                     \
         attention_f32_kernel<HD_, C_><<<grid, threads, lds_, st>>>((const float*)qkv, attention_mask, batch, seq, q_heads, kv_heads, \
-                                                                     scale_log2e, (float*)out, (unsigned short*)pieces);     \
+                                                                     scale_log2e, (float*)out, (unsigned short*)pieces,      \
+                                                                     (const float*)qkv_bias);                                \
     } while (0)
     if (head_dim == 64) { if (causal) TS_ATTN_F32(64, true); else TS_ATTN_F32(64, false); }
     else if (head_dim == 128) { if (causal) TS_ATTN_F32(128, true); else TS_ATTN_F32(128, false); }
@@ -395,8 +399,9 @@ extern "C" int ts_gemma_norm_pieces(int device, const void* y, const void* x, co
     return gemma_norm_impl(device, y, x, w_post, w_next, eps, rows, d, TS_F32, out_sum, out_norm, (unsigned short*)pieces, stream);
 }
 
-extern "C" int ts_act_pieces(int device, const void* x, int64_t rows, int32_t n, int kind, void* pieces, void* stream) {
+extern "C" int ts_act_pieces(int device, const void* x, const void* bias, int64_t rows, int32_t n, int kind, void* pieces, void* stream) {
     if (!x || !pieces) return fail(TS_ERR_INVALID, "NULL argument");
+    if (((uintptr_t)bias & 15) != 0) return fail(TS_ERR_INVALID, "bias must be 16-byte aligned");
     if (rows < 0 || n < 4 || n % 4 || kind < 0 || kind > 2) return fail(TS_ERR_INVALID, "n = %d must be a multiple of 4, kind 0 / 1 / 2", n);
     if ((((uintptr_t)x) & 15) != 0 || (((uintptr_t)pieces) & 7) != 0) return fail(TS_ERR_INVALID, "x must be 16-byte, pieces 8-byte aligned");
     if (rows == 0) return TS_OK;
@@ -405,9 +410,9 @@ extern "C" int ts_act_pieces(int device, const void* x, int64_t rows, int32_t n,
     const int64_t total = rows * (n / 4);
     const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 16384);
     hipStream_t st = (hipStream_t)stream;
-    if (kind == 0) act_pieces_kernel<0><<<grid, 256, 0, st>>>((const float*)x, rows, n, (unsigned short*)pieces);
-    else if (kind == 1) act_pieces_kernel<1><<<grid, 256, 0, st>>>((const float*)x, rows, n, (unsigned short*)pieces);
-    else act_pieces_kernel<2><<<grid, 256, 0, st>>>((const float*)x, rows, n, (unsigned short*)pieces);
+    if (kind == 0) act_pieces_kernel<0><<<grid, 256, 0, st>>>((const float*)x, rows, n, (unsigned short*)pieces, (const float*)bias);
+    else if (kind == 1) act_pieces_kernel<1><<<grid, 256, 0, st>>>((const float*)x, rows, n, (unsigned short*)pieces, (const float*)bias);
+    else act_pieces_kernel<2><<<grid, 256, 0, st>>>((const float*)x, rows, n, (unsigned short*)pieces, (const float*)bias);
     HIP_TRY(hipGetLastError());
     return TS_OK;
 }

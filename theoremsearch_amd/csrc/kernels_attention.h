@@ -728,10 +728,18 @@ __global__ void __launch_bounds__(64 * R) attention_gqa_rows_kernel(const unsign
 constexpr int kAttnF32MaxSeq = 128;
 constexpr int attn_f32_lds(int HD, int T) { return HD * (16 * T + 4) * 4; }
 
+// The key tiles are walked as a RUNNING softmax (one tile's scores in registers at a time: running maximum m, running sum l,
+// O rescaled by 2^(m - m') when the maximum moves), so the loop over key tiles is a plain run-time loop over fixed registers: the
+// K fragments of tile kj + 1 are requested before the MFMAs of tile kj, the V^T fragments of a tile before its softmax arithmetic.
+// (A first cut kept all T score tiles in registers behind `if (kj < kt_end)` branches: no load could move above a branch, every
+// key tile paid an L2 round trip in front of its 16 MFMAs, and the launch took as long as torch's attention with its four copies.)
 template <int HD, bool CAUSAL>
 __global__ void __launch_bounds__(256) attention_f32_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ mask, int B, int S,
                                                              int HQ, int HKV, float scale_log2e, float* __restrict__ out,
-                                                             unsigned short* __restrict__ pieces) {
+                                                             unsigned short* __restrict__ pieces, const float* __restrict__ bias) {
+    // bias (may be NULL): the stacked projection's bias [(HQ + 2 HKV) HD], added to q, k and v as they are loaded - the GEMM in
+    // front then runs without one (torch.addmm with an output type first copies the broadcast bias into the result: 35 us per
+    // GEMM at 256 x 128 tokens, r05 kernel stats)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_attn[];
     float* sVT = (float*)smem_attn;
     const int T = (S + 15) / 16, SP = 16 * T, PP = SP + 4;
@@ -748,7 +756,13 @@ __global__ void __launch_bounds__(256) attention_f32_kernel(const float* __restr
     for (int i = threadIdx.x; i < SP * (HD / 4); i += blockDim.x) {
         const int key = i / (HD / 4), c = i - key * (HD / 4);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (key < S) v = *(const float4*)(vb + (int64_t)key * tok + 4 * c);
+        if (key < S) {
+            v = *(const float4*)(vb + (int64_t)key * tok + 4 * c);
+            if (bias) {
+                const float4 bv = *(const float4*)(bias + (int64_t)(HQ + HKV + hk) * HD + 4 * c);
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            }
+        }
         sVT[(4 * c + 0) * PP + key] = v.x;
         sVT[(4 * c + 1) * PP + key] = v.y;
         sVT[(4 * c + 2) * PP + key] = v.z;
@@ -756,82 +770,102 @@ __global__ void __launch_bounds__(256) attention_f32_kernel(const float* __restr
     }
     __syncthreads();
     constexpr int KC = HD / 16;                                          // 16-float chunks of a row
-    constexpr int TM = kAttnF32MaxSeq / 16;
     for (int qi = wave; qi < T; qi += nwaves) {
         const int qrow = min(16 * qi + r16, S - 1);
-        float4 qf[KC];
+        const int qpos = 16 * qi + r16;
+        float4 qf[KC], kf[KC], kbias[KC];
 #pragma unroll
-        for (int s = 0; s < KC; ++s) qf[s] = *(const float4*)(qb + (int64_t)qrow * tok + 16 * s + 4 * g);
-        const int kt_end = CAUSAL ? qi + 1 : T;                          // key tiles that hold an allowed key
-        f32x4 sc[TM];
-#pragma unroll
-        for (int kj = 0; kj < TM; ++kj) {
-            sc[kj] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (kj < kt_end) {
-                const int krow = min(16 * kj + r16, S - 1);
-                float4 kf[KC];
-#pragma unroll
-                for (int s = 0; s < KC; ++s) kf[s] = *(const float4*)(kb + (int64_t)krow * tok + 16 * s + 4 * g);
-                f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < KC; ++s) {
-                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].x, qf[s].x, a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].y, qf[s].y, a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].z, qf[s].z, a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].w, qf[s].w, a, 0, 0, 0);
-                }
-                sc[kj] = a;
+        for (int s = 0; s < KC; ++s) {
+            qf[s] = *(const float4*)(qb + (int64_t)qrow * tok + 16 * s + 4 * g);
+            kbias[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bias) {
+                const float4 bq = *(const float4*)(bias + (int64_t)h * HD + 16 * s + 4 * g);
+                qf[s].x += bq.x; qf[s].y += bq.y; qf[s].z += bq.z; qf[s].w += bq.w;
+                kbias[s] = *(const float4*)(bias + (int64_t)(HQ + hk) * HD + 16 * s + 4 * g);
             }
         }
-        // lane (g, r16): scores of keys 16 kj + 4 g + r for query 16 qi + r16
-        const int qpos = 16 * qi + r16;
-        float m = -INFINITY;
+        const int kt_end = CAUSAL ? qi + 1 : T;                          // key tiles that hold an allowed key
+        {
+            const int krow = min(r16, S - 1);
 #pragma unroll
-        for (int kj = 0; kj < TM; ++kj)
+            for (int s = 0; s < KC; ++s) kf[s] = *(const float4*)(kb + (int64_t)krow * tok + 16 * s + 4 * g);
+        }
+        f32x4 o[KC];
+#pragma unroll
+        for (int dj = 0; dj < KC; ++dj) o[dj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float m = -INFINITY, l = 0.0f;                                   // running maximum / sum of query r16 (the same in its four lane groups)
+        for (int kj = 0; kj < kt_end; ++kj) {
+            // scores of this tile: two accumulator chains (a dependent 16x16x4 MFMA waits 40 cycles, an independent one 32)
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+            if (bias) {
+#pragma unroll
+                for (int s = 0; s < KC; ++s) { kf[s].x += kbias[s].x; kf[s].y += kbias[s].y; kf[s].z += kbias[s].z; kf[s].w += kbias[s].w; }
+            }
+#pragma unroll
+            for (int s = 0; s < KC; s += 2) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].x, qf[s].x, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s + 1].x, qf[s + 1].x, a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].y, qf[s].y, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s + 1].y, qf[s + 1].y, a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].z, qf[s].z, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s + 1].z, qf[s + 1].z, a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].w, qf[s].w, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s + 1].w, qf[s + 1].w, a1, 0, 0, 0);
+            }
+            // the next tile's K fragments and this tile's V^T fragments are on their way while the softmax arithmetic runs
+            if (kj + 1 < kt_end) {
+                const int krow = min(16 * (kj + 1) + r16, S - 1);
+#pragma unroll
+                for (int s = 0; s < KC; ++s) kf[s] = *(const float4*)(kb + (int64_t)krow * tok + 16 * s + 4 * g);
+            }
+            float4 vf[KC];
+#pragma unroll
+            for (int dj = 0; dj < KC; ++dj) vf[dj] = *(const float4*)(sVT + (16 * dj + r16) * PP + 16 * kj + 4 * g);
+            float sc[4], tmax = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = 16 * kj + 4 * g + r;
-                const bool ok = kj < kt_end && key < S && (!mask || mask[(int64_t)b * S + key] != 0) && (!CAUSAL || key <= qpos);
-                sc[kj][r] = ok ? sc[kj][r] : -INFINITY;
-                m = fmaxf(m, sc[kj][r]);
+                const bool ok = key < S && (!mask || mask[(int64_t)b * S + key] != 0) && (!CAUSAL || key <= qpos);
+                sc[r] = ok ? a0[r] + a1[r] : -INFINITY;
+                tmax = fmaxf(tmax, sc[r]);
             }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        float sum = 0.0f;
-#pragma unroll
-        for (int kj = 0; kj < TM; ++kj)
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m, tmax);
+            // a tile without a single allowed key so far leaves m = -inf: nothing to rescale, nothing to add
+            const float alpha = m_new > -INFINITY ? __builtin_amdgcn_exp2f((m - m_new) * scale_log2e) : 1.0f;
+            float psum = 0.0f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = sc[kj][r] > -INFINITY ? exp2f((sc[kj][r] - m) * scale_log2e) : 0.0f;
-                sc[kj][r] = e;
-                sum += e;
+                sc[r] = sc[r] > -INFINITY ? __builtin_amdgcn_exp2f((sc[r] - m_new) * scale_log2e) : 0.0f;
+                psum += sc[r];
             }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;                // a query without a single allowed key: zeros
+            psum += __shfl_xor(psum, 16, 64);
+            psum += __shfl_xor(psum, 32, 64);
+            l = l * alpha + psum;
+            m = m_new;
 #pragma unroll
-        for (int kj = 0; kj < TM; ++kj)
+            for (int dj = 0; dj < KC; ++dj) {
+                o[dj][0] *= alpha; o[dj][1] *= alpha; o[dj][2] *= alpha; o[dj][3] *= alpha;
+            }
+            // O^T += V^T P^T: KC independent accumulators, MFMA r of the tile takes keys 16 kj + 4 g + r
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sc[kj][r] *= inv;
-        // O^T[d][q]
-        const bool live = qpos < S;
-        float* orow = out + ((int64_t)b * S + min(qpos, S - 1)) * HQ * HD + (int64_t)h * HD;
+            for (int dj = 0; dj < KC; ++dj) o[dj] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[dj].x, sc[0], o[dj], 0, 0, 0);
 #pragma unroll
-        for (int dj = 0; dj < KC; ++dj) {
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            for (int dj = 0; dj < KC; ++dj) o[dj] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[dj].y, sc[1], o[dj], 0, 0, 0);
 #pragma unroll
-            for (int kj = 0; kj < TM; ++kj)
-                if (kj < kt_end) {
-                    const float4 vf = *(const float4*)(sVT + (16 * dj + r16) * PP + 16 * kj + 4 * g);
-                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.x, sc[kj][0], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.y, sc[kj][1], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.z, sc[kj][2], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.w, sc[kj][3], a, 0, 0, 0);
-                }
-            if (live) {
-                *(float4*)(orow + 16 * dj + 4 * g) = make_float4(a[0], a[1], a[2], a[3]);
+            for (int dj = 0; dj < KC; ++dj) o[dj] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[dj].z, sc[2], o[dj], 0, 0, 0);
+#pragma unroll
+            for (int dj = 0; dj < KC; ++dj) o[dj] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[dj].w, sc[3], o[dj], 0, 0, 0);
+        }
+        const float inv = l > 0.0f ? 1.0f / l : 0.0f;                    // a query without a single allowed key: zeros
+        if (qpos < S) {
+            float* orow = out + ((int64_t)b * S + qpos) * HQ * HD + (int64_t)h * HD;
+#pragma unroll
+            for (int dj = 0; dj < KC; ++dj) {
+                const float y[4] = {o[dj][0] * inv, o[dj][1] * inv, o[dj][2] * inv, o[dj][3] * inv};
+                *(float4*)(orow + 16 * dj + 4 * g) = make_float4(y[0], y[1], y[2], y[3]);
                 if (pieces) {
-                    const float y[4] = {a[0], a[1], a[2], a[3]};
                     const int dtot = HQ * HD;
                     store_pieces4(pieces + ((int64_t)b * S + qpos) * 3 * dtot, dtot, (h * HD + 16 * dj + 4 * g) / 4, y);
                 }

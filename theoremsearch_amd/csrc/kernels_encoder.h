@@ -175,7 +175,8 @@ constexpr int kLnMax = 4;
 template <int DT, int LN = kLnMax>
 __global__ void __launch_bounds__(256) add_layernorm_kernel(const void* a, const void* b,      // `out` may alias a or b: no restrict
                                                              const void* __restrict__ gamma, const void* __restrict__ beta, float eps,
-                                                             int64_t rows, int d, void* out, unsigned short* pieces = nullptr) {
+                                                             int64_t rows, int d, void* out, unsigned short* pieces = nullptr,
+                                                             const float* __restrict__ a_bias = nullptr) {   // fp32 only: a + a_bias[col]
     constexpr int VEC = DT == 0 ? 4 : 8;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -212,6 +213,10 @@ __global__ void __launch_bounds__(256) add_layernorm_kernel(const void* a, const
             float fa[VEC], fb[VEC];
             unpack(ra[j], fa);
             unpack(rb[j], fb);
+            if (DT == 0 && a_bias) {                 // the bias of the GEMM that produced `a` (it ran without one)
+                const float4 bb = ((const float4*)a_bias)[c];
+                fa[0] += bb.x; fa[1] += bb.y; fa[2] += bb.z; fa[3] += bb.w;
+            }
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 x[j][e] = fa[e] + fb[e];
@@ -684,7 +689,8 @@ __global__ void __launch_bounds__(256) geglu_kernel(const void* __restrict__ gat
 //   KIND 1: y = silu(gate) * up (Qwen3MLP),  KIND 2: y = gelu_tanh(gate) * up (Gemma3MLP), x = [rows][2 n]: gate columns, then up
 // out [rows][3 n] bf16 = [hi | lo | hi] of y.
 template <int KIND>
-__global__ void __launch_bounds__(256) act_pieces_kernel(const float* __restrict__ x, int64_t rows, int n, unsigned short* __restrict__ out) {
+__global__ void __launch_bounds__(256) act_pieces_kernel(const float* __restrict__ x, int64_t rows, int n, unsigned short* __restrict__ out,
+                                                          const float* __restrict__ bias) {    // bias (may be NULL): [n] (KIND 0) / [2 n], added to x
     const int per_row = n / 4;
     const int64_t total = rows * per_row;
     const int in_row = (KIND == 0 ? 1 : 2) * per_row;
@@ -692,14 +698,22 @@ __global__ void __launch_bounds__(256) act_pieces_kernel(const float* __restrict
         const int64_t r = i / per_row;
         const int c = (int)(i - r * per_row);
         const float4 g4 = ((const float4*)x)[r * in_row + c];
-        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+        float g[4] = {g4.x, g4.y, g4.z, g4.w};
+        if (bias) {
+            const float4 bg = ((const float4*)bias)[c];
+            g[0] += bg.x; g[1] += bg.y; g[2] += bg.z; g[3] += bg.w;
+        }
         float y[4];
         if (KIND == 0) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = 0.5f * g[e] * (1.0f + erff(g[e] * 0.7071067811865476f));
         } else {
             const float4 u4 = ((const float4*)x)[r * in_row + per_row + c];
-            const float u[4] = {u4.x, u4.y, u4.z, u4.w};
+            float u[4] = {u4.x, u4.y, u4.z, u4.w};
+            if (bias) {
+                const float4 bu = ((const float4*)bias)[per_row + c];
+                u[0] += bu.x; u[1] += bu.y; u[2] += bu.z; u[3] += bu.w;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (KIND == 1) {

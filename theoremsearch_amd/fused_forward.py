@@ -53,31 +53,33 @@ def pieces_mm(x_pieces: torch.Tensor, w_pieces: torch.Tensor, bias: Optional[tor
     return torch.mm(x_pieces, w_pieces.t(), out_dtype=torch.float32)
 
 
-def act_pieces(x: torch.Tensor, kind: int) -> torch.Tensor:
+def act_pieces(x: torch.Tensor, kind: int, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fp32 activation straight into pieces (``ts_act_pieces``): kind 0 = gelu (erf) of ``[rows x n]``; 1 = silu(gate) * up,
-    2 = gelu_tanh(gate) * up of ``[rows x 2n]``.  Returns bf16 ``[rows x 3n]``."""
+    2 = gelu_tanh(gate) * up of ``[rows x 2n]``; ``bias`` (over the input's width) is added first.  Returns bf16 ``[rows x 3n]``."""
     import ctypes as C
     from . import _ffi
     x = x.contiguous()
     rows = x.numel() // x.shape[-1]
     n = x.shape[-1] if kind == 0 else x.shape[-1] // 2
     out = torch.empty((rows, 3 * n), dtype=torch.bfloat16, device=x.device)
-    _ffi.check(_ffi.load().ts_act_pieces(x.device.index or 0, C.c_void_p(x.data_ptr()), rows, n, kind, C.c_void_p(out.data_ptr()),
-                                         C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+    _ffi.check(_ffi.load().ts_act_pieces(x.device.index or 0, C.c_void_p(x.data_ptr()), C.c_void_p(bias.data_ptr()) if bias is not None else None,
+                                         rows, n, kind, C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
     return out
 
 
 def attention_float(qkv: torch.Tensor, key_mask: Optional[torch.Tensor], B: int, S: int, hq: int, hkv: int, hd: int, causal: bool,
-                    scale: float, want_pieces: bool = False):
+                    scale: float, want_pieces: bool = False, bias: Optional[torch.Tensor] = None):
     """fp32 attention of at most 128 tokens on the exact-fp32 matrix instructions, straight from the stacked projection's output
-    ``qkv [B x S x (hq + 2 hkv) hd]`` (``ts_attention_float``): ``(context fp32 [B x S x hq hd], its bf16 pieces or None)``."""
+    ``qkv [B x S x (hq + 2 hkv) hd]`` (``ts_attention_float``; ``bias``: the projection's bias when its GEMM ran without one):
+    ``(context fp32 [B x S x hq hd], its bf16 pieces or None)``."""
     import ctypes as C
     from . import _ffi
     qkv = qkv.contiguous()
     ctx = torch.empty((B, S, hq * hd), dtype=torch.float32, device=qkv.device)
     pieces = torch.empty((B * S, 3 * hq * hd), dtype=torch.bfloat16, device=qkv.device) if want_pieces else None
     _ffi.check(_ffi.load().ts_attention_float(
-        qkv.device.index or 0, C.c_void_p(qkv.data_ptr()), C.c_void_p(key_mask.data_ptr()) if key_mask is not None else None, B, S, hq,
+        qkv.device.index or 0, C.c_void_p(qkv.data_ptr()), C.c_void_p(bias.data_ptr()) if bias is not None else None,
+        C.c_void_p(key_mask.data_ptr()) if key_mask is not None else None, B, S, hq,
         hkv, hd, 1 if causal else 0, float(scale), C.c_void_p(ctx.data_ptr()), C.c_void_p(pieces.data_ptr()) if pieces is not None else None,
         C.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream)))
     return ctx, pieces
@@ -189,8 +191,9 @@ class FusedBertForward:
             B, S, self.heads, 64, C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream)))
         return out
 
-    def _add_ln_pieces(self, a: torch.Tensor, b: torch.Tensor, ln):
-        """`_add_ln` of fp32 operands that also writes the pieces of its output: ``(out fp32, pieces bf16 [rows x 3d])``."""
+    def _add_ln_pieces(self, a: torch.Tensor, b: torch.Tensor, ln, a_bias: Optional[torch.Tensor] = None):
+        """`_add_ln` of fp32 operands (``a + a_bias + b``) that also writes the pieces of its output: ``(out fp32, pieces bf16
+        [rows x 3d])``."""
         import ctypes as C
         from . import _ffi
         a, b = a.contiguous(), b.contiguous()
@@ -198,7 +201,8 @@ class FusedBertForward:
         rows, d = a.numel() // a.shape[-1], a.shape[-1]
         pieces = torch.empty((rows, 3 * d), dtype=torch.bfloat16, device=a.device)
         _ffi.check(_ffi.load().ts_add_layernorm_pieces(
-            a.device.index or 0, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(ln.weight.data_ptr()),
+            a.device.index or 0, C.c_void_p(a.data_ptr()), C.c_void_p(a_bias.data_ptr()) if a_bias is not None else None,
+            C.c_void_p(b.data_ptr()), C.c_void_p(ln.weight.data_ptr()),
             C.c_void_p(ln.bias.data_ptr()), self.eps, rows, d, C.c_void_p(out.data_ptr()), C.c_void_p(pieces.data_ptr()),
             C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)))
         return out, pieces
@@ -260,17 +264,19 @@ class FusedBertForward:
         exact_gelu = self.cfg.hidden_act == "gelu"
         xp = split_pieces(x.view(B * S, H), 0)
         for L in self.layers:
-            qkv = pieces_mm(xp, L["wqkv_p"], L["bqkv"])
+            # every GEMM runs WITHOUT its bias: the kernel that reads its output adds it on the way in (torch.addmm with an output
+            # type first copies the broadcast bias into the result: one more pass over every GEMM's output)
+            qkv = pieces_mm(xp, L["wqkv_p"])
             if short32:                # the attention writes the pieces of its output itself
-                cp = attention_float(qkv, key_mask, B, S, self.heads, self.heads, hd, False, hd ** -0.5, want_pieces=True)[1]
+                cp = attention_float(qkv, key_mask, B, S, self.heads, self.heads, hd, False, hd ** -0.5, want_pieces=True, bias=L["bqkv"])[1]
             else:
-                qkv = qkv.view(B, S, 3, self.heads, hd).permute(2, 0, 3, 1, 4)
+                qkv = (qkv + L["bqkv"]).view(B, S, 3, self.heads, hd).permute(2, 0, 3, 1, 4)
                 ctx = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], attn_mask=mask)
                 cp = split_pieces(ctx.transpose(1, 2).reshape(B * S, H), 0)
-            x, xp = self._add_ln_pieces(pieces_mm(cp, L["wo_p"], L["bo"]).view(B, S, H), x, L["ln1"])
-            h = pieces_mm(xp, L["w1_p"], L["b1"])
-            hp = act_pieces(h, 0) if exact_gelu else split_pieces(self.act(h), 0)
-            x, xp = self._add_ln_pieces(pieces_mm(hp, L["w2_p"], L["b2"]).view(B, S, H), x, L["ln2"])
+            x, xp = self._add_ln_pieces(pieces_mm(cp, L["wo_p"]).view(B, S, H), x, L["ln1"], a_bias=L["bo"])
+            h = pieces_mm(xp, L["w1_p"])
+            hp = act_pieces(h, 0, bias=L["b1"]) if exact_gelu else split_pieces(self.act(h + L["b1"]), 0)
+            x, xp = self._add_ln_pieces(pieces_mm(hp, L["w2_p"]).view(B, S, H), x, L["ln2"], a_bias=L["b2"])
         return x
 
 

@@ -70,6 +70,12 @@ def main(src, tag):
         b = os.path.join(src, f"bench_{w}.json")
         if os.path.exists(b) and os.path.getsize(b) > 0:
             shutil.copy(b, os.path.join(out, f"{tag}_bench_{w}.json"))
+    # round 5: every bench line and kernel-stats summary the run left (c5 lines carry encoder, tokens and dtype in their names)
+    for b in glob.glob(os.path.join(src, "bench_*.json")):
+        if os.path.getsize(b) > 0:
+            shutil.copy(b, os.path.join(out, f"{tag}_{os.path.basename(b)}"))
+    for st_ in glob.glob(os.path.join(src, "*_kernel_stats.csv")):
+        shutil.copy(st_, os.path.join(out, f"{tag}_{os.path.basename(st_)}"))
     stats = newest(glob.glob(os.path.join(src, "shard_1p25M_kernel_stats.csv")) or
                    glob.glob(os.path.join(src, "trace_shard", "**", "*kernel_stats.csv"), recursive=True))
     if stats:
