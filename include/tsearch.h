@@ -350,7 +350,7 @@ int ts_attention_short(int device, const void *qkv, const int64_t *attention_mas
                       int32_t head_dim, void *out, void *stream);
 
 /* fp32 attention of the encoder at the reference's fp32 storage (SentenceTransformer(name) without a dtype, streamlit_app.py:55,173),
- * at most 128 tokens, head size 64 / 128 / 256: softmax(Q K^T * scale + key mask [+ causal]) V on the exact-fp32 matrix
+ * head size 64 / 128 / 256 up to 512 / 256 / 128 tokens: softmax(Q K^T * scale + key mask [+ causal]) V on the exact-fp32 matrix
  * instructions, straight from the stacked projection's output qkv [batch][seq][(q_heads + 2 kv_heads) * head_dim] (query heads, key
  * heads, value heads) to out [batch][seq][q_heads * head_dim]; grouped-query when kv_heads < q_heads.  attention_mask: int64
  * [batch][seq] key mask or NULL.  pieces (may be NULL): also the bf16 pieces [batch * seq][3 * q_heads * head_dim] of the output

@@ -199,9 +199,9 @@ extern "C" int ts_attention_float(int device, const void* qkv, const void* qkv_b
     if (((uintptr_t)qkv_bias & 15) != 0) return fail(TS_ERR_INVALID, "qkv_bias must be 16-byte aligned");
     if (batch < 0 || seq < 1 || q_heads < 1 || kv_heads < 1 || q_heads % kv_heads != 0)
         return fail(TS_ERR_INVALID, "batch = %d, seq = %d, heads = %d over %d", batch, seq, q_heads, kv_heads);
-    if ((head_dim != 64 && head_dim != 128 && head_dim != 256) || seq > kAttnF32MaxSeq)
-        return fail(TS_ERR_UNSUPPORTED, "head size %d / %d tokens: this kernel serves head sizes 64, 128, 256 and at most %d tokens", head_dim,
-                    seq, kAttnF32MaxSeq);
+    if ((head_dim != 64 && head_dim != 128 && head_dim != 256) || seq > attn_f32_max_seq(head_dim))
+        return fail(TS_ERR_UNSUPPORTED, "head size %d / %d tokens: this kernel serves head sizes 64 / 128 / 256 up to 512 / 256 / 128 tokens",
+                    head_dim, seq);
     if ((((uintptr_t)qkv | (uintptr_t)out) & 15) != 0 || (((uintptr_t)pieces) & 7) != 0)
         return fail(TS_ERR_INVALID, "qkv and out must be 16-byte aligned, pieces 8-byte");
     if (!(scale > 0.0f)) return fail(TS_ERR_INVALID, "scale must be positive");
@@ -220,7 +220,7 @@ extern "C" int ts_attention_float(int device, const void* qkv, const void* qkv_b
         const unsigned long long bit_ = 1ull << (device & 63);                                                                \
         if (!(attr_.load(std::memory_order_acquire) & bit_)) {                                                                \
             HIP_TRY(hipFuncSetAttribute((const void*)attention_f32_kernel<HD_, C_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                        attn_f32_lds(HD_, kAttnF32MaxSeq / 16)));                                             \
+                                        attn_f32_lds(HD_, attn_f32_max_seq(HD_) / 16)));                                      \
             attr_.fetch_or(bit_, std::memory_order_release);                                                                  \
         }                                                                                                                     \
         attention_f32_kernel<HD_, C_><<<grid, threads, lds_, st>>>((const float*)qkv, attention_mask, batch, seq, q_heads, kv_heads, \

@@ -711,7 +711,8 @@ __global__ void __launch_bounds__(64 * R) attention_gqa_rows_kernel(const unsign
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // fp32 attention (the encoder at the reference's fp32 storage: SentenceTransformer(name) without a dtype, streamlit_app.py:55,173)
-// for sequences of at most 128 tokens, any of the three families: softmax(Q K^T * scale + key mask [+ causal]) V with every
+// for sequences of at most 512 (head 64) / 256 (head 128) / 128 (head 256) tokens - the corpus texts of app_create_embeddings.py:48-70
+// are global context + statement, up to BERT's 512 positions - any of the three families: softmax(Q K^T * scale + key mask [+ causal]) V with every
 // product on v_mfma_f32_16x16x4_f32 - exact fp32 multiplies, fp32 accumulation - straight from the stacked projection's output
 // [B][S][(HQ + 2 HKV) HD] into the context layout [B][S][HQ HD] (and, for the fp32-class GEMM behind it, its bf16 pieces).
 // torch's attention on this layout first copies q, k, v and the context (four launches of 34 us each per BERT layer at 256 x 128
@@ -725,7 +726,8 @@ __global__ void __launch_bounds__(64 * R) attention_gqa_rows_kernel(const unsign
 //     [d r16][those four keys] = ONE ds_read_b128 of the transposed image (pitch SP + 4 floats: conflict-free);
 //     D[d 4 g + r][query r16]: four consecutive d per lane, stored as 16 bytes.
 // HD = head size (64 BERT, 128 Qwen3, 256 Gemma3); CAUSAL skips key tiles past the query tile; grouped-query: KV head = h / (HQ / HKV).
-constexpr int kAttnF32MaxSeq = 128;
+constexpr int kAttnF32MaxSeq = 128;                                  // every head size; smaller heads go further:
+constexpr int attn_f32_max_seq(int HD) { return HD == 64 ? 512 : HD == 128 ? 256 : 128; }   // V^T must fit the CU's LDS (<= 133 KB)
 constexpr int attn_f32_lds(int HD, int T) { return HD * (16 * T + 4) * 4; }
 
 // The key tiles are walked as a RUNNING softmax (one tile's scores in registers at a time: running maximum m, running sum l,

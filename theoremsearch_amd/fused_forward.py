@@ -85,9 +85,13 @@ def attention_float(qkv: torch.Tensor, key_mask: Optional[torch.Tensor], B: int,
     return ctx, pieces
 
 
+_FLOAT_ATTENTION_MAX_SEQ = {64: 512, 128: 256, 256: 128}      # what fits the CU's LDS as V^T (attn_f32_max_seq, kernels_attention.h)
+
+
 def float_attention_applies(x: torch.Tensor, S: int, hd: int) -> bool:
-    """fp32 hidden states, at most 128 tokens, a head size the kernel serves; TS_ENCODER_ATTENTION=0 keeps torch's attention."""
-    return (x.dtype == torch.float32 and hd in (64, 128, 256) and S <= 128 and os.environ.get("TS_ENCODER_ATTENTION", "1") != "0")
+    """fp32 hidden states, a head size the kernel serves and a sequence whose V^T fits the LDS (512 / 256 / 128 tokens for heads
+    of 64 / 128 / 256); TS_ENCODER_ATTENTION=0 keeps torch's attention."""
+    return (x.dtype == torch.float32 and S <= _FLOAT_ATTENTION_MAX_SEQ.get(hd, 0) and os.environ.get("TS_ENCODER_ATTENTION", "1") != "0")
 
 
 class FusedBertForward:

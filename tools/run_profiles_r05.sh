@@ -3,7 +3,8 @@
 # profiles/.  Usage: bash tools/run_profiles_r05.sh <out-dir under gpurun_out> <part>
 #   part a: c3 (bench line; kernel trace of the SAME command; FETCH / WRITE / SQ counter passes), c2 (+ passes), c2b
 #   part b: c3q (bench, trace, FETCH / WRITE), c4 on one GPU, c1
-#   part c: c5 - three encoders x {32, 128} tokens x {fp32, fp32x3, bf16}: bench lines; kernel traces of the BERT ones
+#   part c_bert | c_qwen | c_gemma: c5 - that encoder x {32, 128} tokens x {fp32, fp32x3, bf16}: bench lines
+#   part c_trace: kernel traces of the BERT lines and of the Qwen3 / Gemma3 fp32x3 lines at 32 tokens
 # Trace and counter passes are separate runs (never --pmc together with a trace domain other than kernel-trace).
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$R/gpurun_out/${1:-r05}"
@@ -45,14 +46,17 @@ elif [ "$PART" = "b" ]; then
   pmc c3q WRITE_SIZE --workload c3q
   bench_only c4_one_gpu --workload c4 --no-cpu-baseline --no-ceiling || echo "c4 failed (non-fatal)" >&2
   bench_only c1 --workload c1 || echo "c1 failed (non-fatal)" >&2
-else
-  for enc in bert qwen gemma; do for sl in 32 128; do for dt in fp32 fp32x3 bf16; do
-    extra="--no-cpu-baseline"
-    [ "$enc" = "bert" ] && [ "$sl" = "32" ] && extra=""                 # the BERT lines at 32 tokens carry the CPU baseline (host encode + search)
-    bench_only "c5_${enc}_${sl}_${dt}" --workload c5 --encoder $enc --seq-len $sl --encoder-dtype $dt --no-ceiling --sustained-steps 100 $extra
-  done; done; done
+elif [ "$PART" = "c_trace" ]; then
   for sl in 32 128; do for dt in fp32 fp32x3 bf16; do
     trace "c5_bert_${sl}_${dt}" --workload c5 --encoder bert --seq-len $sl --encoder-dtype $dt --no-ceiling --sustained-steps 40 --steps 10 --warmup 3
   done; done
   trace c5_qwen_32_fp32x3 --workload c5 --encoder qwen --seq-len 32 --encoder-dtype fp32x3 --no-ceiling --sustained-steps 40 --steps 10 --warmup 3
+  trace c5_gemma_32_fp32x3 --workload c5 --encoder gemma --seq-len 32 --encoder-dtype fp32x3 --no-ceiling --sustained-steps 40 --steps 10 --warmup 3
+else
+  # part c_bert / c_qwen / c_gemma: the c5 lines of one encoder
+  for enc in ${PART#c_}; do for sl in 32 128; do for dt in fp32 fp32x3 bf16; do
+    extra="--no-cpu-baseline"
+    [ "$enc" = "bert" ] && [ "$sl" = "32" ] && extra=""                 # the BERT lines at 32 tokens carry the CPU baseline (host encode + search)
+    bench_only "c5_${enc}_${sl}_${dt}" --workload c5 --encoder $enc --seq-len $sl --encoder-dtype $dt --no-ceiling --sustained-steps 100 $extra
+  done; done; done
 fi
