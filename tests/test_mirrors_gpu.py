@@ -1067,3 +1067,34 @@ def test_float_attention_kernel_matches_fp64():
     want = attention_float(qkv + bias, None, 2, 40, 12, 12, 64, False, 0.125)[0]
     got = attention_float(qkv, None, 2, 40, 12, 12, 64, False, 0.125, bias=bias)[0]
     assert (got - want).abs().max().item() < 1e-5
+
+
+def test_long_corpus_texts_take_the_float_attention_in_the_fused_fp32_forward():
+    """Corpus texts are global context + statement (app_create_embeddings.py:48-70): hundreds of tokens, up to BERT's 512 positions.
+    In fp32 - the reference's storage - the fused BERT forward serves them with ts_attention_float up to 512 tokens (Qwen3 heads:
+    256): ragged batches of 150-400 tokens against the model's own forward, and against torch's attention (TS_ENCODER_ATTENTION=0)."""
+    import torch
+    from theoremsearch_amd.encoder import SentenceEncoder
+    texts = [("Let $X_%d$ be a compact Hausdorff space and $f$ a continuous map. " % i) * (12 + 3 * (i % 7)) for i in range(9)]
+    for name, layers in (("math-similarity/Bert-MLM_arXiv-MP-class_zbMath", 3), ("Qwen/Qwen3-Embedding-0.6B", 2)):
+        enc = SentenceEncoder(name, num_layers=layers, allow_random_init=True, dtype=torch.float32)
+        assert enc._fused is not None
+        if "Qwen" in name:
+            texts_ = [t[: len(t) * 2 // 5] for t in texts]                # up to ~230 tokens: the Qwen3 heads' limit is 256
+        else:
+            texts_ = texts
+        tok = {k: v.cuda() for k, v in enc._tokenize(texts_).items()}
+        S = tok["input_ids"].shape[1]
+        assert 128 < S <= (256 if "Qwen" in name else 512), S
+        with torch.inference_mode():
+            want = enc.model(input_ids=tok["input_ids"], attention_mask=tok["attention_mask"]).last_hidden_state
+            got = enc.forward_hidden(tok["input_ids"], tok["attention_mask"])
+            os.environ["TS_ENCODER_ATTENTION"] = "0"
+            try:
+                torch_way = enc.forward_hidden(tok["input_ids"], tok["attention_mask"])
+            finally:
+                del os.environ["TS_ENCODER_ATTENTION"]
+        real = tok["attention_mask"].bool()
+        scale = want[real].abs().max().item()
+        assert (want - got)[real].abs().max().item() < 1e-4 * scale, (name, S)
+        assert (torch_way - got)[real].abs().max().item() < 1e-4 * scale, (name, S)
