@@ -772,7 +772,13 @@ __global__ void __launch_bounds__(256) attention_f32_kernel(const float* __restr
     }
     __syncthreads();
     constexpr int KC = HD / 16;                                          // 16-float chunks of a row
-    for (int qi = wave; qi < T; qi += nwaves) {
+    // query tiles of this wave: wave, wave + nwaves, ...  CAUSAL: tile qi walks qi + 1 key tiles, so every second round runs from
+    // the far end (rounds of tiles {w, 2 nw - 1 - w}: with eight tiles every wave walks nine key tiles instead of six to twelve)
+    for (int it = 0;; ++it) {
+        const int lo_ = it * nwaves + wave, hi_ = (it + 1) * nwaves - 1 - wave;
+        const int qi = (CAUSAL && (it & 1)) ? hi_ : lo_;
+        if (it * nwaves >= T) break;
+        if (qi >= T) continue;
         const int qrow = min(16 * qi + r16, S - 1);
         const int qpos = 16 * qi + r16;
         float4 qf[KC], kf[KC], kbias[KC];
