@@ -358,12 +358,6 @@ int ts_attention_short(int device, const void *qkv, const int64_t *attention_mas
  * layout copies around it in the three fused forwards. */
 int ts_attention_float(int device, const void *qkv, const void *qkv_bias, const int64_t *attention_mask, int32_t batch, int32_t seq,
                        int32_t q_heads, int32_t kv_heads, int32_t head_dim, int causal, float scale, void *out, void *pieces, void *stream);
-/* ts_attention_float's arithmetic with every product on the bf16 matrix pipe from bf16 pieces of Q, K, V and the probabilities (sixteen
- * significant bits per factor, fp32 accumulation): the attention of the fp32-class forward (SentenceEncoder(fp32_gemm="bf16x3")).  Same
- * arguments; sequences up to 256 / 128 / 64 tokens for heads of 64 / 128 / 256 (K and V^T pieces must fit the LDS). */
-int ts_attention_pieces(int device, const void *qkv, const void *qkv_bias, const int64_t *attention_mask, int32_t batch, int32_t seq,
-                        int32_t q_heads, int32_t kv_heads, int32_t head_dim, int causal, float scale, void *out, void *pieces,
-                        void *stream);
 /* The same for the decoder-style encoder the production app embeds with (Qwen/Qwen3-Embedding-0.6B, streamlit_app.py:55;
  * Qwen3Attention: grouped-query, causal, head size 128): out = softmax(Q K^T / sqrt(128) + causal + key mask) V per (sequence,
  * query head); query head h reads key / value head h / (q_heads / kv_heads).  qkv: device bf16 [batch * seq][(q_heads + 2 kv_heads)

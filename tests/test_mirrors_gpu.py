@@ -1061,29 +1061,17 @@ def test_float_attention_kernel_matches_fp64():
         with pytest.raises(_ffi.TSearchError):
             _ffi.check(_ffi.load().ts_attention_float(0, C.c_void_p(x.data_ptr()), None, None, 1, S, 1, 1, hd, 0, 0.125,
                                                       C.c_void_p(out.data_ptr()), None, None))
-    # the pieces form (every product on the bf16 matrix pipe from bf16 pieces: ts_attention_pieces) against fp64 and against the fp32
-    # form, where its sequences fit; the same masks and the causal / grouped-query shapes
-    for hq, hkv, hd, causal, scale, smax in ((12, 12, 64, False, 0.125, 256), (16, 8, 128, True, 128 ** -0.5, 128), (3, 1, 256, False, 0.0625, 64)):
-        for B, S in ((3, 5), (2, 33), (2, smax)):
-            qkv = (torch.randn(B, S, (hq + 2 * hkv) * hd, generator=g) * 1.5).cuda()
-            mask = torch.ones(B, S, dtype=torch.int64)
-            mask[0, S // 2 + 1:] = 0
-            mask = mask.cuda()
-            f32, _ = attention_float(qkv, mask, B, S, hq, hkv, hd, causal, scale)
-            x3, px3 = attention_float(qkv, mask, B, S, hq, hkv, hd, causal, scale, want_pieces=True, from_pieces=True)
-            real = mask.bool()
-            assert (x3 - f32)[real].abs().max().item() < 2e-4 * max(1.0, f32[real].abs().max().item()), (hd, S)
-            assert torch.equal(px3.view(B, S, -1)[real], split_pieces(x3.view(B * S, -1), 0).view(B, S, -1)[real])
-            only = attention_float(qkv, mask, B, S, hq, hkv, hd, causal, scale, want_pieces=True, from_pieces=True, want_context=False)
-            assert only[0] is None and torch.equal(only[1].view(B, S, -1)[real], px3.view(B, S, -1)[real])
+    # only the pieces (the fp32-class forward reads nothing else): the same pieces, no fp32 context
+    qkv = (torch.randn(2, 33, 3 * 12 * 64, generator=g) * 1.5).cuda()
+    both = attention_float(qkv, None, 2, 33, 12, 12, 64, False, 0.125, want_pieces=True)
+    only = attention_float(qkv, None, 2, 33, 12, 12, 64, False, 0.125, want_pieces=True, want_context=False)
+    assert only[0] is None and torch.equal(only[1], both[1])
     # the stacked projection's bias added on the way in (the GEMM in front then runs without one): the same answer as on qkv + bias
     qkv = torch.randn(2, 40, 3 * 12 * 64, generator=g).cuda()
     bias = torch.randn(3 * 12 * 64, generator=g).cuda()
     want = attention_float(qkv + bias, None, 2, 40, 12, 12, 64, False, 0.125)[0]
     got = attention_float(qkv, None, 2, 40, 12, 12, 64, False, 0.125, bias=bias)[0]
     assert (got - want).abs().max().item() < 1e-5
-    got3 = attention_float(qkv, None, 2, 40, 12, 12, 64, False, 0.125, bias=bias, from_pieces=True)[0]
-    assert (got3 - want).abs().max().item() < 2e-4
 
 
 def test_long_corpus_texts_take_the_float_attention_in_the_fused_fp32_forward():

@@ -109,8 +109,6 @@ _SIGNATURES = {
     "ts_attention_short": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "ts_attention_float": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int,
                                      C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "ts_attention_pieces": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int,
-                                      C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ts_attention_gqa": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int,
                                    C.c_void_p, C.c_void_p]),
     "ts_add_rmsnorm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_int32, C.c_int, C.c_void_p,

@@ -235,49 +235,6 @@ extern "C" int ts_attention_float(int device, const void* qkv, const void* qkv_b
     return TS_OK;
 }
 
-extern "C" int ts_attention_pieces(int device, const void* qkv, const void* qkv_bias, const int64_t* attention_mask, int32_t batch, int32_t seq,
-                                   int32_t q_heads, int32_t kv_heads, int32_t head_dim, int causal, float scale, void* out, void* pieces,
-                                   void* stream) {
-    if (!qkv || (!out && !pieces)) return fail(TS_ERR_INVALID, "NULL argument");
-    if (((uintptr_t)qkv_bias & 15) != 0) return fail(TS_ERR_INVALID, "qkv_bias must be 16-byte aligned");
-    if (batch < 0 || seq < 1 || q_heads < 1 || kv_heads < 1 || q_heads % kv_heads != 0)
-        return fail(TS_ERR_INVALID, "batch = %d, seq = %d, heads = %d over %d", batch, seq, q_heads, kv_heads);
-    if ((head_dim != 64 && head_dim != 128 && head_dim != 256) || seq > attn_x3_max_seq(head_dim))
-        return fail(TS_ERR_UNSUPPORTED, "head size %d / %d tokens: this kernel serves head sizes 64 / 128 / 256 up to 256 / 128 / 64 tokens",
-                    head_dim, seq);
-    if ((((uintptr_t)qkv | (uintptr_t)out) & 15) != 0 || (((uintptr_t)pieces) & 7) != 0)
-        return fail(TS_ERR_INVALID, "qkv and out must be 16-byte aligned, pieces 8-byte");
-    if (!(scale > 0.0f)) return fail(TS_ERR_INVALID, "scale must be positive");
-    if (batch == 0) return TS_OK;
-    TS_TRY(check_device(device));
-    HIP_TRY(hipSetDevice(device));
-    hipStream_t st = (hipStream_t)stream;
-    const int T = (seq + 15) / 16, SP = (seq + 31) / 32 * 32;
-    const unsigned grid = (unsigned)((int64_t)batch * q_heads);
-    const unsigned threads = 64u * (unsigned)std::min(T, 4);
-    const float scale_log2e = scale * 1.4426950408889634f;
-#define TS_ATTN_X3(HD_, C_)                                                                                                   \
-    do {                                                                                                                      \
-        const int lds_ = attn_x3_lds(HD_, SP);                                                                                \
-        static std::atomic<unsigned long long> attr_{0};                                                                      \
-        const unsigned long long bit_ = 1ull << (device & 63);                                                                \
-        if (!(attr_.load(std::memory_order_acquire) & bit_)) {                                                                \
-            HIP_TRY(hipFuncSetAttribute((const void*)attention_x3_kernel<HD_, C_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                        attn_x3_lds(HD_, attn_x3_max_seq(HD_))));                                             \
-            attr_.fetch_or(bit_, std::memory_order_release);                                                                  \
-        }                                                                                                                     \
-        attention_x3_kernel<HD_, C_><<<grid, threads, lds_, st>>>((const float*)qkv, attention_mask, batch, seq, q_heads, kv_heads, \
-                                                                    scale_log2e, (float*)out, (unsigned short*)pieces,       \
-                                                                    (const float*)qkv_bias);                                  \
-    } while (0)
-    if (head_dim == 64) { if (causal) TS_ATTN_X3(64, true); else TS_ATTN_X3(64, false); }
-    else if (head_dim == 128) { if (causal) TS_ATTN_X3(128, true); else TS_ATTN_X3(128, false); }
-    else { if (causal) TS_ATTN_X3(256, true); else TS_ATTN_X3(256, false); }
-#undef TS_ATTN_X3
-    HIP_TRY(hipGetLastError());
-    return TS_OK;
-}
-
 extern "C" int ts_attention_gqa(int device, const void* qkv, const int64_t* attention_mask, int32_t batch, int32_t seq, int32_t q_heads,
                                int32_t kv_heads, int32_t head_dim, int causal, void* out, void* stream) {
     if (!qkv || !out) return fail(TS_ERR_INVALID, "NULL argument");

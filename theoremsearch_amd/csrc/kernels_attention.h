@@ -882,186 +882,4 @@ __global__ void __launch_bounds__(256) attention_f32_kernel(const float* __restr
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// The same attention with every product on the bf16 matrix pipe from bf16 PIECES (hi = bf16(x), lo = bf16(x - hi): sixteen
-// significant bits per factor, fp32 accumulation) - the attention of the fp32-class forward (fp32_gemm = "bf16x3", fused_forward.py):
-//     S^T = K_hi Q_hi^T + K_lo Q_hi^T + K_hi Q_lo^T        O^T = V^T_hi P_hi^T + V^T_lo P_hi^T + V^T_hi P_lo^T
-// on v_mfma_f32_16x16x32_bf16: 3 x 16 cycles per 32-deep step where the exact-fp32 form spends 8 x 32.  A workgroup per (sequence,
-// query head) splits K and V ONCE into LDS (K_hi / K_lo [key][HD], V^T_hi / V^T_lo [d][key]; a wave that split them per tile would be
-// bound by the conversions, not by the MFMAs); a wave walks blocks of 32 keys with a running softmax.  The rows of the two
-// 16-key score tiles of a block are the keys 8 g' + 4 t + r (tile t, row 4 g' + r): the lane that holds D[4 g' + r][q] of both tiles
-// then holds P[q][32 kb + 8 g' .. + 8) - exactly the B fragment of the second product, whose A fragment V^T[d][32 kb + 8 g .. + 8) is
-// one 16-byte LDS read.  No value crosses a lane between the two products.
-// Sequences: what fits the LDS as four bf16 images - 256 / 128 / 64 tokens for heads of 64 / 128 / 256; longer ones take the fp32 form.
-constexpr int attn_x3_max_seq(int HD) { return HD == 64 ? 256 : HD == 128 ? 128 : 64; }
-constexpr int attn_x3_kpitch(int HD) { return HD + 8; }                       // bf16 elements per key row of K_hi / K_lo
-constexpr int attn_x3_vpitch(int SP) { return SP + 8; }                       // bf16 elements per d row of V^T_hi / V^T_lo
-constexpr int attn_x3_lds(int HD, int SP) { return 2 * SP * attn_x3_kpitch(HD) * 2 + 2 * HD * attn_x3_vpitch(SP) * 2; }
-
-__device__ __forceinline__ void split8_bf16(const float* x, bf16x8& hi, bf16x8& lo) {
-    float h[8], l[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        h[e] = bf16_to_f32(f32_to_bf16(x[e]));
-        l[e] = x[e] - h[e];
-    }
-    const uint4 ph = make_uint4(pack_bf16_hw(h[0], h[1]), pack_bf16_hw(h[2], h[3]), pack_bf16_hw(h[4], h[5]), pack_bf16_hw(h[6], h[7]));
-    const uint4 pl = make_uint4(pack_bf16_hw(l[0], l[1]), pack_bf16_hw(l[2], l[3]), pack_bf16_hw(l[4], l[5]), pack_bf16_hw(l[6], l[7]));
-    hi = *reinterpret_cast<const bf16x8*>(&ph);
-    lo = *reinterpret_cast<const bf16x8*>(&pl);
-}
-
-template <int HD, bool CAUSAL>
-__global__ void __launch_bounds__(256) attention_x3_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ mask, int B, int S,
-                                                            int HQ, int HKV, float scale_log2e, float* __restrict__ out,
-                                                            unsigned short* __restrict__ pieces, const float* __restrict__ bias) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_x3[];
-    const int NB32 = (S + 31) / 32, SP = 32 * NB32;                      // key blocks of 32, padded sequence
-    constexpr int KP = attn_x3_kpitch(HD);
-    const int VP = attn_x3_vpitch(SP);
-    unsigned short* sKh = (unsigned short*)smem_x3;                      // [SP][KP]
-    unsigned short* sKl = sKh + SP * KP;
-    unsigned short* sVh = sKl + SP * KP;                                 // [HD][VP]
-    unsigned short* sVl = sVh + HD * VP;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const int b = blockIdx.x / HQ, h = blockIdx.x - b * HQ;
-    const int hk = h / (HQ / HKV);
-    const int r16 = lane & 15, g = lane >> 4;
-    const int64_t tok = (int64_t)(HQ + 2 * HKV) * HD;
-    const float* base = qkv + (int64_t)b * S * tok;
-    const float* qb = base + (int64_t)h * HD;
-    const float* kb = base + (int64_t)(HQ + hk) * HD;
-    const float* vb = base + (int64_t)(HQ + HKV + hk) * HD;
-    // K pieces [key][d]: 8 floats of a key row per thread -> 16 bytes of K_hi and of K_lo (keys past the sequence: zeros)
-    for (int i = threadIdx.x; i < SP * (HD / 8); i += blockDim.x) {
-        const int key = i / (HD / 8), c = i - key * (HD / 8);
-        float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (key < S) {
-            const float4 a = *(const float4*)(kb + (int64_t)key * tok + 8 * c), a2 = *(const float4*)(kb + (int64_t)key * tok + 8 * c + 4);
-            x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = a2.x; x[5] = a2.y; x[6] = a2.z; x[7] = a2.w;
-            if (bias) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] += bias[(int64_t)(HQ + hk) * HD + 8 * c + e];
-            }
-        }
-        bf16x8 hi, lo;
-        split8_bf16(x, hi, lo);
-        *(bf16x8*)(sKh + key * KP + 8 * c) = hi;
-        *(bf16x8*)(sKl + key * KP + 8 * c) = lo;
-    }
-    // V^T pieces [d][key]: a thread takes 4 columns of TWO consecutive keys and writes key pairs (4-byte LDS stores)
-    for (int i = threadIdx.x; i < (SP / 2) * (HD / 4); i += blockDim.x) {
-        const int kp = i / (HD / 4), c = i - kp * (HD / 4);
-        float v0[4] = {0.f, 0.f, 0.f, 0.f}, v1[4] = {0.f, 0.f, 0.f, 0.f};
-        if (2 * kp < S) { const float4 a = *(const float4*)(vb + (int64_t)(2 * kp) * tok + 4 * c); v0[0] = a.x; v0[1] = a.y; v0[2] = a.z; v0[3] = a.w; }
-        if (2 * kp + 1 < S) { const float4 a = *(const float4*)(vb + (int64_t)(2 * kp + 1) * tok + 4 * c); v1[0] = a.x; v1[1] = a.y; v1[2] = a.z; v1[3] = a.w; }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (bias) {
-                const float bv = bias[(int64_t)(HQ + HKV + hk) * HD + 4 * c + e];
-                if (2 * kp < S) v0[e] += bv;
-                if (2 * kp + 1 < S) v1[e] += bv;
-            }
-            const float h0 = bf16_to_f32(f32_to_bf16(v0[e])), h1 = bf16_to_f32(f32_to_bf16(v1[e]));
-            *(u32*)(sVh + (4 * c + e) * VP + 2 * kp) = pack_bf16_hw(h0, h1);
-            *(u32*)(sVl + (4 * c + e) * VP + 2 * kp) = pack_bf16_hw(v0[e] - h0, v1[e] - h1);
-        }
-    }
-    __syncthreads();
-    constexpr int KC = HD / 32;                                          // 32-deep steps of the first product
-    constexpr int DJ = HD / 16;                                          // 16-row tiles of O^T
-    const int T = (S + 15) / 16;
-    for (int it = 0;; ++it) {
-        const int lo_ = it * nwaves + wave, hi_ = (it + 1) * nwaves - 1 - wave;
-        const int qi = (CAUSAL && (it & 1)) ? hi_ : lo_;
-        if (it * nwaves >= T) break;
-        if (qi >= T) continue;
-        const int qrow = min(16 * qi + r16, S - 1);
-        const int qpos = 16 * qi + r16;
-        bf16x8 qh[KC], ql[KC];
-#pragma unroll
-        for (int c = 0; c < KC; ++c) {
-            const float4 a = *(const float4*)(qb + (int64_t)qrow * tok + 32 * c + 8 * g), a2 = *(const float4*)(qb + (int64_t)qrow * tok + 32 * c + 8 * g + 4);
-            float x[8] = {a.x, a.y, a.z, a.w, a2.x, a2.y, a2.z, a2.w};
-            if (bias) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] += bias[(int64_t)h * HD + 32 * c + 8 * g + e];
-            }
-            split8_bf16(x, qh[c], ql[c]);
-        }
-        f32x4 o[DJ];
-#pragma unroll
-        for (int dj = 0; dj < DJ; ++dj) o[dj] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float m = -INFINITY, l = 0.0f;
-        const int kb_end = CAUSAL ? (16 * qi + 15) / 32 + 1 : NB32;      // key blocks that hold an allowed key
-        for (int kbk = 0; kbk < kb_end; ++kbk) {
-            // scores of the block's two tiles; row i = r16 of tile t is key 32 kbk + 8 (i >> 2) + 4 t + (i & 3)
-            f32x4 st[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int krow = 32 * kbk + 8 * (r16 >> 2) + 4 * t + (r16 & 3);
-                f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int c = 0; c < KC; ++c) {
-                    const bf16x8 kh = *(const bf16x8*)(sKh + krow * KP + 32 * c + 8 * g);
-                    const bf16x8 kl = *(const bf16x8*)(sKl + krow * KP + 32 * c + 8 * g);
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[c], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[c], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[c], a, 0, 0, 0);
-                }
-                st[t] = a;
-            }
-            // lane (g, q = r16): st[t][r] = score of key 32 kbk + 8 g + 4 t + r
-            float p[8], tmax = -INFINITY;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int key = 32 * kbk + 8 * g + j;
-                const bool ok = key < S && (!mask || mask[(int64_t)b * S + key] != 0) && (!CAUSAL || key <= qpos);
-                p[j] = ok ? st[j >> 2][j & 3] : -INFINITY;
-                tmax = fmaxf(tmax, p[j]);
-            }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(m, tmax);
-            const float alpha = m_new > -INFINITY ? __builtin_amdgcn_exp2f((m - m_new) * scale_log2e) : 1.0f;
-            float psum = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                p[j] = p[j] > -INFINITY ? __builtin_amdgcn_exp2f((p[j] - m_new) * scale_log2e) : 0.0f;
-                psum += p[j];
-            }
-            psum += __shfl_xor(psum, 16, 64);
-            psum += __shfl_xor(psum, 32, 64);
-            l = l * alpha + psum;
-            m = m_new;
-            bf16x8 ph, pl;
-            split8_bf16(p, ph, pl);
-#pragma unroll
-            for (int dj = 0; dj < DJ; ++dj) {
-                const bf16x8 vh = *(const bf16x8*)(sVh + (16 * dj + r16) * VP + 32 * kbk + 8 * g);
-                const bf16x8 vl = *(const bf16x8*)(sVl + (16 * dj + r16) * VP + 32 * kbk + 8 * g);
-                f32x4 a = o[dj];
-                a[0] *= alpha; a[1] *= alpha; a[2] *= alpha; a[3] *= alpha;
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph, a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph, a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl, a, 0, 0, 0);
-                o[dj] = a;
-            }
-        }
-        const float inv = l > 0.0f ? 1.0f / l : 0.0f;
-        if (qpos < S) {
-            float* orow = out ? out + ((int64_t)b * S + qpos) * HQ * HD + (int64_t)h * HD : nullptr;
-#pragma unroll
-            for (int dj = 0; dj < DJ; ++dj) {
-                const float y[4] = {o[dj][0] * inv, o[dj][1] * inv, o[dj][2] * inv, o[dj][3] * inv};
-                if (orow) *(float4*)(orow + 16 * dj + 4 * g) = make_float4(y[0], y[1], y[2], y[3]);
-                if (pieces) {
-                    const int dtot = HQ * HD;
-                    store_pieces4(pieces + ((int64_t)b * S + qpos) * 3 * dtot, dtot, (h * HD + 16 * dj + 4 * g) / 4, y);
-                }
-            }
-        }
-    }
-}
-
 }  // namespace ts

@@ -68,21 +68,16 @@ def act_pieces(x: torch.Tensor, kind: int, bias: Optional[torch.Tensor] = None) 
 
 
 def attention_float(qkv: torch.Tensor, key_mask: Optional[torch.Tensor], B: int, S: int, hq: int, hkv: int, hd: int, causal: bool,
-                    scale: float, want_pieces: bool = False, bias: Optional[torch.Tensor] = None, want_context: bool = True,
-                    from_pieces: bool = False):
+                    scale: float, want_pieces: bool = False, bias: Optional[torch.Tensor] = None, want_context: bool = True):
     """fp32 attention of at most 128 tokens on the exact-fp32 matrix instructions, straight from the stacked projection's output
     ``qkv [B x S x (hq + 2 hkv) hd]`` (``ts_attention_float``; ``bias``: the projection's bias when its GEMM ran without one):
-    ``(context fp32 [B x S x hq hd] - None with ``want_context=False`` - , its bf16 pieces or None)``.  ``from_pieces=True`` (the
-    fp32-class forward): the same attention with every product on the bf16 matrix pipe from bf16 pieces of Q, K, V and the
-    probabilities (``ts_attention_pieces``) where the sequence fits (256 / 128 / 64 tokens for heads of 64 / 128 / 256)."""
+    ``(context fp32 [B x S x hq hd] - None with ``want_context=False`` - , its bf16 pieces or None)``."""
     import ctypes as C
     from . import _ffi
     qkv = qkv.contiguous()
     ctx = torch.empty((B, S, hq * hd), dtype=torch.float32, device=qkv.device) if (want_context or not want_pieces) else None
     pieces = torch.empty((B * S, 3 * hq * hd), dtype=torch.bfloat16, device=qkv.device) if want_pieces else None
-    lib = _ffi.load()
-    fn = lib.ts_attention_pieces if (from_pieces and S <= _PIECES_ATTENTION_MAX_SEQ.get(hd, 0)) else lib.ts_attention_float
-    _ffi.check(fn(
+    _ffi.check(_ffi.load().ts_attention_float(
         qkv.device.index or 0, C.c_void_p(qkv.data_ptr()), C.c_void_p(bias.data_ptr()) if bias is not None else None,
         C.c_void_p(key_mask.data_ptr()) if key_mask is not None else None, B, S, hq,
         hkv, hd, 1 if causal else 0, float(scale), C.c_void_p(ctx.data_ptr()) if ctx is not None else None,
@@ -92,7 +87,6 @@ def attention_float(qkv: torch.Tensor, key_mask: Optional[torch.Tensor], B: int,
 
 
 _FLOAT_ATTENTION_MAX_SEQ = {64: 512, 128: 256, 256: 128}      # what fits the CU's LDS as V^T (attn_f32_max_seq, kernels_attention.h)
-_PIECES_ATTENTION_MAX_SEQ = {64: 256, 128: 128, 256: 64}      # ... as the bf16 pieces of K and V^T (attn_x3_max_seq)
 
 
 def float_attention_applies(x: torch.Tensor, S: int, hd: int) -> bool:
@@ -279,7 +273,7 @@ class FusedBertForward:
             # type first copies the broadcast bias into the result: one more pass over every GEMM's output)
             qkv = pieces_mm(xp, L["wqkv_p"])
             if short32:                # the attention writes the pieces of its output itself
-                cp = attention_float(qkv, key_mask, B, S, self.heads, self.heads, hd, False, hd ** -0.5, want_pieces=True, bias=L["bqkv"], want_context=False, from_pieces=True)[1]
+                cp = attention_float(qkv, key_mask, B, S, self.heads, self.heads, hd, False, hd ** -0.5, want_pieces=True, bias=L["bqkv"], want_context=False)[1]
             else:
                 qkv = (qkv + L["bqkv"]).view(B, S, 3, self.heads, hd).permute(2, 0, 3, 1, 4)
                 ctx = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], attn_mask=mask)
@@ -446,7 +440,7 @@ class FusedQwen3Forward:
                                                C.c_void_p(cos.data_ptr()), C.c_void_p(sin.data_ptr()), self.eps, B * S, S, self.hq, self.hkv,
                                                hd, dt, stream))
                 if short32:
-                    cp = attention_float(qkv, key_mask, B, S, self.hq, self.hkv, hd, True, hd ** -0.5, want_pieces=True, want_context=False, from_pieces=True)[1]
+                    cp = attention_float(qkv, key_mask, B, S, self.hq, self.hkv, hd, True, hd ** -0.5, want_pieces=True, want_context=False)[1]
                 else:
                     cp = split_pieces(self._sdpa(qkv, mask, B, S, nq, nkv, hd).reshape(B * S, nq), 0)
                 x, h, hp = self._add_rmsnorm_pieces(x, pieces_mm(cp, L["wo_p"]).view(B, S, H), L["ln2"], True)
@@ -635,8 +629,7 @@ class FusedGemma3Forward:
                                                  hd, dt, stream))
             cp = None
             if short32:
-                ctx, cp = attention_float(qkv, key_mask, B, S, self.hq, self.hkv, hd, False, self.scaling, want_pieces=pieces, want_context=not pieces,
-                                          from_pieces=pieces)
+                ctx, cp = attention_float(qkv, key_mask, B, S, self.hq, self.hkv, hd, False, self.scaling, want_pieces=pieces, want_context=not pieces)
             else:
                 q = qkv[..., :nq].view(B, S, self.hq, hd).transpose(1, 2)
                 k = qkv[..., nq:nq + nkv].view(B, S, self.hkv, hd).transpose(1, 2)

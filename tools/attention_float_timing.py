@@ -50,9 +50,5 @@ for name, hq, hkv, hd, causal, scale in (("bert", 12, 12, 64, False, 0.125), ("q
                "max_abs_diff": float((got - want).abs().max()),
                "torch_us": timed(torch_way), "ts_attention_float_us": timed(lambda: attention_float(qkv, None, B, S, hq, hkv, hd, causal, scale)),
                "pieces_only_us": timed(lambda: attention_float(qkv, None, B, S, hq, hkv, hd, causal, scale, want_pieces=True, want_context=False)),
-               "x3_pieces_only_us": (timed(lambda: attention_float(qkv, None, B, S, hq, hkv, hd, causal, scale, want_pieces=True, want_context=False,
-                                                                     from_pieces=True)) if S <= {64: 256, 128: 128, 256: 64}[hd] else None),
-               "x3_max_abs_diff": (float((attention_float(qkv, None, B, S, hq, hkv, hd, causal, scale, from_pieces=True)[0] - want).abs().max())
-                                   if S <= {64: 256, 128: 128, 256: 64}[hd] else None),
                "gflop": round(4.0 * B * hq * S * S * hd / 1e9 * (0.5 if causal else 1.0), 2)}
         print(json.dumps(row), flush=True)
