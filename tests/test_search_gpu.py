@@ -756,38 +756,3 @@ def test_threshold_sample_of_degenerate_score_distributions(ts, dtype):
         local = np.searchsorted(rows, i)
         assert (rows[local] == i).all()
         check(q2, c2[rows], "ip", dtype, 200, s, local)
-
-
-@pytest.mark.parametrize("dtype,d", [("f32", 768), ("bf16", 768), ("f32", 100), ("bf16", 1024)])
-def test_tournament_select_of_the_scan_matches_the_histogram_select(ts, dtype, d):
-    """Small k behind the scan: the final k come from a tournament over the workgroups' sorted lists (select_lists_kernel);
-    TS_SELECT_LISTS=0 keeps the histogram select.  Same bits either way, 1 / 3 / 4 queries (one scan pass serves up to four),
-    k = 1 ... 16, with exact duplicates across workgroups, fewer rows than k, and a filtered search."""
-    rng = np.random.default_rng(1234 + d)
-    n = 300_000
-    c = rng.standard_normal((n, d), dtype=np.float32)
-    c[250_000] = c[7]                                           # the same score in two workgroups' lists: the lower row first
-    q = c[[7, 99, 5000, 123456]] + 0.05 * rng.standard_normal((4, d), dtype=np.float32)
-    with ts.TheoremIndex.from_embeddings(c, dtype=dtype, metric="cos") as ix:
-        for nq in (1, 3, 4):
-            for k in (1, 5, 10, 16):
-                s1, i1 = ix.search(q[:nq], k, algo="scan")
-                ix.set_option("TS_SELECT_LISTS", 0)
-                s0, i0 = ix.search(q[:nq], k, algo="scan")
-                ix.set_option("TS_SELECT_LISTS", None)
-                assert np.array_equal(i1, i0) and np.array_equal(s1, s0), (nq, k)
-                check(q[:nq], c, "cos", dtype, k, s1, i1)
-        if dtype == "f32":
-            assert ix.search(q[:1], 2, algo="scan")[1][0].tolist() == [7, 250_000]
-        mask = np.zeros(n, dtype=bool)
-        mask[::3] = True
-        s1, i1 = ix.search(q, 10, mask=mask)
-        ix.set_option("TS_SELECT_LISTS", 0)
-        s0, i0 = ix.search(q, 10, mask=mask)
-        ix.set_option("TS_SELECT_LISTS", None)
-        assert np.array_equal(i1, i0) and np.array_equal(s1, s0) and mask[i1].all()
-    small = rng.standard_normal((9, d), dtype=np.float32)           # fewer rows than k: padding
-    with ts.TheoremIndex.from_embeddings(small, dtype=dtype, metric="cos") as ix:
-        s, i = ix.search(q[:2], 12, algo="scan")
-        assert (i[:, 9:] == -1).all() and np.isneginf(s[:, 9:]).all()
-        check(q[:2], small, "cos", dtype, 12, s, i)

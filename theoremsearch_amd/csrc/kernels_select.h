@@ -686,55 +686,6 @@ __global__ void __launch_bounds__(kLevelThreads) select_hist_kernel(SelectArgs a
     }
 }
 
-// The same reduction for small k as a TOURNAMENT over the scan's sorted lists ([lists][k] keys, each list descending, lists <= 1024):
-// thread t holds list t in registers; every round the workgroup's largest head key is the next result and its owner - keys carry
-// the row, so they are unique - pops it.  k rounds of a wave maximum (shuffles), a 16-entry second level through LDS and one
-// barrier pair: ~1.5 us for k = 10 where the histogram select takes 18 us behind an fp32 scan (profiles/r05_c2_kernel_stats.csv) -
-// the single-query searches of the apps (streamlit_app.py:282-283, app_showcase_model.py:93-96) are one scan + this.
-constexpr int kListSelectMaxK = 16;
-template <int KMAX>
-__global__ void __launch_bounds__(1024) select_lists_kernel(SelectArgs a, int lists) {
-    __shared__ u64 wbest[16];
-    __shared__ u64 result[KMAX];
-    const int slot = blockIdx.x;
-    if (a.qcount && slot >= *a.qcount) return;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int k = a.kout;
-    u64 key[KMAX];
-    const u64* src = a.in + (int64_t)slot * a.in_stride + (int64_t)t * k;
-#pragma unroll
-    for (int j = 0; j < KMAX; ++j) key[j] = (t < lists && j < k) ? src[j] : 0ull;
-    for (int r = 0; r < a.k_user; ++r) {
-        u64 best = key[0];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const u64 o = shfl_u64(best, lane ^ off);
-            best = o > best ? o : best;
-        }
-        if (lane == 0) wbest[wave] = best;
-        __syncthreads();
-        u64 g = wbest[lane & 15];                         // every wave reduces the sixteen wave maxima itself
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) {
-            const u64 o = shfl_u64(g, lane ^ off);
-            g = o > g ? o : g;
-        }
-        if (t == 0) result[r] = g;
-        if (g != 0ull && key[0] == g) {                   // the owner pops its head (0 = an exhausted list never wins)
-#pragma unroll
-            for (int j = 0; j + 1 < KMAX; ++j) key[j] = key[j + 1];
-            key[KMAX - 1] = 0ull;
-        }
-        __syncthreads();
-    }
-    const int qid = a.qlist ? a.qlist[slot] : slot;
-    for (int i = t; i < a.k_user; i += blockDim.x) {
-        const u64 kk = result[i];
-        a.out_scores[(int64_t)qid * a.k_user + i] = kk ? key_score(kk) : -INFINITY;
-        a.out_idx[(int64_t)qid * a.k_user + i] = !kk ? -1 : a.id_map ? a.id_map[key_row(kk)] : (int64_t)key_row(kk) + a.row_offset;
-    }
-}
-
 // Cross-shard merge: per query, nparts * k_in (score, global id) pairs ->
 // best k_out.  Global ids are 64-bit here, so the sort runs on (ordered score, id) pairs.
 struct MergeArgs {

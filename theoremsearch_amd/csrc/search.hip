@@ -103,26 +103,6 @@ static int run_select_rounds(ts_index* ix, int slots, int m, int k, float* out_s
     u64* scratch[2] = {ix->partial2, ix->partial};
     int which = 0;
     int64_t in_stride = m;
-    // the scan's own output - `m / k` lists of k keys, each descending - for small k: a tournament over the list heads, one launch
-    // (TS_SELECT_LISTS=0 keeps the histogram select: the A/B of profiles/HISTORY.md, round 5)
-    if (k <= kListSelectMaxK && m % k == 0 && m / k <= 1024 && m / k >= 64 && ix->knobs.get(K_SELECT_LISTS, 1) != 0) {
-        SelectArgs a;
-        memset(&a, 0, sizeof(a));
-        a.in = in;
-        a.in_stride = in_stride;
-        a.m = m;
-        a.kout = k;
-        a.k_user = k;
-        a.row_offset = ix->row_offset;
-        a.id_map = ix->id_map;
-        a.qlist = qlist;
-        a.qcount = qcount;
-        a.out_scores = out_scores;
-        a.out_idx = out_idx;
-        select_lists_kernel<kListSelectMaxK><<<slots, 1024, 0, st>>>(a, m / k);
-        HIP_TRY(hipGetLastError());
-        return TS_OK;
-    }
     for (;;) {
         if (m > 1024 && m <= kHistSelectMax) {
             // the usual case (k <= 12 over 1024 workgroups, or k up to 256 over the fewer workgroups scan_search uses on a
