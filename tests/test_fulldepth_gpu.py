@@ -1,13 +1,14 @@
 """The three fused encoder forwards at the PUBLISHED depth of the checkpoints they stand for (12 / 28 / 24 layers), against the
 model's own forward on the same random-init weights, in the reference's arithmetic (fp32: SentenceTransformer(name) without a
-dtype, streamlit_app.py:55,173, app_create_embeddings.py:22,81) and in the opt-in bf16:
+dtype, streamlit_app.py:55,173, app_create_embeddings.py:22,81), in fp32x3 (the same fp32 weights and activations with every GEMM on
+the bf16 matrix pipe from bf16 pieces, fp32_gemm="bf16x3") and in the opt-in bf16:
 
   FusedBertForward    math-similarity/Bert-MLM_arXiv-MP-class_zbMath   12 layers, 768 wide, mean pooling
   FusedQwen3Forward   Qwen/Qwen3-Embedding-0.6B                        28 layers, 1024 wide, last-token pooling
   FusedGemma3Forward  google/embeddinggemma-300m                       24 layers, 768 wide, mean pooling + 2 Dense + Normalize
 
-40 ragged texts (padding masks, the library's attention kernels with key masks in bf16, torch's in fp32) and one unpadded
-batch (the form bench.py --workload c5 runs).  What is compared: the last hidden state of the real tokens (max and mean
+40 ragged texts (padding masks: the library's attention kernels with key masks, bf16 and fp32 alike) and one unpadded batch (the
+form bench.py --workload c5 runs).  What is compared: the last hidden state of the real tokens (max and mean
 absolute difference relative to the largest hidden value) and the sentence embeddings (cosine per text).  The tolerances
 below were MEASURED on an MI355X (`python tests/test_fulldepth_gpu.py` prints the table; profiles/r05_fulldepth.txt) and are
 pinned with a margin; DESIGN.md section 8 quotes them.  The weights are random: parity with the published checkpoints stays
