@@ -26,7 +26,13 @@ declares, read from its own files - never from a table in this module:
 A module type or option this class cannot run raises ``NotImplementedError`` - it never substitutes another pipeline
 silently.  A directory without ``modules.json`` is a plain transformers checkpoint: sentence-transformers then applies
 mean pooling, and so does this class.  Pretrained weights run in fp32 by default (as the reference does) with the
-checkpoint's own ``max_seq_length``; ``dtype=torch.bfloat16`` is an opt-in.
+checkpoint's own ``max_seq_length``.  Two opt-ins trade arithmetic for speed (measured on the random-init stand-ins at the
+published depths, tests/test_fulldepth_gpu.py, profiles/r05_encoder_topk_agreement.jsonl):
+``fp32_gemm="bf16x3"`` keeps fp32 weights and activations and runs every GEMM on the bf16 matrix pipe from bf16 pieces
+(embeddings 1 - cos <= 8.2e-8 from the fp32 forward's; 99.3-99.8 % of the top-10 positions over a 10M-row bf16 index unchanged;
+1.6-2.2 x the throughput); ``dtype=torch.bfloat16`` runs the whole forward in bf16 (1 - cos up to 1.4e-4; it REORDERS 14-32 % of
+the top-10 positions of random rows and changes the best row of up to 3.5 % of the queries; 2.6-4.3 x): a speed option for
+corpora whose neighbouring scores lie further apart than that, not the reference's answer.
 
 No weights offline.  When no checkpoint is found the constructor RAISES, unless ``allow_random_init=True`` (or
 ``TS_ALLOW_RANDOM_ENCODER=1``) asks for the stand-in used by the benchmark and the tests: a randomly initialised,
