@@ -16,7 +16,10 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def encoder():
     from theoremsearch_amd.encoder import SentenceEncoder
-    return SentenceEncoder(num_layers=2, allow_random_init=True)          # random-init BERT-base-shaped stand-in on cuda:0
+    import torch
+    # random-init BERT-base-shaped stand-in on cuda:0, in the opt-in bf16 (the tests below were written for its kernels; the fp32
+    # default - what the reference runs - is covered by the dtype=torch.float32 legs, tests/test_fulldepth_gpu.py and the long-text test)
+    return SentenceEncoder(num_layers=2, allow_random_init=True, dtype=torch.bfloat16)
 
 
 def test_cos_sim_and_semantic_search_match_oracle():
@@ -649,7 +652,7 @@ def test_fused_bert_forward_matches_the_models_own(encoder):
     fused = encoder.encode(texts, normalize_embeddings=True, convert_to_numpy=True)
     os.environ["TS_ENCODER_FUSED"] = "0"
     try:
-        plain_enc = SentenceEncoder(num_layers=2, allow_random_init=True)
+        plain_enc = SentenceEncoder(num_layers=2, allow_random_init=True, dtype=torch.bfloat16)
     finally:
         del os.environ["TS_ENCODER_FUSED"]
     assert plain_enc._fused is None
@@ -829,7 +832,7 @@ def test_fused_qwen3_forward_matches_the_models_own():
     import torch
     from theoremsearch_amd.encoder import FusedQwen3Forward, SentenceEncoder
     name = "Qwen/Qwen3-Embedding-0.6B"
-    enc = SentenceEncoder(name, num_layers=3, allow_random_init=True)
+    enc = SentenceEncoder(name, num_layers=3, allow_random_init=True, dtype=torch.bfloat16)
     assert isinstance(enc._fused, FusedQwen3Forward) and enc.pooling == "lasttoken" and enc.embedding_dim == 1024
     texts = [f"lemma {i}: every finite group of order {i} " + "is solvable " * (i % 5) for i in range(40)]
     tok = {k: v.cuda() for k, v in enc._tokenize(texts).items()}
@@ -848,7 +851,7 @@ def test_fused_qwen3_forward_matches_the_models_own():
     fused = enc.encode(texts, normalize_embeddings=True, convert_to_numpy=True)
     os.environ["TS_ENCODER_FUSED"] = "0"
     try:
-        plain_enc = SentenceEncoder(name, num_layers=3, allow_random_init=True)
+        plain_enc = SentenceEncoder(name, num_layers=3, allow_random_init=True, dtype=torch.bfloat16)
     finally:
         del os.environ["TS_ENCODER_FUSED"]
     assert plain_enc._fused is None
@@ -948,7 +951,7 @@ def test_fused_gemma3_forward_matches_the_models_own():
     import torch
     from theoremsearch_amd.encoder import FusedGemma3Forward, SentenceEncoder
     name = "google/embeddinggemma-300m"
-    enc = SentenceEncoder(name, num_layers=7, allow_random_init=True)              # seven layers: sliding and full attention ones
+    enc = SentenceEncoder(name, num_layers=7, allow_random_init=True, dtype=torch.bfloat16)   # seven layers: sliding and full attention ones
     assert isinstance(enc._fused, FusedGemma3Forward) and enc.pooling == "mean" and enc.embedding_dim == 768
     assert len(set(enc.model.config.layer_types)) == 2
     texts = [f"lemma {i}: every finite group of order {i} " + "is solvable " * (i % 5) for i in range(40)]
@@ -970,7 +973,7 @@ def test_fused_gemma3_forward_matches_the_models_own():
     assert np.allclose(np.sum(fused * fused, axis=1), 1.0, atol=1e-3)               # the pipeline's Normalize module
     os.environ["TS_ENCODER_FUSED"] = "0"
     try:
-        plain_enc = SentenceEncoder(name, num_layers=7, allow_random_init=True)
+        plain_enc = SentenceEncoder(name, num_layers=7, allow_random_init=True, dtype=torch.bfloat16)
     finally:
         del os.environ["TS_ENCODER_FUSED"]
     assert plain_enc._fused is None

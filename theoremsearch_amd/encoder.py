@@ -283,7 +283,7 @@ class SentenceEncoder:
                 self.pipeline.normalize = True
             self.max_seq_length = min(max_len, 512)
             if dtype is None:
-                dtype = torch.bfloat16 if self.device.type == "cuda" else torch.float32
+                dtype = torch.float32                  # the stand-in runs what a real checkpoint runs; bf16 is an opt-in for both
         self.pooling = self.pipeline.pooling
         self.model.to(self.device, dtype=dtype).eval()
         # BERT-family and Qwen3-family models on a GPU run a fused forward (FusedBertForward / FusedQwen3Forward);
