@@ -1,6 +1,7 @@
 """GPU tests of the host-side API added in round 2: index growth (reserve / append), the sharded search behind the C ABI
 (ts_shards_*, ts_comm_*), ordering of calls across streams, per-handle options.  Everything goes through libtsearch.so."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -183,12 +184,24 @@ def test_shards_on_one_device_answer_like_the_whole_index(ts, ngpu):
     c[70_000] = c[5]                                        # an exact tie across shards: the lower global id ranks first
     with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as whole:
         want_s, want_i = whole.search(q, k)
-    with Shards(n, 768, ngpu, dtype="bf16", metric="ip", devices=[0] * ngpu) as sh:
-        assert not sh.uses_rccl
-        assert sh.bounds(0)[0] == 0 and sh.bounds(ngpu - 1)[1] == n
-        for r0 in range(0, n, 25_000):                      # uploads that straddle shard boundaries
-            sh.upload(c[r0:r0 + 25_000], r0)
-        scores, idx = sh.search(q, k)
+    for threads in ("1", "0"):                              # one host thread per shard (default) / every enqueue from the caller's thread
+        os.environ["TS_SHARDS_THREADS"] = threads
+        try:
+            with Shards(n, 768, ngpu, dtype="bf16", metric="ip", devices=[0] * ngpu) as sh:
+                assert not sh.uses_rccl
+                assert sh.bounds(0)[0] == 0 and sh.bounds(ngpu - 1)[1] == n
+                for r0 in range(0, n, 25_000):              # uploads that straddle shard boundaries
+                    sh.upload(c[r0:r0 + 25_000], r0)
+                scores, idx = sh.search(q, k)
+                for _ in range(3):                          # the workers are persistent: the same answer call after call
+                    s2, i2 = sh.search(q, k)
+                    assert np.array_equal(i2, idx) and np.array_equal(s2, scores)
+        finally:
+            del os.environ["TS_SHARDS_THREADS"]
+        if threads == "1":
+            first = (scores, idx)
+        else:
+            assert np.array_equal(idx, first[1]) and np.array_equal(scores, first[0])
     # same ids; scores bit-identical while the shards run the same kernel as the whole index (small shards fall under
     # the MFMA path's minimum size and take the scan, whose fp32 summation order differs in the last bit)
     assert np.array_equal(idx, want_i)
