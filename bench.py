@@ -248,6 +248,16 @@ def launch_ranks(n):
     sys.exit(rc)
 
 
+def decide_placement(overlap_ms, inline_ms, discard=1, margin=0.02):
+    """The exchange-placement rule of the N > 1 trial: per mode the rounds' ms per step in the order they ran; the first
+    `discard` rounds of each mode do not count (lazy connection set-up, clock ramp), the MEDIANS of the rest are compared, and
+    `overlap` - the placement the design argues for - is kept unless `inline` wins by more than `margin`.
+    Returns (use_overlap, median_overlap, median_inline)."""
+    med_o = float(np.median(overlap_ms[discard:] if len(overlap_ms) > discard else overlap_ms))
+    med_i = float(np.median(inline_ms[discard:] if len(inline_ms) > discard else inline_ms))
+    return (not (med_i < (1.0 - margin) * med_o)), med_o, med_i
+
+
 def rank_dies_with_parent():
     """A rank started by `launch_ranks`: ask the kernel for SIGTERM when the parent goes away (prctl PR_SET_PDEATHSIG), so a
     parent killed with SIGKILL (`timeout -k`) does not leave ranks holding their GPUs.  Called before torch is imported."""
@@ -686,8 +696,8 @@ def main():
                 t_ = torch.tensor([time.perf_counter() - tt], dtype=torch.float64, device="cuda")
                 dist.all_reduce(t_, op=dist.ReduceOp.MAX)
                 times[mode].append(float(t_.item()) / trial * 1e3)
-        med = {m_: float(np.median(times[m_][1:])) for m_ in (True, False)}
-        overlap[0] = not (med[False] < 0.98 * med[True])
+        overlap[0], med_o_, med_i_ = decide_placement(times[True], times[False])
+        med = {True: med_o_, False: med_i_}
         placement_trial = {"overlap_ms_per_step": [round(x, 4) for x in times[True]], "inline_ms_per_step": [round(x, 4) for x in times[False]],
                            "steps_per_round": trial, "rounds": rounds, "rounds_discarded": 1, "warmup_exchanges_per_mode": warm,
                            "median_overlap_ms": round(med[True], 4), "median_inline_ms": round(med[False], 4),

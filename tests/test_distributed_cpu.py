@@ -143,3 +143,20 @@ def test_bench_launches_eight_ranks_and_runs_its_host_collectives():
                          capture_output=True, text=True, timeout=280, cwd=root, env=env)
     if not __import__("conftest").gpu_available():
         assert bad.returncode != 0 and not bad.stdout.strip(), (bad.returncode, bad.stdout)
+
+
+def test_the_exchange_placement_rule_does_not_decide_on_noise():
+    """bench.decide_placement: the first round of each mode is discarded (RCCL's lazy set-up: round 4's trial saw 1.2 ms then
+    5-11 ms in consecutive rounds of the same mode), medians are compared, and `inline` must win by more than 2 % to displace
+    `overlap`."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    use, mo, mi = bench.decide_placement([9.0, 0.450, 0.452, 0.449], [0.30, 0.455, 0.451, 0.460])
+    assert use and abs(mo - 0.450) < 1e-9 and abs(mi - 0.455) < 1e-9          # a lucky first inline round does not count
+    assert bench.decide_placement([0.5, 0.450, 0.451, 0.449], [0.5, 0.445, 0.446, 0.444])[0]       # 1.1 % better: not enough
+    assert not bench.decide_placement([0.5, 0.450, 0.451, 0.449], [0.5, 0.430, 0.431, 0.429])[0]   # 4.4 % better: inline
+    assert bench.decide_placement([0.5, 0.450, 5.0, 0.449], [0.5, 0.452, 0.451, 0.453])[0]         # one slow overlap round: the median holds
+    assert bench.decide_placement([1.23, 5.15], [1.20, 11.12])[0]                                    # round 4's two noisy rounds: overlap stays
