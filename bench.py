@@ -991,7 +991,12 @@ def main():
             # very queries whose search was timed above; one untimed call on two queries first (thread pool, primitive caches)
             from theoremsearch_amd.encoder import SentenceEncoder
             host_enc = SentenceEncoder(enc_name, device="cpu", dtype=torch.float32, allow_random_init=True)
-            torch.set_num_threads(ncpu)
+            # the reference asks for every core (torch.set_num_threads(cpu_count), ec2/generate_embeddings/embeddings.py:21); on a
+            # 256-thread host that turns a 16-query forward into minutes of thread-pool contention (measured: 27 s for the BERT
+            # shape, 168 s for the Qwen3 / Gemma3 shapes), so the baseline's encode runs on at most 32 threads - the faster
+            # setting for the baseline - and says so
+            enc_threads = max(1, min(ncpu, 32))
+            torch.set_num_threads(enc_threads)
             ids_h, mask_h = tok_ids[:nq_timed].cpu(), tok_mask[:nq_timed].cpu()
             with torch.inference_mode():
                 host_enc.pool(host_enc.forward_hidden(ids_h[:2], mask_h[:2]), mask_h[:2], True)
@@ -1001,8 +1006,9 @@ def main():
             # the host's fp32 embeddings against the device's (the fused forward at --encoder-dtype): cosine per query
             e_dev = oracle.bf16_bits_to_f32(q_host[:nq_timed]) if bf16 else q_host[:nq_timed]
             cosines = np.sum(emb_h.numpy() * e_dev, axis=1) / np.maximum(np.linalg.norm(e_dev, axis=1), 1e-12)
+            torch.set_num_threads(ncpu)
             enc_how = (f"; host model.encode of the same {nq_timed} x {args.seq_len}-token queries (same random-init weights, fp32, "
-                       f"{ncpu} threads): {t_enc:.2f}s, included; cosine of the device's embeddings ({args.encoder_dtype} forward) "
+                       f"{enc_threads} threads): {t_enc:.2f}s, included; cosine of the device's embeddings ({args.encoder_dtype} forward) "
                        f"with the host's fp32 ones: min {float(cosines.min()):.6f}")
             del host_enc
             t_cpu += t_enc
@@ -1013,6 +1019,7 @@ def main():
                          f"nothing scaled{enc_how}"}
         if encoder is not None:
             cpu["encode_seconds"] = round(t_enc, 3)
+            cpu["encode_threads"] = enc_threads
         del c_s
 
     if rank == 0:
