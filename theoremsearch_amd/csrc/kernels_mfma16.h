@@ -242,20 +242,31 @@ __device__ __forceinline__ void pair_read_word(unsigned& dst, unsigned lds_word)
 // 32x32x2 kernel of kernels_mfma_f32.h stays selectable: TS_MFMA_F32=32).
 // PAIR: the paired full pass (MfmaArgs::pair; a template parameter, not a run-time branch: the headline instantiation has no
 // register to spare for the pair's bookkeeping).
-template <int D, int NB, int VARIANT, bool SPARSE, bool F32 = false, bool PAIR = false>
+// KSPLIT (the paired pass of d = 1024): the four waves of a workgroup are a 2 x 2 grid - wave w holds the queries of column
+// w & 1 (64 of the workgroup's 128: NB = 4 blocks) for the k-steps of HALF w >> 1 of every unit (4 of its 8 k-steps).  Each
+// corpus fragment a wave reads from LDS then feeds four MFMAs, as at d = 768, instead of two - at NB = 2 the pass spends 8 x the
+// corpus in LDS reads and runs 15 % behind d = 768 per flop - and the two partial sums of a (row, query) meet through LDS once per
+// tile: a wave keeps two of its four query blocks and hands the other two to its partner (wave ^ 2), 4 KB each way; the
+// partner's half of tile t is picked up at the end of tile t + 1 (four unit barriers later: no barrier of its own), so the
+// threshold test of a tile runs one tile late.
+template <int D, int NB, int VARIANT, bool SPARSE, bool F32 = false, bool PAIR = false, bool KSPLIT = false>
 __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a) {
     static_assert(!PAIR || (!SPARSE && !F32), "pairs exist for the bf16 full pass");
+    static_assert(!KSPLIT || (PAIR && NB == 4 && VARIANT == 0 && D == 1024), "the k-split is the paired pass of d = 1024 with four query blocks per wave");
     constexpr int Deq = F32 ? 2 * D : D;                 // row length in 2-byte elements
-    using dims = Mfma16Dims<Deq>;
+    using dims = typename std::conditional<KSPLIT, MfmaDims<Deq, MfmaGeomKsplit<Deq>>, Mfma16Dims<Deq>>::type;
     constexpr bool kNoEpi = VARIANT == 1 || VARIANT == 7;
     constexpr bool kNoDma = VARIANT == 7;
     constexpr bool kNoMma = VARIANT == 2;
-    constexpr int kSteps = Deq / 32;                     // k-steps (16-byte chunks per lane) per tile
-    constexpr int kUnitSteps = dims::kUnitK / 32;        // k-steps per unit
+    constexpr int kStepsAll = Deq / 32;                  // k-steps (16-byte chunks per lane) per tile
+    constexpr int kUnitStepsAll = dims::kUnitK / 32;     // k-steps per unit
+    constexpr int kSteps = KSPLIT ? kStepsAll / 2 : kStepsAll;               // ... of them, this wave's
+    constexpr int kUnitSteps = KSPLIT ? kUnitStepsAll / 2 : kUnitStepsAll;
     constexpr int kUnits = dims::kUnits, kUnitBytes = dims::kUnitBytes, kSlots = dims::kSlots, kPieces = dims::kPieces;
     constexpr int kUnitK = dims::kUnitK;
     constexpr int kPieceEvery = kUnitSteps / kPieces;    // one DMA piece every so many k-steps
     static_assert(kUnitSteps % kPieces == 0 && kPieceEvery >= 1, "DMA pieces must spread evenly over the k-steps");
+    static_assert(!KSPLIT || (kUnitSteps == 4 && kPieces == 4), "k-split: four k-steps and four DMA pieces per unit and wave");
     static_assert(NB >= 1 && NB * kSteps * 4 <= 384, "query fragments must fit the register file");
     static_assert(!F32 || NB <= 2, "the fp32 issue order is written for one or two query blocks per wave");
     static_assert(kUnits == 1 || kUnits == 2 || kUnits == 4 || kUnits == 8, "units per tile");
@@ -282,14 +293,19 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     const int G = PAIR ? (int)(gridDim.x >> 1) : (int)gridDim.x;
     const int nwriters = 4 * gridDim.x;
     const int writer = 4 * blockIdx.x + kq;
+    const int khalf = KSPLIT ? (wave >> 1) : 0;          // k-split: which half of every unit's k-steps this wave multiplies
     int qid[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) qid[b] = qhalf * 64 * NB + (b * 4 + wave) * 16 + r16;
+    for (int b = 0; b < NB; ++b)
+        qid[b] = KSPLIT ? qhalf * 128 + (b * 2 + (wave & 1)) * 16 + r16 : qhalf * 64 * NB + (b * 4 + wave) * 16 + r16;
 
     mfma_level_begin(a);
     uint4* stage = (uint4*)(smem + dims::kLds) + wave * kMfma16StageCap;          // this wave's staged candidates
     u32* stage_cnt = (u32*)(smem + dims::kLds + 4 * kMfma16StageCap * 16) + wave;
     if (kStaged && lane == 0) *stage_cnt = 0;
+    // k-split: the partial sums a wave hands to its partner, [tile parity][wave][4][lane] x 16 bytes = 2 x 16 KB behind the pair's word
+    uint4* const xbuf = (uint4*)(smem + dims::kLds + kMfma16StageBytes + kMfma16PaceBytes);
+    f32x4 held[2][2];                                    // ... and the two blocks it keeps, until the partner's half has arrived
     // pair pacing (see pair_publish_and_fetch): wave 0 only; `pace_word` = LDS address of the partner's position
     const bool pace = PAIR && a.pair_pos != nullptr && a.pair_lag > 0 && wave == 0;
     unsigned* const pace_mine = PAIR ? a.pair_pos + 2 * wg + qhalf : nullptr;
@@ -332,6 +348,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     int xo[2];
 #pragma unroll
     for (int sp = 0; sp < 2; ++sp) xo[sp] = lane_off + (((4 * sp + kq) ^ sw) << 4);
+    const unsigned koff = KSPLIT ? (unsigned)(khalf * (kUnitSteps / 2) * 4096) : 0u;     // this wave's k-steps inside a unit image
 
 #define TS16_ISSUED()                                                                 \
     do {                                                                              \
@@ -359,11 +376,14 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     for (int b = 0; b < NB; ++b) {
         const bf16x8* pq = F32 ? (const bf16x8*)((const float*)a.q + (int64_t)qid[b] * D + 4 * kq)
                                : (const bf16x8*)(a.q + (int64_t)qid[b] * D + 8 * kq);
+        if (KSPLIT) pq += 4 * kUnitSteps * khalf;          // this wave's k-steps of a unit: 4 khalf .. 4 khalf + 3
 #pragma unroll
         for (int ks = 0; ks < kSteps; ++ks) {
             const int f = b * kSteps + ks;
-            if (f < kQV) qv[f < kQV ? f : 0] = pq[4 * ks];
-            else qa[f >= kQV ? f - kQV : 0] = pq[4 * ks];
+            // the k-step of the row this fragment multiplies (k-split: local step ks = unit ks / 4, step ks % 4 of this wave's half)
+            const int kabs = KSPLIT ? (ks / kUnitSteps) * kUnitStepsAll + (ks % kUnitSteps) : ks;
+            if (f < kQV) qv[f < kQV ? f : 0] = pq[4 * kabs];
+            else qa[f >= kQV ? f - kQV : 0] = pq[4 * kabs];
         }
     }
     float thr[NB];
@@ -385,7 +405,8 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     // A-fragment ring: af[2 (s % kA) + rb]; k-steps 0 .. kA - 2 of the first unit are fetched here
     frag16 af[2 * kA] = {};
     {
-        const unsigned p0 = lds_base + xo[0], p1 = lds_base + xo[1];
+        const unsigned p0 = lds_base + xo[0] + (KSPLIT ? khalf * (kUnitSteps / 2) * 4096 : 0);
+        const unsigned p1 = lds_base + xo[1] + (KSPLIT ? khalf * (kUnitSteps / 2) * 4096 : 0);
         lds_read16<0>(af[0], p0);
         lds_read16<2048>(af[1], p0);
         lds_read16<0>(af[2], p1);
@@ -526,8 +547,8 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         constexpr int cui_ = ((UI) + kSlots - 1) % kUnits;                                                 \
         const unsigned noff = (soff + kUnitBytes == (unsigned)dims::kLds) ? 0u : soff + kUnitBytes;        \
         unsigned ua[2], na[2];                                                                             \
-        ua[0] = lds_base + soff + xo[0]; ua[1] = lds_base + soff + xo[1];                                  \
-        na[0] = lds_base + noff + xo[0]; na[1] = lds_base + noff + xo[1];                                  \
+        ua[0] = lds_base + soff + xo[0] + koff; ua[1] = lds_base + soff + xo[1] + koff;                    \
+        na[0] = lds_base + noff + xo[0] + koff; na[1] = lds_base + noff + xo[1] + koff;                    \
         if constexpr (!kNoDma) wait_vmcnt<(kSlots - 3) * kPieces>();   /* own pieces of unit u + 1 */       \
         if constexpr (PAIR && (UI) == (2 % kUnits)) {                   /* ahead of the partner: give way */ \
             /* (the read and its use are unconditional: a value defined under a branch would reach this point through a */ \
@@ -551,7 +572,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         const unsigned char* ssrc = s_tile + cui_ * (kUnitK * 2);       /* wave-uniform: SGPRs */           \
         const unsigned idst = lds0 + poff;                                                                 \
         TS16_STEP(UI, 0); TS16_STEP(UI, 1); TS16_STEP(UI, 2); TS16_STEP(UI, 3);                            \
-        TS16_STEP(UI, 4); TS16_STEP(UI, 5); TS16_STEP(UI, 6); TS16_STEP(UI, 7);                            \
+        if constexpr (kUnitSteps > 4) { TS16_STEP(UI, 4 % kUnitSteps); TS16_STEP(UI, 5 % kUnitSteps); TS16_STEP(UI, 6 % kUnitSteps); TS16_STEP(UI, 7 % kUnitSteps); } \
         if constexpr (kUnitSteps > 8) { TS16_STEP(UI, 8 % kUnitSteps); TS16_STEP(UI, 9 % kUnitSteps); TS16_STEP(UI, 10 % kUnitSteps); TS16_STEP(UI, 11 % kUnitSteps); } \
         if constexpr (cui_ == kUnits - 1 && !kNoDma) s_tile += steady_jump;                                \
         poff = soff;                                                                                       \
@@ -562,8 +583,8 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     do {                                                                                                   \
         const int nslot = (slot + 1 == kSlots) ? 0 : slot + 1;                                             \
         unsigned ua[2], na[2];                                                                             \
-        ua[0] = lds_base + slot * kUnitBytes + xo[0]; ua[1] = lds_base + slot * kUnitBytes + xo[1];        \
-        na[0] = lds_base + nslot * kUnitBytes + xo[0]; na[1] = lds_base + nslot * kUnitBytes + xo[1];      \
+        ua[0] = lds_base + slot * kUnitBytes + xo[0] + koff; ua[1] = lds_base + slot * kUnitBytes + xo[1] + koff;   \
+        na[0] = lds_base + nslot * kUnitBytes + xo[0] + koff; na[1] = lds_base + nslot * kUnitBytes + xo[1] + koff; \
         /* certify unit u + 1 (own pieces, then everyone's); every wave is past unit u - 1: its slot is free */ \
         unsigned long long s0_ = 0, s1_ = 0;                                                               \
         if (VARIANT == 5) s0_ = cycle_stamp();                                                             \
@@ -580,14 +601,40 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         /* (wave-uniform by construction; with one unit per tile hipcc loses track of that and would hand M0 a VGPR) */ \
         const unsigned idst = __builtin_amdgcn_readfirstlane(lds0 + issue_slot * kUnitBytes);              \
         TS16_STEP(UI, 0); TS16_STEP(UI, 1); TS16_STEP(UI, 2); TS16_STEP(UI, 3);                            \
-        TS16_STEP(UI, 4); TS16_STEP(UI, 5); TS16_STEP(UI, 6); TS16_STEP(UI, 7);                            \
+        if constexpr (kUnitSteps > 4) { TS16_STEP(UI, 4 % kUnitSteps); TS16_STEP(UI, 5 % kUnitSteps); TS16_STEP(UI, 6 % kUnitSteps); TS16_STEP(UI, 7 % kUnitSteps); } \
         if constexpr (kUnitSteps > 8) { TS16_STEP(UI, 8 % kUnitSteps); TS16_STEP(UI, 9 % kUnitSteps); TS16_STEP(UI, 10 % kUnitSteps); TS16_STEP(UI, 11 % kUnitSteps); } \
         if (do_issue) TS16_ISSUED();                                                                       \
         slot = nslot;                                                                                      \
         ++u;                                                                                               \
     } while (0)
 
-    static_assert(kUnitSteps == 8 || kUnitSteps == 12, "unit = 8 or 12 k-steps of 32");
+    // k-split: the test of tile TP (one tile late): the partner's partial sums of the two blocks this wave kept + its own
+#define TS16_KSPLIT_FINISH(TP)                                                                             \
+    do {                                                                                                   \
+        const int tp_ = (TP);                                                                              \
+        const uint4* theirs = xbuf + ((tp_ & 1) * 4 + (wave ^ 2)) * 256 + lane;                            \
+        f32x4 sum_[2][2];                                                                                  \
+        _Pragma("unroll") for (int rb_ = 0; rb_ < 2; ++rb_)                                                \
+            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                             \
+                const uint4 v_ = theirs[(rb_ * 2 + i_) * 64];                                              \
+                sum_[rb_][i_] = held[rb_][i_] + *reinterpret_cast<const f32x4*>(&v_);                      \
+            }                                                                                              \
+        const int kb_ = 2 * khalf;                                                                         \
+        float best_[2];                                                                                    \
+        u64 hit_[2];                                                                                       \
+        hit_[0] = mfma16_block_test(sum_[0][0], sum_[1][0], khalf ? thr[2] : thr[0], best_[0]);            \
+        hit_[1] = mfma16_block_test(sum_[0][1], sum_[1][1], khalf ? thr[3] : thr[1], best_[1]);            \
+        if (__builtin_expect((hit_[0] | hit_[1]) != 0, 0)) {                                               \
+            const int64_t lt_ = t0 + tp_;                                                                  \
+            const int64_t tile_row_ = (a.run == 1 ? lt_ * a.tile_stride : (lt_ / a.run) * a.run * a.tile_stride + lt_ % a.run) * kTileRows; \
+            const int64_t row_base_ = tile_row_ + 4 * kq;                                                  \
+            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                               \
+                if (hit_[i_] != 0)                                                                         \
+                    mfma16_append_block<kStaged>(sum_[0][i_], sum_[1][i_], khalf ? thr[2 + i_] : thr[i_], best_[i_],     \
+                                                 khalf ? qid[2 + i_] : qid[i_], writer, nwriters, cnt[(kb_ + i_) & (NB - 1)], row_base_, a, stage, stage_cnt); \
+        }                                                                                                  \
+    } while (0)
+    static_assert(kUnitSteps == 8 || kUnitSteps == 12 || (KSPLIT && kUnitSteps == 4), "unit = 8 or 12 k-steps of 32 (k-split: this wave's 4 of 8)");
     static_assert(kSlots >= 3, "the steady part keeps kSlots - 3 units in flight behind its wait");
     // Steady tiles: every unit of the tile still has a unit to issue kSlots - 1 ahead.  (Runs of tiles, a shallower
     // ring and the stamped build go through the general units below.)
@@ -639,6 +686,21 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
             if constexpr (!kNoMma) lds_ring_landed(af);
         }
         if constexpr (kNoMma) continue;
+        if constexpr (KSPLIT) {
+            mfma16_settle<NB>(acc);
+            if (t > 0) TS16_KSPLIT_FINISH(t - 1);        // the previous tile: the partner's half was written four barriers ago
+            uint4* mine = xbuf + ((t & 1) * 4 + wave) * 256 + lane;
+            if (khalf == 0) {                             // keep blocks 0, 1; blocks 2, 3 go to the partner
+                held[0][0] = acc[0][0]; held[0][1] = acc[0][1]; held[1][0] = acc[1][0]; held[1][1] = acc[1][1];
+                mine[0] = *reinterpret_cast<const uint4*>(&acc[0][2]); mine[64] = *reinterpret_cast<const uint4*>(&acc[0][3]);
+                mine[128] = *reinterpret_cast<const uint4*>(&acc[1][2]); mine[192] = *reinterpret_cast<const uint4*>(&acc[1][3]);
+            } else {
+                held[0][0] = acc[0][2]; held[0][1] = acc[0][3]; held[1][0] = acc[1][2]; held[1][1] = acc[1][3];
+                mine[0] = *reinterpret_cast<const uint4*>(&acc[0][0]); mine[64] = *reinterpret_cast<const uint4*>(&acc[0][1]);
+                mine[128] = *reinterpret_cast<const uint4*>(&acc[1][0]); mine[192] = *reinterpret_cast<const uint4*>(&acc[1][1]);
+            }
+            continue;
+        }
         // The last k-step issued its MFMAs in block order, so with NB = 4 the results of block b are at least 6 MFMAs
         // old when its test (5 VALU instructions per block, in order) reads them; fewer blocks need explicit wait states.
 #ifdef TS16_ORDER_A
@@ -675,6 +737,14 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
                                                  stage, stage_cnt);
         }
     }
+    if constexpr (KSPLIT) {
+        // the last tile's halves: one more barrier (every wave has written), then the same test
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        TS16_KSPLIT_FINISH(nt - 1);
+    }
+#undef TS16_KSPLIT_FINISH
 #undef TS16_UNIT
 #undef TS16_UNIT_S
 #undef TS16_STEP

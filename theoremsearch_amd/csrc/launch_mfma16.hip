@@ -68,6 +68,19 @@ static int launch_mfma16_pair(int grid, hipStream_t st, const MfmaArgs& a) {
         attr_done.fetch_or(bit, std::memory_order_release);
     }
     if (grid % 16 != 0) return fail(TS_ERR_INTERNAL, "the paired pass needs a grid of whole groups of 16 workgroups, not %d", grid);
+    if (a.pair == 2) {
+        // the k-split form: 2 x 2 waves (query column x k half), six ring slots, two 16 KB exchange buffers for the partial sums
+        constexpr int lds_k = MfmaDims<1024, MfmaGeomKsplit<1024>>::kLds + kMfma16StageBytes + kMfma16PaceBytes + 2 * 16384;
+        static_assert(lds_k <= 160 * 1024, "ring + staged candidates + the pair's word + the exchange buffers must fit the CU's LDS");
+        static std::atomic<unsigned long long> attr_k{0};
+        if (!(attr_k.load(std::memory_order_acquire) & bit)) {
+            HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<1024, 4, 0, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_k));
+            attr_k.fetch_or(bit, std::memory_order_release);
+        }
+        mfma16_topk_kernel<1024, 4, 0, false, false, true, true><<<grid, kMfmaThreads, lds_k, st>>>(a);
+        HIP_TRY(hipGetLastError());
+        return TS_OK;
+    }
     mfma16_topk_kernel<1024, 2, 0, false, false, true><<<grid, kMfmaThreads, lds, st>>>(a);
     HIP_TRY(hipGetLastError());
     return TS_OK;
@@ -76,7 +89,7 @@ static int launch_mfma16_pair(int grid, hipStream_t st, const MfmaArgs& a) {
 // d = 384 / 512 / 768 / 1024, nb = query blocks of 16 per wave (64 * nb queries per launch; d = 1024: at most 3)
 int launch_pass_mfma16(int d, int nb, bool full_pass, int variant, int grid, hipStream_t st, const MfmaArgs& a) {
     if (a.pair) {
-        if (d != 1024 || nb != 2 || !full_pass) return fail(TS_ERR_INTERNAL, "paired pass asked for d = %d, %d blocks per wave", d, nb);
+        if (d != 1024 || nb != 2 || !full_pass) return fail(TS_ERR_INTERNAL, "paired pass asked for d = %d, %d blocks per wave", d, nb);   // (a.pair == 2: the k-split form, same queries per workgroup)
         return launch_mfma16_pair(grid, st, a);
     }
 #define TS_NB_SWITCH(D_)                                                          \
