@@ -65,7 +65,7 @@ template <int D> struct MfmaGeom16 : MfmaGeom<D> {};
 template <> struct MfmaGeom16<384> { static constexpr int kUnitK = 384, kSlots = 6; };
 // the k-split form of the paired d = 1024 pass (kernels_mfma16.h): six slots - the ring gives 32 KB of LDS to the partial sums
 // the wave pairs exchange
-template <int D> struct MfmaGeomKsplit { static constexpr int kUnitK = 256, kSlots = 6; };
+template <int D> struct MfmaGeomKsplit { static constexpr int kUnitK = 256, kSlots = 8; };
 template <int D, class Geom = MfmaGeom<D>> struct MfmaDims {
     static constexpr int kKSteps = D / 16;
     static constexpr int kUnitK = Geom::kUnitK;

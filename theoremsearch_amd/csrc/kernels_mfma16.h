@@ -156,6 +156,24 @@ __device__ __forceinline__ u64 mfma16_block_test(const f32x4& a0, const f32x4& a
     return mask;
 }
 
+// The same test in three parts and the sum in front of it, for the k-split: placed one by one in the gaps behind the MFMAs
+// of a tile's last unit (see TS16_FILL), where the matrix pipe leaves the vector issue free.
+__device__ __forceinline__ void ksplit_add4(f32x4& d, const f32x4& a, const f32x4& b) {
+    ts_f32x2 lo, hi;
+    const ts_f32x2 a0 = {a[0], a[1]}, a1 = {a[2], a[3]}, b0 = {b[0], b[1]}, b1 = {b[2], b[3]};
+    asm volatile("v_pk_add_f32 %0, %2, %4\n\tv_pk_add_f32 %1, %3, %5" : "=&v"(lo), "=v"(hi) : "v"(a0), "v"(a1), "v"(b0), "v"(b1));
+    d = f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+__device__ __forceinline__ void ksplit_test_a(float& m, const f32x4& a0, const f32x4& a1) {
+    asm volatile("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5" : "=&v"(m) : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]));
+}
+__device__ __forceinline__ void ksplit_test_b(float& m, const f32x4& a1) {
+    asm volatile("v_max3_f32 %0, %0, %1, %2\n\tv_max_f32 %0, %0, %3" : "+v"(m) : "v"(a1[1]), "v"(a1[2]), "v"(a1[3]));
+}
+__device__ __forceinline__ void ksplit_test_c(u64& mask, float m, float thr) {
+    asm volatile("v_cmp_ge_f32 %0, %1, %2" : "=s"(mask) : "v"(m), "v"(thr));
+}
+
 // Append the passing scores of one query block (rare path: entered for a block only when some lane passed).  Written
 // for few instructions when ONE lane holds ONE passing score - the usual case: a slow wave holds up the other three
 // at the next barrier, so this path is paid four-fold.  STAGED: into the wave's LDS list (stage / stage_cnt); else into
@@ -252,7 +270,7 @@ __device__ __forceinline__ void pair_read_word(unsigned& dst, unsigned lds_word)
 template <int D, int NB, int VARIANT, bool SPARSE, bool F32 = false, bool PAIR = false, bool KSPLIT = false>
 __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a) {
     static_assert(!PAIR || (!SPARSE && !F32), "pairs exist for the bf16 full pass");
-    static_assert(!KSPLIT || (PAIR && NB == 4 && VARIANT == 0 && D == 1024), "the k-split is the paired pass of d = 1024 with four query blocks per wave");
+    static_assert(!KSPLIT || (PAIR && NB == 4 && (VARIANT == 0 || VARIANT == 1 || VARIANT == 2 || VARIANT == 7) && D == 1024), "the k-split is the paired pass of d = 1024 with four query blocks per wave");
     constexpr int Deq = F32 ? 2 * D : D;                 // row length in 2-byte elements
     using dims = typename std::conditional<KSPLIT, MfmaDims<Deq, MfmaGeomKsplit<Deq>>, Mfma16Dims<Deq>>::type;
     constexpr bool kNoEpi = VARIANT == 1 || VARIANT == 7;
@@ -276,7 +294,10 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     // has just left, right behind the first two MFMAs of s (two k-steps = 16 MFMAs of latency cover at NB = 4).  The ring
     // position is s % kA inside every unit, so kA divides the unit: 3 for units of 12 k-steps, 4 for units of 8.
     constexpr int kA = (kUnitSteps % 3 == 0) ? 3 : 4;
-    constexpr int kQVmax = 36 - 2 * (kA - 2);            // the ring's registers come out of the VGPR share of the queries
+    // (k-split: the exchange holds 32 registers more - the kept blocks and the partner's sums; with the queries' share left at 32
+    // fragments hipcc parks two of them in AGPRs and copies them back right in front of their MFMA inside the asm stream, where
+    // its hazard recognizer sees no MFMA: the k-steps of those two fragments came out wrong on the GPU)
+    constexpr int kQVmax = KSPLIT ? 24 : 36 - 2 * (kA - 2);   // the ring's registers come out of the VGPR share of the queries
     constexpr int kQV = kFrags < kQVmax ? kFrags : kQVmax;   // ... the first kQV of them in VGPRs, the rest in AGPRs
     // cache policy of the corpus stream: non-temporal (read once per search) - except in the paired pass, where the first
     // of a pair's two reads of a tile must leave its lines in the XCD's L2 for the second (with nt on both the fabric
@@ -297,15 +318,18 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     int qid[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b)
-        qid[b] = KSPLIT ? qhalf * 128 + (b * 2 + (wave & 1)) * 16 + r16 : qhalf * 64 * NB + (b * 4 + wave) * 16 + r16;
+        qid[b] = KSPLIT ? qhalf * 128 + (((b + 2 * khalf) & 3) * 2 + (wave & 1)) * 16 + r16 : qhalf * 64 * NB + (b * 4 + wave) * 16 + r16;
 
     mfma_level_begin(a);
     uint4* stage = (uint4*)(smem + dims::kLds) + wave * kMfma16StageCap;          // this wave's staged candidates
     u32* stage_cnt = (u32*)(smem + dims::kLds + 4 * kMfma16StageCap * 16) + wave;
     if (kStaged && lane == 0) *stage_cnt = 0;
-    // k-split: the partial sums a wave hands to its partner, [tile parity][wave][4][lane] x 16 bytes = 2 x 16 KB behind the pair's word
+    // k-split: the partial sums a wave hands to its partner, [wave][4][lane] x 16 bytes = 16 KB behind the pair's word; written
+    // at the end of a tile, fetched by the partner behind the third unit barrier of the next tile (into `got`: an asynchronous
+    // read like the ring's, long landed when the tile ends) - a barrier between every write and its read, and one between
+    // that read's wait and the next write
     uint4* const xbuf = (uint4*)(smem + dims::kLds + kMfma16StageBytes + kMfma16PaceBytes);
-    f32x4 held[2][2];                                    // ... and the two blocks it keeps, until the partner's half has arrived
+    frag16 got[4] = {};
     // pair pacing (see pair_publish_and_fetch): wave 0 only; `pace_word` = LDS address of the partner's position
     const bool pace = PAIR && a.pair_pos != nullptr && a.pair_lag > 0 && wave == 0;
     unsigned* const pace_mine = PAIR ? a.pair_pos + 2 * wg + qhalf : nullptr;
@@ -341,6 +365,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
     const unsigned lds0 = lds_base + wave * 1024;
     const unsigned pace_word = __builtin_amdgcn_readfirstlane(lds_base + dims::kLds + kMfma16StageBytes);
+    const unsigned xfetch = lds_base + dims::kLds + kMfma16StageBytes + kMfma16PaceBytes + (((wave ^ 2) * 256 + lane) << 4);
 
     // operand read offsets inside a unit image: row block rb, k-step s -> (s >> 1) * 4096 + rb * 2048 + xo[s & 1]
     const int lane_off = (r16 >> 3) * 1024 + (r16 & 7) * 128;
@@ -421,6 +446,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     lds_ring_landed(af);
 
     f32x4 acc[2][NB];
+    f32x4 accK[2][2][2] = {};                            // k-split: [tile parity][row block][kept block]
     u32 cnt[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) cnt[b] = 0;
@@ -434,16 +460,18 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         __builtin_amdgcn_s_waitcnt(0xC07F);
     }
 
+    // the accumulator of (row block, query block); k-split: the kept blocks 0, 1 live in the tile parity's half of accK
+#define TS16_ACC(RB_, B_) (*((KSPLIT && (B_) < 2) ? &accK[par_][RB_][(B_) & 1] : &acc[RB_][B_]))
     // one MFMA of block B_, row block RB_, global k-step KS_ (all compile-time); F32: MFMA I_ of the chunk's four
 #define TS16_MMA(RB_, B_, KS_, AF_)                                                                        \
     do {                                                                                                   \
         constexpr int f_ = (B_) * kSteps + (KS_);                                                          \
         if constexpr ((KS_) == 0) {                                                                        \
-            if constexpr (f_ < kQV) mfma16_v_first(acc[RB_][B_], AF_, qv[f_ < kQV ? f_ : 0]);              \
-            else mfma16_a_first(acc[RB_][B_], AF_, qa[f_ >= kQV ? f_ - kQV : 0]);                          \
+            if constexpr (f_ < kQV) mfma16_v_first(TS16_ACC(RB_, B_), AF_, qv[f_ < kQV ? f_ : 0]);         \
+            else mfma16_a_first(TS16_ACC(RB_, B_), AF_, qa[f_ >= kQV ? f_ - kQV : 0]);                     \
         } else {                                                                                           \
-            if constexpr (f_ < kQV) mfma16_v(acc[RB_][B_], AF_, qv[f_ < kQV ? f_ : 0]);                    \
-            else mfma16_a(acc[RB_][B_], AF_, qa[f_ >= kQV ? f_ - kQV : 0]);                                \
+            if constexpr (f_ < kQV) mfma16_v(TS16_ACC(RB_, B_), AF_, qv[f_ < kQV ? f_ : 0]);               \
+            else mfma16_a(TS16_ACC(RB_, B_), AF_, qa[f_ >= kQV ? f_ - kQV : 0]);                           \
         }                                                                                                  \
     } while (0)
 #define TS16_MMAF(RB_, B_, KS_, AF_, I_)                                                                   \
@@ -479,9 +507,42 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
                 if (VARIANT == 5) t_dma += cycle_stamp() - d0_;                                            \
             }                                                                                              \
     } while (0)
+    // k-split: the blocks that go to the partner (2, 3) first - at the end of a tile their sums are four MFMAs old when they are
+    // stored, no wait states to add - and one filler behind each MFMA of the kept blocks: in the tile's last unit the sum and the
+    // test of the PREVIOUS tile's kept blocks (held + the partner's half, long landed), ten pieces of two instructions
+#define TS16_FILL(KS_, G_)                                                                                 \
+    do {                                                                                                   \
+        constexpr int fi_ = ((KS_) - (kSteps - 3)) * 4 + (G_);                                             \
+        if constexpr (KSPLIT && !kNoEpi && (KS_) >= kSteps - 3) {                                          \
+            if constexpr (fi_ == 0) {                                                                      \
+                asm volatile("" : "+v"(got[0]), "+v"(got[1]), "+v"(got[2]), "+v"(got[3]));                 \
+                ksplit_add4(sum_[0][0], accK[par_ ^ 1][0][0], reinterpret_cast<const f32x4&>(got[0]));               \
+            }                                                                                              \
+            if constexpr (fi_ == 1) ksplit_add4(sum_[1][0], accK[par_ ^ 1][1][0], reinterpret_cast<const f32x4&>(got[2])); \
+            if constexpr (fi_ == 2) ksplit_add4(sum_[0][1], accK[par_ ^ 1][0][1], reinterpret_cast<const f32x4&>(got[1])); \
+            if constexpr (fi_ == 3) ksplit_add4(sum_[1][1], accK[par_ ^ 1][1][1], reinterpret_cast<const f32x4&>(got[3])); \
+            if constexpr (fi_ == 4) ksplit_test_a(best_[0], sum_[0][0], sum_[1][0]);                       \
+            if constexpr (fi_ == 5) ksplit_test_b(best_[0], sum_[1][0]);                                   \
+            if constexpr (fi_ == 6) ksplit_test_c(hit_[0], best_[0], thr[0]);                              \
+            if constexpr (fi_ == 7) ksplit_test_a(best_[1], sum_[0][1], sum_[1][1]);                       \
+            if constexpr (fi_ == 8) ksplit_test_b(best_[1], sum_[1][1]);                                   \
+            if constexpr (fi_ == 9) ksplit_test_c(hit_[1], best_[1], thr[1]);                              \
+        }                                                                                                  \
+    } while (0)
 #ifndef TS16_ORDER_A
 #define TS16_BF16_ORDER(KS_, R0_, N_, S_)                                                                  \
     do {                                                                                                   \
+        if constexpr (KSPLIT) {                                                                            \
+            TS16_MMA(0, 2, KS_, af[R0_]); TS16_LOAD(0, N_);                                                \
+            TS16_MMA(1, 2, KS_, af[R0_ + 1]); TS16_LOAD(1, N_);                                            \
+            TS16_MMA(0, 3, KS_, af[R0_]); TS16_MMA(1, 3, KS_, af[R0_ + 1]);                                \
+            TS16_PIECE(S_);                                                                                \
+            TS16_MMA(0, 0, KS_, af[R0_]); TS16_FILL(KS_, 0);                                               \
+            TS16_MMA(1, 0, KS_, af[R0_ + 1]); TS16_FILL(KS_, 1);                                           \
+            TS16_MMA(0, 1, KS_, af[R0_]); TS16_FILL(KS_, 2);                                               \
+            TS16_MMA(1, 1, KS_, af[R0_ + 1]); TS16_FILL(KS_, 3);                                           \
+            break;                                                                                         \
+        }                                                                                                  \
         TS16_MMA(0, 0, KS_, af[R0_]); TS16_LOAD(0, N_);                                                    \
         TS16_MMA(1, 0, KS_, af[R0_ + 1]); TS16_LOAD(1, N_);                                                \
         if constexpr (NB > 1) { TS16_MMA(0, 1, KS_, af[R0_]); TS16_MMA(1, 1, KS_, af[R0_ + 1]); }          \
@@ -538,6 +599,12 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         if constexpr (kNoMma) TS16_PIECE(S_);                                                              \
     } while (0)
 
+    // k-split: the partner's partial sums of the previous tile (its blocks 2, 3 = this wave's blocks 0, 1), four asynchronous reads
+#define TS16_KSPLIT_FETCH()                                                                                \
+    do {                                                                                                   \
+        lds_read16<0>(got[0], xfetch); lds_read16<1024>(got[1], xfetch);                                   \
+        lds_read16<2048>(got[2], xfetch); lds_read16<3072>(got[3], xfetch);                                \
+    } while (0)
     // A unit of the steady part of the tile loop: the unit kSlots - 1 ahead is still to be issued (so every piece goes out,
     // no branch), exactly kSlots - 3 units stay in flight behind the counted wait (an immediate, no ladder), the unit in
     // the tile that is issued is a compile-time constant, and the ring positions are three running byte offsets
@@ -561,6 +628,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         }                                                                                                  \
         __builtin_amdgcn_s_barrier();                                   /* ... and everyone's */            \
         asm volatile("" ::: "memory");                                                                     \
+        if constexpr (KSPLIT && (UI) == 2) TS16_KSPLIT_FETCH();                                            \
         if constexpr (PAIR && (UI) == 0) {                                                                 \
             if (pace) pair_publish_and_fetch(pace_mine, pace_partner, (unsigned)t, pace_word);            \
         }                                                                                                  \
@@ -592,6 +660,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         if (VARIANT == 5) s1_ = cycle_stamp();                                                             \
         __builtin_amdgcn_s_barrier();                                                                      \
         asm volatile("" ::: "memory");                                                                     \
+        if constexpr (KSPLIT && (UI) == 2) TS16_KSPLIT_FETCH();                                            \
         if (VARIANT == 5) { t_vm += s1_ - s0_; t_bar += cycle_stamp() - s1_; }                             \
         if (VARIANT == 6) __builtin_amdgcn_s_sleep(4);   /* ~256 idle cycles per unit: elasticity of time to cycles */ \
         const bool do_issue = issue_u < nu && !kNoDma;                                                     \
@@ -608,30 +677,17 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         ++u;                                                                                               \
     } while (0)
 
-    // k-split: the test of tile TP (one tile late): the partner's partial sums of the two blocks this wave kept + its own
-#define TS16_KSPLIT_FINISH(TP)                                                                             \
+    // k-split: the candidates of tile TP (one tile late), from the sums and masks the fillers of the next tile's last unit left
+#define TS16_KSPLIT_APPEND(TP)                                                                             \
     do {                                                                                                   \
-        const int tp_ = (TP);                                                                              \
-        const uint4* theirs = xbuf + ((tp_ & 1) * 4 + (wave ^ 2)) * 256 + lane;                            \
-        f32x4 sum_[2][2];                                                                                  \
-        _Pragma("unroll") for (int rb_ = 0; rb_ < 2; ++rb_)                                                \
-            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                             \
-                const uint4 v_ = theirs[(rb_ * 2 + i_) * 64];                                              \
-                sum_[rb_][i_] = held[rb_][i_] + *reinterpret_cast<const f32x4*>(&v_);                      \
-            }                                                                                              \
-        const int kb_ = 2 * khalf;                                                                         \
-        float best_[2];                                                                                    \
-        u64 hit_[2];                                                                                       \
-        hit_[0] = mfma16_block_test(sum_[0][0], sum_[1][0], khalf ? thr[2] : thr[0], best_[0]);            \
-        hit_[1] = mfma16_block_test(sum_[0][1], sum_[1][1], khalf ? thr[3] : thr[1], best_[1]);            \
         if (__builtin_expect((hit_[0] | hit_[1]) != 0, 0)) {                                               \
-            const int64_t lt_ = t0 + tp_;                                                                  \
+            const int64_t lt_ = t0 + (TP);                                                                 \
             const int64_t tile_row_ = (a.run == 1 ? lt_ * a.tile_stride : (lt_ / a.run) * a.run * a.tile_stride + lt_ % a.run) * kTileRows; \
             const int64_t row_base_ = tile_row_ + 4 * kq;                                                  \
             _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                               \
                 if (hit_[i_] != 0)                                                                         \
-                    mfma16_append_block<kStaged>(sum_[0][i_], sum_[1][i_], khalf ? thr[2 + i_] : thr[i_], best_[i_],     \
-                                                 khalf ? qid[2 + i_] : qid[i_], writer, nwriters, cnt[(kb_ + i_) & (NB - 1)], row_base_, a, stage, stage_cnt); \
+                    mfma16_append_block<kStaged>(sum_[0][i_], sum_[1][i_], thr[i_], best_[i_], qid[i_], writer, nwriters, cnt[i_], \
+                                                 row_base_, a, stage, stage_cnt);                          \
         }                                                                                                  \
     } while (0)
     static_assert(kUnitSteps == 8 || kUnitSteps == 12 || (KSPLIT && kUnitSteps == 4), "unit = 8 or 12 k-steps of 32 (k-split: this wave's 4 of 8)");
@@ -645,7 +701,14 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
     // prologue has issued `ahead` units: the next one lies in visited tile t0 + ahead / kUnits
     const unsigned dma_voff = (unsigned)(drow * (Deq * 2) + dchunk * 16);
     const unsigned char* s_tile = (const unsigned char*)a.corpus + (t0 + ahead / kUnits) * steady_jump;
-    for (int t = 0; t < nt; ++t) {
+    f32x4 sum_[2][2] = {};                                // k-split: what the fillers of a tile's last unit leave for its end
+    float best_[2] = {};
+    u64 hit_[2] = {};
+    // One tile.  (k-split: PAR = the tile's parity - the kept blocks of a tile stay where they are, in accK[PAR], while the next
+    // tile's sums grow in accK[PAR ^ 1], instead of being copied: the loop below runs two tiles per trip.)
+    auto tile = [&](auto par_c, const int t) __attribute__((always_inline)) {
+        constexpr int par_ = decltype(par_c)::value;
+        (void)par_;
         if (t < nt_steady) {
             TS16_UNIT_S(0);
             if constexpr (kUnits >= 2) TS16_UNIT_S(1 % kUnits);
@@ -685,21 +748,20 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
             }
             if constexpr (!kNoMma) lds_ring_landed(af);
         }
-        if constexpr (kNoMma) continue;
+        if constexpr (kNoMma) return;
         if constexpr (KSPLIT) {
-            mfma16_settle<NB>(acc);
-            if (t > 0) TS16_KSPLIT_FINISH(t - 1);        // the previous tile: the partner's half was written four barriers ago
-            uint4* mine = xbuf + ((t & 1) * 4 + wave) * 256 + lane;
-            if (khalf == 0) {                             // keep blocks 0, 1; blocks 2, 3 go to the partner
-                held[0][0] = acc[0][0]; held[0][1] = acc[0][1]; held[1][0] = acc[1][0]; held[1][1] = acc[1][1];
-                mine[0] = *reinterpret_cast<const uint4*>(&acc[0][2]); mine[64] = *reinterpret_cast<const uint4*>(&acc[0][3]);
-                mine[128] = *reinterpret_cast<const uint4*>(&acc[1][2]); mine[192] = *reinterpret_cast<const uint4*>(&acc[1][3]);
-            } else {
-                held[0][0] = acc[0][2]; held[0][1] = acc[0][3]; held[1][0] = acc[1][2]; held[1][1] = acc[1][3];
-                mine[0] = *reinterpret_cast<const uint4*>(&acc[0][0]); mine[64] = *reinterpret_cast<const uint4*>(&acc[0][1]);
-                mine[128] = *reinterpret_cast<const uint4*>(&acc[1][0]); mine[192] = *reinterpret_cast<const uint4*>(&acc[1][1]);
+            if constexpr (kNoEpi) {
+                asm volatile("s_nop 15\n\ts_nop 3" : "+v"(accK[par_][0][0]), "+v"(accK[par_][0][1]), "+v"(accK[par_][1][0]), "+v"(accK[par_][1][1]),
+                             "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][2]), "+v"(acc[1][3]));
+                return;
             }
-            continue;
+            if (t > 0) TS16_KSPLIT_APPEND(t - 1);        // the previous tile, summed and tested by this tile's fillers
+            // blocks 2, 3 go to the partner (their last MFMAs are four MFMAs back: TS16_BF16_ORDER); blocks 0, 1 are kept
+            asm volatile("" : "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][2]), "+v"(acc[1][3]));
+            uint4* mine = xbuf + wave * 256 + lane;
+            mine[0] = *reinterpret_cast<const uint4*>(&acc[0][2]); mine[64] = *reinterpret_cast<const uint4*>(&acc[0][3]);
+            mine[128] = *reinterpret_cast<const uint4*>(&acc[1][2]); mine[192] = *reinterpret_cast<const uint4*>(&acc[1][3]);
+            return;
         }
         // The last k-step issued its MFMAs in block order, so with NB = 4 the results of block b are at least 6 MFMAs
         // old when its test (5 VALU instructions per block, in order) reads them; fewer blocks need explicit wait states.
@@ -711,7 +773,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         if constexpr (kNoEpi) {
 #pragma unroll
             for (int b = 0; b < NB; ++b) asm volatile("" ::"v"(acc[0][b]), "v"(acc[1][b]));
-            continue;
+            return;
         }
         // lane holds rows 4 kq + {0..3} of both row blocks for query qid[b]
         float best[NB];
@@ -723,7 +785,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
         }
         if (VARIANT == 4) {                      // diagnostic: the test without the append path
             asm volatile("" ::"s"(any_hit));
-            continue;
+            return;
         }
         if (__builtin_expect(any_hit != 0, 0)) {
             const int64_t lt = t0 + t;
@@ -736,22 +798,49 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
                     mfma16_append_block<kStaged>(acc[0][b], acc[1][b], thr[b], best[b], qid[b], writer, nwriters, cnt[b], row_base, a,
                                                  stage, stage_cnt);
         }
-    }
+        };
     if constexpr (KSPLIT) {
+        for (int t = 0; t < nt; t += 2) {
+            tile(std::integral_constant<int, 0>{}, t);
+            if (t + 1 < nt) tile(std::integral_constant<int, 1>{}, t + 1);
+        }
+    } else {
+        for (int t = 0; t < nt; ++t) tile(std::integral_constant<int, 0>{}, t);
+    }
+    if constexpr (KSPLIT && !kNoEpi && !kNoMma) {
         // the last tile's halves: one more barrier (every wave has written), then the same test
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        TS16_KSPLIT_FINISH(nt - 1);
+        TS16_KSPLIT_FETCH();
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(got[0]), "+v"(got[1]), "+v"(got[2]), "+v"(got[3]));
+        // the last tile's kept blocks (its parity's half; the tile's last MFMAs wrote them: wait states first)
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(accK[0][0][0]), "+v"(accK[0][0][1]), "+v"(accK[0][1][0]), "+v"(accK[0][1][1]),
+                     "+v"(accK[1][0][0]), "+v"(accK[1][0][1]), "+v"(accK[1][1][0]), "+v"(accK[1][1][1]));
+        f32x4 held[2][2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) held[rb][i] = ((nt - 1) & 1) ? accK[1][rb][i] : accK[0][rb][i];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) sum_[rb][i] = held[rb][i] + reinterpret_cast<const f32x4&>(got[rb * 2 + i]);
+        hit_[0] = mfma16_block_test(sum_[0][0], sum_[1][0], thr[0], best_[0]);
+        hit_[1] = mfma16_block_test(sum_[0][1], sum_[1][1], thr[1], best_[1]);
+        TS16_KSPLIT_APPEND(nt - 1);
     }
-#undef TS16_KSPLIT_FINISH
+#undef TS16_KSPLIT_APPEND
+#undef TS16_KSPLIT_FETCH
 #undef TS16_UNIT
 #undef TS16_UNIT_S
 #undef TS16_STEP
 #undef TS16_MMA
+#undef TS16_ACC
 #undef TS16_MMAF
 #undef TS16_LOAD
 #undef TS16_BF16_ORDER
+#undef TS16_FILL
 #undef TS16_PIECE
 #undef TS16_ISSUED
     if (kStaged) {

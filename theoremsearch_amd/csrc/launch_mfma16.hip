@@ -56,7 +56,7 @@ static int launch_mfma16(bool full_pass, int variant, int grid, hipStream_t st, 
 
 
 // The paired full pass of d = 1024 (MfmaArgs::pair): 128 queries per workgroup, two workgroups per tile range.
-static int launch_mfma16_pair(int grid, hipStream_t st, const MfmaArgs& a) {
+static int launch_mfma16_pair(int variant, int grid, hipStream_t st, const MfmaArgs& a) {
     constexpr int lds = Mfma16Dims<1024>::kLds + kMfma16StageBytes + kMfma16PaceBytes;
     static_assert(lds <= 160 * 1024, "DMA ring + staged candidates + the pair's word must fit the CU's LDS");
     static std::atomic<unsigned long long> attr_done{0};
@@ -69,18 +69,42 @@ static int launch_mfma16_pair(int grid, hipStream_t st, const MfmaArgs& a) {
     }
     if (grid % 16 != 0) return fail(TS_ERR_INTERNAL, "the paired pass needs a grid of whole groups of 16 workgroups, not %d", grid);
     if (a.pair == 2) {
-        // the k-split form: 2 x 2 waves (query column x k half), six ring slots, two 16 KB exchange buffers for the partial sums
-        constexpr int lds_k = MfmaDims<1024, MfmaGeomKsplit<1024>>::kLds + kMfma16StageBytes + kMfma16PaceBytes + 2 * 16384;
+        // the k-split form: 2 x 2 waves (query column x k half), eight ring slots, one 16 KB exchange buffer for the partial sums
+        constexpr int lds_k = MfmaDims<1024, MfmaGeomKsplit<1024>>::kLds + kMfma16StageBytes + kMfma16PaceBytes + 16384;
         static_assert(lds_k <= 160 * 1024, "ring + staged candidates + the pair's word + the exchange buffers must fit the CU's LDS");
         static std::atomic<unsigned long long> attr_k{0};
         if (!(attr_k.load(std::memory_order_acquire) & bit)) {
             HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<1024, 4, 0, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_k));
             attr_k.fetch_or(bit, std::memory_order_release);
         }
+#ifdef TS_DIAG
+        if (variant == 1 || variant == 2 || variant == 7) {
+            HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<1024, 4, 1, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_k));
+            HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<1024, 4, 2, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_k));
+            HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<1024, 4, 7, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_k));
+            if (variant == 1) mfma16_topk_kernel<1024, 4, 1, false, false, true, true><<<grid, kMfmaThreads, lds_k, st>>>(a);
+            else if (variant == 2) mfma16_topk_kernel<1024, 4, 2, false, false, true, true><<<grid, kMfmaThreads, lds_k, st>>>(a);
+            else mfma16_topk_kernel<1024, 4, 7, false, false, true, true><<<grid, kMfmaThreads, lds_k, st>>>(a);
+            HIP_TRY(hipGetLastError());
+            return TS_OK;
+        }
+#endif
         mfma16_topk_kernel<1024, 4, 0, false, false, true, true><<<grid, kMfmaThreads, lds_k, st>>>(a);
         HIP_TRY(hipGetLastError());
         return TS_OK;
     }
+#ifdef TS_DIAG
+    if (variant == 1 || variant == 2 || variant == 7) {
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<1024, 2, 1, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<1024, 2, 2, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mfma16_topk_kernel<1024, 2, 7, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        if (variant == 1) mfma16_topk_kernel<1024, 2, 1, false, false, true><<<grid, kMfmaThreads, lds, st>>>(a);
+        else if (variant == 2) mfma16_topk_kernel<1024, 2, 2, false, false, true><<<grid, kMfmaThreads, lds, st>>>(a);
+        else mfma16_topk_kernel<1024, 2, 7, false, false, true><<<grid, kMfmaThreads, lds, st>>>(a);
+        HIP_TRY(hipGetLastError());
+        return TS_OK;
+    }
+#endif
     mfma16_topk_kernel<1024, 2, 0, false, false, true><<<grid, kMfmaThreads, lds, st>>>(a);
     HIP_TRY(hipGetLastError());
     return TS_OK;
@@ -90,7 +114,7 @@ static int launch_mfma16_pair(int grid, hipStream_t st, const MfmaArgs& a) {
 int launch_pass_mfma16(int d, int nb, bool full_pass, int variant, int grid, hipStream_t st, const MfmaArgs& a) {
     if (a.pair) {
         if (d != 1024 || nb != 2 || !full_pass) return fail(TS_ERR_INTERNAL, "paired pass asked for d = %d, %d blocks per wave", d, nb);   // (a.pair == 2: the k-split form, same queries per workgroup)
-        return launch_mfma16_pair(grid, st, a);
+        return launch_mfma16_pair(variant, grid, st, a);
     }
 #define TS_NB_SWITCH(D_)                                                          \
     switch (nb) {                                                                 \

@@ -290,7 +290,7 @@ int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* out_idx
         a.fb_count = ix->fb_count;
         a.part = (balance && full_pass) ? ix->part : nullptr;
         a.wg_ticks = (balance && full_pass) ? ix->wg_ticks : nullptr;
-        a.pair = (pair && full_pass) ? (ix->knobs.get(K_MFMA_PAIR, 1) == 2 ? 2 : 1) : 0;      // TS_MFMA_PAIR=2: the k-split form
+        a.pair = (pair && full_pass) ? (ix->knobs.get(K_MFMA_PAIR, 2) == 1 ? 1 : 2) : 0;      // 2: the k-split form (TS_MFMA_PAIR=1: two blocks per wave over the whole row)
         a.pair_pos = nullptr;
         a.pair_lag = 0;
         if (a.pair && ix->knobs.get(K_MFMA_PAIR_LAG, 1) > 0) {

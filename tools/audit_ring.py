@@ -9,6 +9,11 @@ order (LDS returns in order; `lgkmcnt(N)` retires all but the youngest N), and r
 vector register an outstanding ds_read_b128 is still to write.  The walk is linear in the text and runs twice, so that
 what a loop leaves in flight at its end is seen by its head.
 
+Second check, same walk: the MFMAs are text inside `asm volatile` too, so hipcc's hazard recognizer does not see them: a
+vector instruction of the compiler's (a copy, a v_accvgpr_read that brings a parked query fragment back) that writes an MFMA
+operand within two instructions in front of that MFMA gets no wait states - on the GPU those k-steps came out wrong
+(round 5, the first k-split build).  Reported as "operand written right in front of its MFMA".
+
     python tools/audit_ring.py theoremsearch_amd/csrc/build/asm/launch_mfma16-hip-amdgcn-amd-amdhsa-gfx950.s
 """
 import re
@@ -30,6 +35,7 @@ def regs(op):
 def audit(name, lines):
     fifo = []          # outstanding lgkm operations: set of destination registers (empty for the others)
     bad = []
+    recent = []        # destination registers of the last two instructions, if they were the compiler's vector instructions
     for rnd in range(2):
         for no, ln in lines:
             t = ln.split(";")[0].strip()
@@ -37,6 +43,11 @@ def audit(name, lines):
                 continue
             op, _, rest = t.partition(" ")
             ops = [o.strip() for o in rest.split(",")] if rest else []
+            if op.startswith("v_mfma") and rnd == 1:
+                if set().union(*[regs(o) for o in ops[1:]]) & (set().union(*recent) if recent else set()):
+                    bad.append((no, "operand written right in front of its MFMA: " + t))
+            valu = op.startswith("v_") and not op.startswith(("v_mfma", "v_cmp", "v_cmpx", "v_readfirstlane", "v_readlane"))
+            recent = (recent + [regs(ops[0]) if valu and ops else set()])[-2:]
             if op == "s_waitcnt":
                 m = re.search(r"lgkmcnt\((\d+)\)", t)
                 if m:
