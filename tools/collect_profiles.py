@@ -39,7 +39,7 @@ def main(src, tag):
         traffic = json.load(open(tpath))
     notes = []
     kernels = (("c3", "mfma16_topk_kernel<768, 4, 0, false"), ("c2", "scan_kernel"), ("c2b", "mfma16_topk_kernel<768, 2, 0, false, true"),
-               ("c3q", "mfma16_topk_kernel<1024, 2, 0, false, false, true"))
+               ("c3q", "mfma16_topk_kernel<1024, 4, 0, false, false, true, true"))   # the k-split form (round 4 / first half of round 5: <1024, 2, 0, false, false, true>)
     for w, kern in kernels:
         # tools/run_profiles_r04.sh leaves <w>_kernel_stats.csv beside the trace directories; round 3's script only the directories
         stats = newest(glob.glob(os.path.join(src, f"{w}_kernel_stats.csv")) or
