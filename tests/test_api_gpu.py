@@ -236,6 +236,24 @@ def test_comm_of_one_rank_runs_the_rccl_exchange(ts):
         lib.ts_comm_destroy(comm)
 
 
+def test_shards_of_the_production_table_shape_answer_like_the_whole_index(ts):
+    """vector(1024) bf16 rows (rds_schema.sql:50-56) and a full launch of 256 queries: every shard runs the k-split paired pass
+    over its own tile ranges; a score is the same two half sums wherever its row lives, so ids AND score bits are those of one
+    index over all the rows."""
+    from theoremsearch_amd.distributed import Shards
+    n, k = 200_003, 10
+    q, c = oracle.inputs(n, 256, 1024, 15, "ip")
+    c[150_000] = c[7]                                       # an exact tie across shards
+    with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as whole:
+        want_s, want_i, st = whole.search(q, k, algo="mfma", return_stats=True)
+        assert st["algo"] == 2 and st["fallback_queries"] == 0
+    for shards in (2, 5):
+        with Shards(n, 1024, shards, dtype="bf16", metric="ip", devices=[0] * shards) as sh:
+            sh.upload(c, 0)
+            scores, idx = sh.search(q, k)
+            assert np.array_equal(idx, want_i) and np.array_equal(scores, want_s), shards
+
+
 @pytest.mark.parametrize("pipeline", [1, 2])
 def test_sharded_searcher_device_pipeline_with_changing_queries(ts, pipeline):
     """ShardedSearcher.search_device - the loop bench.py times - with DIFFERENT queries every step (identical queries
