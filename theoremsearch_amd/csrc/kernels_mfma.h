@@ -63,8 +63,8 @@ template <> struct MfmaGeom<1536> { static constexpr int kUnitK = 384, kSlots = 
 // (12 k-steps, 24 KiB, six slots - the image of a half tile of d = 768); the other widths share the geometry above
 template <int D> struct MfmaGeom16 : MfmaGeom<D> {};
 template <> struct MfmaGeom16<384> { static constexpr int kUnitK = 384, kSlots = 6; };
-// the k-split form of the paired d = 1024 pass (kernels_mfma16.h): six slots - the ring gives 32 KB of LDS to the partial sums
-// the wave pairs exchange
+// the k-split form of the paired d = 1024 pass (kernels_mfma16.h): the same ring as the other forms of that width; 16 KB of LDS
+// behind it carry the partial sums the wave pairs exchange (160,016 bytes of the CU's 163,840 in all)
 template <int D> struct MfmaGeomKsplit { static constexpr int kUnitK = 256, kSlots = 8; };
 template <int D, class Geom = MfmaGeom<D>> struct MfmaDims {
     static constexpr int kKSteps = D / 16;

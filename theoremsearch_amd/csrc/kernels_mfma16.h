@@ -260,13 +260,20 @@ __device__ __forceinline__ void pair_read_word(unsigned& dst, unsigned lds_word)
 // 32x32x2 kernel of kernels_mfma_f32.h stays selectable: TS_MFMA_F32=32).
 // PAIR: the paired full pass (MfmaArgs::pair; a template parameter, not a run-time branch: the headline instantiation has no
 // register to spare for the pair's bookkeeping).
-// KSPLIT (the paired pass of d = 1024): the four waves of a workgroup are a 2 x 2 grid - wave w holds the queries of column
-// w & 1 (64 of the workgroup's 128: NB = 4 blocks) for the k-steps of HALF w >> 1 of every unit (4 of its 8 k-steps).  Each
-// corpus fragment a wave reads from LDS then feeds four MFMAs, as at d = 768, instead of two - at NB = 2 the pass spends 8 x the
-// corpus in LDS reads and runs 15 % behind d = 768 per flop - and the two partial sums of a (row, query) meet through LDS once per
-// tile: a wave keeps two of its four query blocks and hands the other two to its partner (wave ^ 2), 4 KB each way; the
-// partner's half of tile t is picked up at the end of tile t + 1 (four unit barriers later: no barrier of its own), so the
-// threshold test of a tile runs one tile late.
+// KSPLIT (the paired pass of d = 1024; profiles/r05k_c3q_ksplit.txt): the four waves of a workgroup are a 2 x 2 grid - wave w
+// holds the queries of column w & 1 (64 of the workgroup's 128: NB = 4 blocks) for the k-steps of HALF w >> 1 of every unit (4
+// of its 8 k-steps).  Each corpus fragment a wave reads from LDS then feeds four MFMAs, as at d = 768, instead of two - at NB = 2
+// the pass spends 2,048 cycles of LDS reads per tile beside 2,048 cycles of MFMAs.  The two partial sums of a (row, query) meet
+// through LDS once per tile: a wave KEEPS its blocks 0, 1 (in accK[tile parity]: the loop runs two tiles per trip, nothing is
+// copied) and hands its blocks 2, 3 to wave ^ 2, whose kept blocks they are (local block b of half h = block (b + 2 h) & 3 of
+// the column): four ds_write_b128 at the end of a tile - those blocks are multiplied FIRST in every k-step, so they are four
+// MFMAs old by then - and four asynchronous ds_read_b128 behind the third unit barrier of the NEXT tile (TS16_KSPLIT_FETCH:
+// one 16 KB buffer; a barrier between every write and its read, and one between a read's landing and the next write).  Sum and
+// threshold test of tile t - 1 are ten two-instruction fillers behind the MFMAs of the kept blocks in the last three k-steps of
+// tile t (TS16_FILL), where the matrix pipe leaves the vector issue free; what is left at the end of a tile is the branch on the
+// two masks.  So a tile's candidates are appended one tile late, the last tile's after the loop (one more barrier).
+// Registers: 24 query fragments in VGPRs, 40 in AGPRs.  (With 32 in VGPRs hipcc parked two in AGPRs and copied them back one
+// instruction ahead of their MFMA - asm text, no hazard padding: wrong k-steps.  tools/audit_ring.py reports that pattern.)
 template <int D, int NB, int VARIANT, bool SPARSE, bool F32 = false, bool PAIR = false, bool KSPLIT = false>
 __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a) {
     static_assert(!PAIR || (!SPARSE && !F32), "pairs exist for the bf16 full pass");
