@@ -31,6 +31,8 @@
 //
 // Algorithmic traffic: rows * 2 d bytes per launch; flops 2 * queries * rows * d.
 #pragma once
+#include <type_traits>
+
 #include "kernels_mfma.h"
 
 namespace ts {
@@ -805,7 +807,7 @@ __global__ void __launch_bounds__(kMfmaThreads, 1) mfma16_topk_kernel(MfmaArgs a
                     mfma16_append_block<kStaged>(acc[0][b], acc[1][b], thr[b], best[b], qid[b], writer, nwriters, cnt[b], row_base, a,
                                                  stage, stage_cnt);
         }
-        };
+    };
     if constexpr (KSPLIT) {
         for (int t = 0; t < nt; t += 2) {
             tile(std::integral_constant<int, 0>{}, t);
