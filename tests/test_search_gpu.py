@@ -269,6 +269,10 @@ def test_k_split_pairs_on_short_and_odd_tile_ranges(ts, n, grid):
         check(q, c, "ip", "bf16", 10, s1, i1)
         assert np.abs(sk - s1).max() < 3e-7 and np.mean(ik == i1) > 0.995
         ix.set_option("TS_MFMA_PAIR", None)
+        ix.set_option("TS_MFMA_PAIR_LAG", 0)                   # the pairs unpaced: the same sums, bit for bit
+        s0, i0 = ix.search(q, 10, algo="mfma")
+        assert np.array_equal(i0, ik) and np.array_equal(s0, sk)
+        ix.set_option("TS_MFMA_PAIR_LAG", None)
         for k in (1, 100):
             s, i = ix.search(q[:200], k, algo="mfma")
             check(q[:200], c, "ip", "bf16", k, s, i)
