@@ -2,7 +2,7 @@
 oracle's fp64 truth, for a fixed time budget.  Prints a line per case (so a stall is visible) and arms
 faulthandler so that a hung call dumps the Python stack and exits.
 
-    python tests/stress_parity.py --seconds 240 --seed 1
+    python tests/stress_parity.py --seconds 240 --seed 1 [--big | --pairs]
 """
 import argparse
 import faulthandler
@@ -18,7 +18,7 @@ import theoremsearch_amd as ts  # noqa: E402
 from oracle import oracle  # noqa: E402  (checker)
 
 
-def one_case(rng, big: bool, case: int = 0, watchdog: bool = True) -> str:
+def one_case(rng, big: bool, case: int = 0, watchdog: bool = True, pairs: bool = False) -> str:
     """One random combination, checked; returns its description.  Used by the time-boxed sweep below and, with a
     fixed seed list, by tests/test_fullsize_gpu.py (collected by pytest)."""
     d = int(rng.choice([768, 768, 768, 1024, 1024, 384, 384, 512, 512, 40]))
@@ -34,13 +34,24 @@ def one_case(rng, big: bool, case: int = 0, watchdog: bool = True) -> str:
         n = int(rng.choice([1_000_000, 1_700_001, 2_500_000]))
         nq = int(rng.choice([5, 16, 33, 130]))
         k = int(rng.choice([1, 10, 10, 50, 256]))
+    if pairs:
+        # the paired pass of the production table's shape (bf16 x 1024, 193+ queries in a launch): tile ranges of every
+        # parity and length over the pairs of the default grid and of smaller ones, ragged last tiles, ties, masks
+        d, dtype = 1024, "bf16"
+        n = int(rng.choice([16384, 16385, 20_000 + int(rng.integers(0, 4096)), 65_536 + int(rng.integers(0, 64)),
+                            int(rng.integers(100_000, 420_000))]))
+        nq = int(rng.choice([193, 200, 255, 256, 256, 256, 257, 300, 449, 512]))
+        k = int(rng.choice([1, 5, 10, 10, 64, 65, 200]))
     mfma_ok = d in (384, 512, 768, 1024)               # bf16, and fp32 on the exact-fp32 matrix instructions
     algo = str(rng.choice(["auto", "scan", "mfma"])) if mfma_ok else str(rng.choice(["auto", "scan"]))
     if big:
         algo = "auto" if rng.random() < 0.4 else "mfma"     # "auto" may carry a dense host mask (masked MFMA pass)
+    if pairs:
+        algo = str(rng.choice(["auto", "mfma"]))
     if algo == "scan" and nq > 64:
         nq = int(rng.choice([1, 4, 7, 33]))          # the scan serves 4 queries per pass: keep the sweep moving
     use_mask = algo != "mfma" and rng.random() < (0.7 if big else 0.25) and (nq <= 8 or (mfma_ok and n >= 16384))
+    grid = int(rng.choice([0, 0, 16, 64, 208, 240])) if pairs else 0      # 0: the device's CU count
     seed = int(rng.integers(0, 2**31))
     if watchdog:
         faulthandler.dump_traceback_later(300 if big else 120, exit=True)
@@ -62,6 +73,8 @@ def one_case(rng, big: bool, case: int = 0, watchdog: bool = True) -> str:
         mode = "device"
     bias, w = None, 0.0
     with ts.TheoremIndex.from_embeddings(c, dtype=dtype, metric=metric) as ix:
+        if grid:
+            ix.set_option("TS_MFMA_GRID", grid)
         if mode == "biased":
             bias = np.log(rng.integers(1, 5000, n).astype(np.float64)).astype(np.float32) * (rng.random(n) < 0.8)
             w = float(rng.choice([0.0, 0.001, 0.02]))
@@ -95,8 +108,8 @@ def one_case(rng, big: bool, case: int = 0, watchdog: bool = True) -> str:
     assert stats["recall"] == 1.0, stats
     if watchdog:
         faulthandler.cancel_dump_traceback_later()
-    return (f"case {case}: n={n} d={d} {dtype} {metric} nq={nq} k={k} algo={algo} mask={use_mask} {mode} ok "
-            f"({time.time() - t0:.1f}s)")
+    return (f"case {case}: n={n} d={d} {dtype} {metric} nq={nq} k={k} algo={algo} mask={use_mask} {mode}"
+            f"{f' grid={grid}' if grid else ''} ok ({time.time() - t0:.1f}s)")
 
 
 def main():
@@ -104,13 +117,14 @@ def main():
     ap.add_argument("--seconds", type=float, default=240)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--big", action="store_true", help="bf16 x 768 corpora of 1M-2.5M rows through the MFMA path (threshold estimates at scale)")
+    ap.add_argument("--pairs", action="store_true", help="bf16 x 1024 with 193+ queries: the paired (k-split) pass, over several grids")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     t_end = time.time() + args.seconds
     case = 0
     while time.time() < t_end:
         case += 1
-        print(one_case(rng, args.big, case), flush=True)
+        print(one_case(rng, args.big, case, pairs=args.pairs), flush=True)
     print(f"stress: {case} cases passed", flush=True)
 
 
