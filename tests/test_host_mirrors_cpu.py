@@ -40,6 +40,47 @@ def test_metrics_match_reference_outputs(name):
         assert gen == load_qrels(doc, "generated_qrels")
 
 
+@pytest.mark.parametrize("style", ["sparse_graded", "dense_generated", "identity", "some_unjudged"])
+def test_metrics_over_all_queries_at_once_equal_the_oracles_loops(style, capsys):
+    """The six metrics are evaluated for every query at once (running products and sums in rank order); the oracle's
+    restatement - pinned by the reference's own function bodies (tests/golden/metrics_*.json) - walks one query and one rank
+    at a time, as compare_embeddings.py:95-371 does.  Seeded random matrices and judgements: the same floats, bit for bit."""
+    from oracle import oracle
+    for seed in range(40):
+        rng = np.random.default_rng([seed, len(style)])
+        nq, n = int(rng.integers(1, 40)), int(rng.integers(3, 400))
+        sim = rng.standard_normal((nq, n)).astype(np.float32)
+        qrels = {}
+        for q in range(nq):
+            gold = int(rng.integers(n))
+            if style == "sparse_graded":
+                d = {gold: 1.0}
+                for j in rng.choice(n, size=min(n, int(rng.integers(0, 6))), replace=False):
+                    d.setdefault(int(j), float(rng.choice([0.5, 0.25, 2.0, 3.0, 0])))
+            elif style == "dense_generated":          # what _generate_qrels makes (every doc a key), plus the exact doc
+                d = {j: (0.5 if rng.random() < 0.05 else 0) for j in range(n)}
+                d[gold] = 1
+            elif style == "identity":
+                d = {gold: 1}
+            else:
+                d = {gold: 1.0}
+                d.setdefault(int(rng.integers(n)), 0.5)
+            qrels[q] = d
+        graded = {q: (v if q % 3 else {}) for q, v in qrels.items()} if style == "some_unjudged" else qrels
+        shared = ce._SharedRanking(sim)
+        ce._top(shared, min(n, 37))                    # one selection: the smaller k below read its head
+        for k in (1, 3, 10, min(n, 37)):
+            for mine, theirs, rels, kw in (
+                    (ce.precision_at_k, oracle.precision_at_k, qrels, dict(k=k)), (ce.hit_at_k, oracle.hit_at_k, qrels, dict(k=k)),
+                    (ce.mrr_at_k, oracle.mrr_at_k, qrels, dict(k=k)), (ce.mrr_at_k, oracle.mrr_at_k, qrels, dict(k=None)),
+                    (ce.ndcg_at_k, oracle.ndcg_at_k, graded, dict(k=k)), (ce.ndcg_at_k, oracle.ndcg_at_k, graded, dict(k=k, gain="linear")),
+                    (ce.err_at_k, oracle.err_at_k, graded, dict(k=k)), (ce.err_at_k, oracle.err_at_k, graded, dict(k=k, max_rel=1.0)),
+                    (ce.q_measure_at_k, oracle.q_measure_at_k, graded, dict(k=k)),
+                    (ce.q_measure_at_k, oracle.q_measure_at_k, graded, dict(k=k, max_rel=4.0))):
+                assert mine(shared, rels, **kw) == theirs(sim, rels, **kw), (seed, mine.__name__, kw)
+    capsys.readouterr()                                # "TOO SMALL" lines of the unjudged queries (the reference prints them too)
+
+
 def test_metric_signatures_and_defaults():
     import inspect
     want = {"precision_at_k": ["sim_matrix", "qrels", "k"], "hit_at_k": ["sim_matrix", "qrels", "k"],

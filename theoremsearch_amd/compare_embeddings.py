@@ -92,8 +92,15 @@ def _top(sim_matrix, k):
             raise ValueError("a full ranking is not materialised for an IndexRanking")
         return sim_matrix.top(k)
     shared = sim_matrix._tops if isinstance(sim_matrix, _SharedRanking) else None
-    if shared is not None and k in shared:
-        return shared[k]
+    if shared is not None:
+        if k in shared:
+            return shared[k]
+        if k is not None:
+            # the partial selection's order is canonical (score descending, then index ascending): the k best are the
+            # head of any longer list it made
+            wider = [kk for kk in shared if kk is not None and kk > k]
+            if wider:
+                return shared[wider[0]][:, :k]
     s = np.asarray(sim_matrix)
     if k is None or k >= s.shape[1]:
         idx = np.argsort(-s, axis=1)
@@ -121,6 +128,7 @@ def evaluate_retrieval(model, theorems, queries, qrels, top_k_report=3):
     print("Cos-sim matrix dim", sim_matrix.shape)
     print("Ranking concepts...")
     print("=" * 50)
+    _top(sim_matrix, max(1, top_k_report))          # P@1 reads the head of the same selection
     print("Binary metrics")
     bin_metrics = {"P@1": precision_at_k, f"H@{top_k_report}": hit_at_k, f"MRR@{top_k_report}": mrr_at_k}
     for item, fn in bin_metrics.items():
@@ -152,14 +160,20 @@ def evaluate_retrieval_index(model, index, queries, qrels, top_k_report=3):
     return out
 
 
+def _exact_docs(qrels, nq):
+    return np.array([_exact_doc(qrels[q]) for q in range(nq)])
+
+
 def precision_at_k(sim_matrix, qrels, k=5):
     top = _top(sim_matrix, k)
-    return float(np.mean([(1 if _exact_doc(qrels[q]) in top[q] else 0) / k for q in range(top.shape[0])]))
+    hit = (top == _exact_docs(qrels, top.shape[0])[:, None]).any(axis=1)
+    return float(np.mean(hit / k))
 
 
 def hit_at_k(sim_matrix, qrels, k=5):
     top = _top(sim_matrix, k)
-    return float(np.mean([1.0 if _exact_doc(qrels[q]) in top[q] else 0.0 for q in range(top.shape[0])]))
+    hit = (top == _exact_docs(qrels, top.shape[0])[:, None]).any(axis=1)
+    return float(np.mean(hit.astype(float)))
 
 
 def mrr_at_k(sim_matrix, qrels, k=None):
@@ -169,11 +183,10 @@ def mrr_at_k(sim_matrix, qrels, k=None):
         ranks = sim_matrix.rank_of(docs)
         return float(np.mean([1.0 / (r + 1) if (r >= 0 and (k is None or r < k)) else 0.0 for r in ranks]))
     top = _top(sim_matrix, k)
-    rr = []
-    for q in range(top.shape[0]):
-        pos = np.flatnonzero(top[q] == _exact_doc(qrels[q]))
-        rr.append(1.0 / (int(pos[0]) + 1) if pos.size else 0.0)
-    return float(np.mean(rr))
+    match = top == _exact_docs(qrels, top.shape[0])[:, None]
+    if match.shape[1] == 0:
+        return float(np.mean(np.zeros(match.shape[0])))
+    return float(np.mean(np.where(match.any(axis=1), 1.0 / (match.argmax(axis=1) + 1), 0.0)))
 
 
 def _generate_qrels(queries, slogans):
@@ -206,16 +219,51 @@ def _dcg_from_rels(rels, gain="exp"):
     return float(np.sum(gains * (1.0 / np.log2(np.arange(2, rels.size + 2)))))
 
 
+def _grade_matrix(top, qrels):
+    """``[Q x k]`` grades of the selected docs (`_get_rels_sparse` for every query at once: one dict lookup per selected doc)."""
+    empty = {}
+    return np.array([[(qrels.get(q) or empty).get(d, 0.0) for d in row] for q, row in enumerate(top.tolist())],
+                    dtype=float).reshape(top.shape)
+
+
+def _per_query(arrays, fn):
+    """``fn`` (a reduction over axis 1) of every query's array, queries with arrays of one length stacked and reduced together:
+    the same values, summed in the same order as one array at a time."""
+    out = np.zeros(len(arrays))
+    lengths = np.array([a.size for a in arrays], dtype=np.int64)
+    for ln in np.unique(lengths):
+        if ln:
+            rows = np.flatnonzero(lengths == ln)
+            out[rows] = fn(np.stack([arrays[r] for r in rows]))
+    return out
+
+
+def _gains(rels, gain):
+    if gain == "exp":
+        return np.exp2(rels) - 1.0
+    if gain == "linear":
+        return rels
+    raise ValueError(f"Unknown gain scheme: {gain}")
+
+
 def ndcg_at_k(ranked, qrels, k=10, gain="exp"):
     top = _top(ranked, k)
-    out = []
-    for q in range(top.shape[0]):
-        rels_dict = qrels.get(q, {})
-        dcg = _dcg_from_rels(_get_rels_sparse(top[q], rels_dict, k), gain=gain)
-        ideal = np.sort(np.array(list(rels_dict.values()), dtype=float))[::-1]
-        idcg = _dcg_from_rels(ideal if k is None else ideal[:k], gain=gain)
-        out.append(0.0 if idcg == 0.0 else dcg / idcg)
-    return float(np.mean(out))
+    nq, kk = top.shape
+    dicts = [qrels.get(q, {}) for q in range(nq)]
+    if kk == 0 or not all(dicts):
+        # some DCG is taken of nothing: the reference says "TOO SMALL" once per such call, in query order - one query at a time
+        out = []
+        for q in range(nq):
+            dcg = _dcg_from_rels(_get_rels_sparse(top[q], dicts[q], k), gain=gain)
+            ideal = np.sort(np.array(list(dicts[q].values()), dtype=float))[::-1]
+            idcg = _dcg_from_rels(ideal if k is None else ideal[:k], gain=gain)
+            out.append(0.0 if idcg == 0.0 else dcg / idcg)
+        return float(np.mean(out))
+    # every query at once; sums run over the same values in the same order as `_dcg_from_rels` on one query's row
+    dcg = np.sum(_gains(_grade_matrix(top, qrels), gain) * (1.0 / np.log2(np.arange(2, kk + 2))), axis=1)
+    ideals = [np.sort(np.array(list(d.values()), dtype=float))[::-1][:k] for d in dicts]
+    idcg = _per_query(ideals, lambda a: np.sum(_gains(a, gain) * (1.0 / np.log2(np.arange(2, a.shape[1] + 2))), axis=1))
+    return float(np.mean(np.divide(dcg, idcg, out=np.zeros(nq), where=idcg != 0.0)))
 
 
 def _max_grade(qrels):
@@ -233,23 +281,22 @@ def err_at_k(ranked, qrels, k=10, max_rel=None):
         if max_rel <= 0.0:
             return 0.0
     denom = 2.0 ** max_rel
-    out = []
-    for q in range(top.shape[0]):
-        rels_dict = qrels.get(q, None)
-        if not rels_dict:
-            out.append(0.0)
-            continue
-        rels = _get_rels_sparse(top[q], rels_dict, k=k)
-        stop_prob = (np.exp2(rels) - 1.0) / denom
-        err_q, going = 0.0, 1.0
-        for i, p in enumerate(stop_prob, start=1):
-            if p > 0.0:
-                err_q += going * p * (1.0 / i)
-            going *= (1.0 - p)
-            if p > 0.0 and going <= 1e-12:
-                break
-        out.append(err_q)
-    return float(np.mean(out)) if out else 0.0
+    nq, kk = top.shape
+    if nq == 0:
+        return 0.0
+    judged = np.array([bool(qrels.get(q, None)) for q in range(nq)])
+    if kk == 0:
+        return float(np.mean(np.zeros(nq)))
+    # the cascade of reference lines 295-307 for every query at once: `going` before rank i is the running product of
+    # (1 - p) over the ranks above it (accumulated in rank order, as the loop does), a query stops counting behind the first
+    # rank that leaves going <= 1e-12, and the terms are added in rank order
+    p = (np.exp2(_grade_matrix(top, qrels)) - 1.0) / denom
+    after = np.multiply.accumulate(1.0 - p, axis=1)
+    before = np.concatenate([np.ones((nq, 1)), after[:, :-1]], axis=1)
+    stop = np.logical_or.accumulate((p > 0.0) & (after <= 1e-12), axis=1)
+    counted = (p > 0.0) & ~np.concatenate([np.zeros((nq, 1), dtype=bool), stop[:, :-1]], axis=1)
+    terms = np.where(counted, before * p * (1.0 / np.arange(1, kk + 1)), 0.0)
+    return float(np.mean(np.where(judged, np.add.accumulate(terms, axis=1)[:, -1], 0.0)))
 
 
 def q_measure_at_k(ranked, qrels, k=10, max_rel=None):
@@ -259,21 +306,17 @@ def q_measure_at_k(ranked, qrels, k=10, max_rel=None):
         if max_rel <= 0.0:
             return 0.0
     denom = 2.0 ** max_rel
-    out = []
-    for q in range(top.shape[0]):
-        rels_dict = qrels.get(q, None)
-        if not rels_dict:
-            out.append(0.0)
-            continue
-        ideal_gain = ((np.exp2(np.array(list(rels_dict.values()), dtype=float)) - 1.0) / denom).sum()
-        if ideal_gain <= 0.0:
-            out.append(0.0)
-            continue
-        gains = (np.exp2(_get_rels_sparse(top[q], rels_dict, k=k)) - 1.0) / denom
-        cum = total = 0.0
-        for i, g in enumerate(gains, start=1):
-            if g > 0.0:
-                cum += g
-                total += g * (cum / i)
-        out.append(total / ideal_gain)
-    return float(np.mean(out)) if out else 0.0
+    nq, kk = top.shape
+    if nq == 0:
+        return 0.0
+    dicts = [qrels.get(q, None) or {} for q in range(nq)]
+    ideal_gain = _per_query([np.array(list(d.values()), dtype=float) for d in dicts],
+                            lambda a: ((np.exp2(a) - 1.0) / denom).sum(axis=1))
+    if kk == 0:
+        return float(np.mean(np.zeros(nq)))
+    # reference lines 347-369 for every query at once: the cumulated gain and the total are running sums in rank order
+    gains = (np.exp2(_grade_matrix(top, qrels)) - 1.0) / denom
+    pos = gains > 0.0
+    cum = np.add.accumulate(np.where(pos, gains, 0.0), axis=1)
+    total = np.add.accumulate(np.where(pos, gains * (cum / np.arange(1, kk + 1)), 0.0), axis=1)[:, -1]
+    return float(np.mean(np.divide(total, ideal_gain, out=np.zeros(nq), where=ideal_gain > 0.0)))
