@@ -228,6 +228,90 @@ def test_pgvector_text_rows_parse_like_vector_in():
     assert empty.shape == (0, 3) and used == 0
 
 
+def _parse_vectors_restated(buf: bytes, d: int, max_rows: int):
+    """What ts_parse_pgvector_text promises, said again in Python: ``(rows, consumed)`` or None where it refuses the text."""
+    ws, n, pos, done, rows = b" \t\n\r\x0b\x0c", len(buf), 0, 0, []
+    while len(rows) < max_rows:
+        i = buf.find(b"[", pos)
+        if i < 0:
+            break
+        p, vals, closed = i + 1, [], False
+        while p < n:
+            while p < n and (buf[p] in ws or buf[p] == 0x2C):
+                p += 1
+            if p < n and buf[p] == 0x5D:
+                closed, p = True, p + 1
+                break
+            t0 = p
+            while p < n and buf[p] not in (0x2C, 0x5D) and buf[p] not in ws and p - t0 < 63:
+                p += 1
+            if p >= n:
+                break                                   # cut off by the end of the buffer: left for the next call
+            tok = buf[t0:p]
+            if len(tok) == 63 and buf[p] not in (0x2C, 0x5D) and buf[p] not in ws:
+                return None
+            if any(c not in b"0123456789+-.eE" for c in tok):
+                return None
+            try:
+                v = float(tok)
+            except ValueError:
+                return None
+            with np.errstate(over="ignore"):
+                v = np.float32(v)
+            if not np.isfinite(v) or len(vals) >= d:
+                return None
+            vals.append(v)
+        if not closed:
+            break
+        if len(vals) != d:
+            return None
+        rows.append(vals)
+        pos = done = p
+    return np.array(rows, dtype=np.float32).reshape(len(rows), d), done
+
+
+def test_pgvector_parser_agrees_with_a_restatement_on_random_text():
+    """Differential test of the C parser on seeded random text - well-formed rows, rows cut anywhere, stray brackets, signs,
+    exponents, over-long literals, NUL bytes: the same rows and the same resume offset, or a refusal where the restatement
+    refuses.  (TS_FUZZ_CASES raises the case count; run once under a host AddressSanitizer build, profiles/HISTORY.md.)"""
+    import ctypes as C
+    from theoremsearch_amd import _ffi
+    lib = _ffi.load()
+    rng = np.random.default_rng(20261005)
+    alphabet = [b"[", b"]", b",", b" ", b"\n", b"\t", b"1", b"23", b"0.5", b"-", b"+", b".", b"e", b"E-3", b"7e2", b"x", b"\x00", b"9" * 70,
+                b"1e50", b"nan", b"[1,2,3]", b"[4.25, -1e-3,0]", b"17\t"]
+    cases = int(os.environ.get("TS_FUZZ_CASES", "400"))
+    refused = parsed = 0
+    for _ in range(cases):
+        d = int(rng.integers(1, 5))
+        if rng.random() < 0.5:                          # mostly well-formed rows of this d, then damaged
+            rows = [b"%d\t[" % i + b",".join(repr(float(np.float32(v))).encode() for v in rng.standard_normal(d)) + b"]\n"
+                    for i in range(int(rng.integers(0, 6)))]
+            buf = bytearray(b"".join(rows))
+            for _ in range(int(rng.integers(0, 3))):
+                if buf:
+                    at = int(rng.integers(len(buf)))
+                    buf[at:at + int(rng.integers(0, 2))] = alphabet[int(rng.integers(len(alphabet)))]
+            buf = bytes(buf[: int(rng.integers(0, len(buf) + 1))]) if rng.random() < 0.5 else bytes(buf)
+        else:
+            buf = b"".join(alphabet[int(j)] for j in rng.integers(0, len(alphabet), size=int(rng.integers(0, 40))))
+        max_rows = int(rng.integers(0, 8))
+        out = np.full((max_rows + 1, d), np.float32(-77.0))           # one row more than allowed: must stay untouched
+        nrows, used = C.c_int64(-1), C.c_int64(-1)
+        rc = lib.ts_parse_pgvector_text(buf, len(buf), d, _ffi.as_ptr(out), max_rows, C.byref(nrows), C.byref(used))
+        want = _parse_vectors_restated(buf, d, max_rows)
+        if want is None:
+            assert rc != 0, buf
+            refused += 1
+        else:
+            assert rc == 0, (buf, _ffi.last_error() if hasattr(_ffi, "last_error") else rc)
+            assert nrows.value == want[0].shape[0] and used.value == want[1], (buf, nrows.value, used.value, want)
+            assert np.array_equal(out[: nrows.value], want[0]), buf
+            parsed += 1
+        assert np.all(out[max_rows] == np.float32(-77.0)), buf
+    assert refused > cases // 20 and parsed > cases // 4           # the generator reaches both outcomes
+
+
 def test_showcase_loaders(tmp_path, monkeypatch):
     """app_showcase_model.load_model / load_embedding_library (app_showcase_model.py:32-58): the model or the error that
     stopped it (the app displays it), the library or (None, None)."""
