@@ -157,6 +157,16 @@ inline int ensure(void** p, size_t* have, size_t want) {
     return TS_OK;
 }
 
+// The staging buffer between host and device holds what ONE call moves, up to kStageBytes (larger transfers pass through it in
+// pieces), in steps of 1 MiB; it only grows.  (A fixed 256 MiB per index cost the throw-away index of util.cos_sim -
+// compare_embeddings.py:61, a thousand rows - 5.6 ms of hipMalloc in its upload and 0.9 ms of hipFree in its close around a
+// 0.4 ms score kernel: profiles/r05m_cos_sim_phases.json.)  `floor_bytes`: the largest single piece the caller will put there.
+inline int ensure_stage(ts_index* ix, size_t need, size_t floor_bytes) {
+    const size_t gran = (size_t)1 << 20;
+    const size_t want = std::max(std::min(kStageBytes, need), std::max(floor_bytes, (size_t)1));
+    return ensure(&ix->stage, &ix->stage_bytes, (want + gran - 1) / gran * gran);
+}
+
 // Event bracket around one launch: prof_begin records the start event and returns the stop event
 // (NULL when profiling is off); the caller records it with prof_end after the launch.
 inline hipEvent_t prof_begin(ts_index* ix, hipStream_t st, int64_t rows) {

@@ -324,8 +324,8 @@ static int upload_host_locked(ts_index* ix, const void* host_rows, int src_dtype
         HIP_TRY(hipStreamSynchronize(own));
         return TS_OK;
     }
-    TS_TRY(ensure(&ix->stage, &ix->stage_bytes, kStageBytes));
-    const int64_t rows_per = std::max<int64_t>(1, (int64_t)(kStageBytes / src_row));
+    TS_TRY(ensure_stage(ix, (size_t)nrows * src_row, src_row));
+    const int64_t rows_per = std::max<int64_t>(1, (int64_t)(ix->stage_bytes / src_row));
     for (int64_t r = 0; r < nrows; r += rows_per) {
         const int64_t cnt = std::min(rows_per, nrows - r);
         HIP_TRY(hipMemcpyAsync(ix->stage, (const char*)host_rows + (size_t)r * src_row, (size_t)cnt * src_row,
@@ -463,11 +463,11 @@ extern "C" int ts_index_download(ts_index* ix, void* host_rows, int64_t row0, in
     if (nrows == 0) return TS_OK;
     HIP_TRY(hipSetDevice(ix->device));
     const size_t row_bytes = (size_t)ix->d * ix->elem();
-    TS_TRY(ensure(&ix->stage, &ix->stage_bytes, kStageBytes));
     hipStream_t own;
     StreamScope scope;
     TS_TRY(enter_stream(ix, nullptr, &own, &scope));
-    const int64_t rows_per = std::max<int64_t>(1, (int64_t)(kStageBytes / row_bytes));
+    TS_TRY(ensure_stage(ix, (size_t)nrows * row_bytes, row_bytes));
+    const int64_t rows_per = std::max<int64_t>(1, (int64_t)(ix->stage_bytes / row_bytes));
     for (int64_t r = 0; r < nrows; r += rows_per) {
         const int64_t cnt = std::min(rows_per, nrows - r);
         const char* src = (const char*)ix->rows + (size_t)(row0 + r) * ix->ld * ix->elem();

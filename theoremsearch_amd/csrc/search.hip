@@ -332,7 +332,7 @@ static int search_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_
         didx = ix->res_idx;
     }
     const size_t q_elem = q_dtype == TS_BF16 ? 2 : 4;
-    if (!q_on_device) TS_TRY(ensure(&ix->stage, &ix->stage_bytes, kStageBytes));
+    if (!q_on_device) TS_TRY(ensure_stage(ix, (size_t)std::min(nq, kQBlock) * ix->d * q_elem, 0));   // one block of queries at a time
 
     // queries are served in blocks: 256 per pass, or what one launch of the MFMA kernel holds
     const int block = (use == TS_ALGO_MFMA) ? mfma_block_queries(ix, nq) : kQBlock;
@@ -507,7 +507,7 @@ static int rank_impl(ts_index* ix, const void* queries, int q_dtype, int q_on_de
     unsigned long long* d_counts = (unsigned long long*)(d_target + kQBlock);
     float* d_tscore = (float*)(d_counts + kQBlock);
     const size_t q_elem = q_dtype == TS_BF16 ? 2 : 4;
-    if (!q_on_device) TS_TRY(ensure(&ix->stage, &ix->stage_bytes, kStageBytes));
+    if (!q_on_device) TS_TRY(ensure_stage(ix, (size_t)std::min(nq, kQBlock) * ix->d * q_elem, 0));   // one block of queries at a time
     std::vector<int64_t> local(kQBlock);
     std::vector<unsigned long long> counts(kQBlock);
     std::vector<float> tscore(kQBlock);
@@ -604,7 +604,7 @@ extern "C" int ts_scores(ts_index* ix, const void* queries, int q_dtype, int q_o
         dout = tmp.as<float>();
     }
     const size_t q_elem = q_dtype == TS_BF16 ? 2 : 4;
-    if (!q_on_device) TS_TRY(ensure(&ix->stage, &ix->stage_bytes, kStageBytes));
+    if (!q_on_device) TS_TRY(ensure_stage(ix, (size_t)std::min(nq, kQBlock) * ix->d * q_elem, 0));   // one block of queries at a time
     int rc = TS_OK;
     for (int q0 = 0; q0 < nq && rc == TS_OK; q0 += kQBlock) {
         const int nb = std::min(kQBlock, nq - q0);
