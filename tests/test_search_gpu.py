@@ -254,11 +254,12 @@ def test_paired_full_pass_at_d1024_answers_like_two_launches(ts, nq):
             assert np.array_equal(out_i.cpu().numpy(), want_i) and np.array_equal(out_s.cpu().numpy(), want_s)
 
 
-@pytest.mark.parametrize("n,grid", [(700, 16), (3_000, 16), (3_000, 32), (9_001, 256), (40_000, 48), (131_072, 256)])
+@pytest.mark.parametrize("n,grid", [(700, 16), (3_000, 16), (3_000, 32), (9_001, 256), (40_000, 48), (131_072, 256), (131_072, 1024)])
 def test_k_split_pairs_on_short_and_odd_tile_ranges(ts, n, grid):
     """The k-split form tests a tile one tile late (the partner's half arrives during the next tile) and keeps its sums in two
     register halves by tile parity: tile ranges of 0, 1, 2, 3 ... tiles per pair, odd and even, a ragged last tile, ranges that
-    end inside the steady part of the loop and ranges that never reach it - against the oracle and the other form."""
+    end inside the steady part of the loop and ranges that never reach it, more workgroups than CUs (the pairs' position words are one
+    per workgroup of the grid) - against the oracle and the other form."""
     q, c = oracle.inputs(n, 256, 1024, 9100 + n + grid, "ip")
     with ts.TheoremIndex.from_embeddings(c, dtype="bf16", metric="ip") as ix:
         ix.set_option("TS_MFMA_GRID", grid)

@@ -131,7 +131,7 @@ struct ts_index {
     bool ordered = false;                                    //   next call behind it (`ordered`: recorded at least once)
     int64_t* part = nullptr;    unsigned* wg_ticks = nullptr;    // full pass of the 16x16 kernel: tile boundaries per workgroup, their times
     int part_g = 0;             int64_t part_ntiles = -1;        // ... the grid and tile count the table was made for
-    unsigned* pair_pos = nullptr;                            // paired full pass: the tile each workgroup has reached (2 x 128 words)
+    unsigned* pair_pos = nullptr;                            // paired full pass: the tile each workgroup has reached (one word per workgroup of the largest grid)
     unsigned long long* dbg = nullptr;                       // TS_MFMA_VARIANT=3: per-wave cycle sums / clock probe
     double probe_ghz = 0.0, probe_cycles_per_unit = 0.0, probe_units = 0.0;   // last clock probe (16x16 shape, VARIANT 3)
     // optional event brackets around the dominant kernel (ts_index_profile_*)

@@ -91,7 +91,8 @@ static std::vector<Level> plan_levels(const Knobs& kn, int64_t n, int kk, bool s
 // workgroup.  A batch of 193 .. 256 queries runs as ONE launch of workgroup PAIRS (MfmaArgs::pair): both workgroups of a pair
 // walk the same tiles with 128 queries each, two blocks per wave, so the corpus crosses HBM once for the whole batch (the
 // pair's second read of a tile is served by the XCD's L2 / the memory-side cache) instead of once per 128 queries.
-static int mfma_grid(const ts_index* ix) { return std::max(1, std::min(ix->knobs.get(K_MFMA_GRID, ix->cu_count), 2048)); }
+constexpr int kMfmaMaxGrid = 2048;   // workgroups of one pass (TS_MFMA_GRID is clamped to it; the pairs' position words are sized by it)
+static int mfma_grid(const ts_index* ix) { return std::max(1, std::min(ix->knobs.get(K_MFMA_GRID, ix->cu_count), kMfmaMaxGrid)); }
 static bool mfma_pairs(const ts_index* ix, int nq) {
     return ix->dtype == TS_BF16 && ix->d == 1024 && nq > 192 && use_shape16(ix) && two_level_search(ix) &&
            ix->knobs.get(K_MFMA_PAIR, 1) != 0 && mfma_grid(ix) % 16 == 0;
@@ -295,8 +296,9 @@ int mfma_search(ts_index* ix, int nq, int k, float* out_scores, int64_t* out_idx
         a.pair_lag = 0;
         if (a.pair && ix->knobs.get(K_MFMA_PAIR_LAG, 1) > 0) {
             if (!ix->pair_pos) {
-                HIP_TRY(hipMalloc((void**)&ix->pair_pos, 2 * 256 * sizeof(unsigned)));
-                HIP_TRY(hipMemsetAsync(ix->pair_pos, 0, 2 * 256 * sizeof(unsigned), st));
+                // one word per workgroup of the pass (index 2 * pair + half < grid): sized for the largest grid the option allows
+                HIP_TRY(hipMalloc((void**)&ix->pair_pos, kMfmaMaxGrid * sizeof(unsigned)));
+                HIP_TRY(hipMemsetAsync(ix->pair_pos, 0, kMfmaMaxGrid * sizeof(unsigned), st));
             }
             a.pair_pos = ix->pair_pos;
             a.pair_lag = ix->knobs.get(K_MFMA_PAIR_LAG, 1);
